@@ -1,0 +1,347 @@
+// Scene authoring on the host: OBJ loader (loader.rs:12-59), Camera::new (camera.rs:45-64),
+// hsv_to_rgb (color.rs:50-61) and the scene builders that BASELINE.json's configs need
+// (main.rs:1020-1153 is the live one).  Output is an hr_scene_desc for hr_upload_scene().
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hanamaru_host.h"
+#include "hh_isaac64.h"
+#include "hh_math.h"
+
+using namespace hh;
+
+struct hh_scene {
+    std::vector<hr_element> elements;
+    std::deque<std::vector<hr_vec3>> vertex_store;
+    std::deque<std::vector<uint64_t>> face_store;
+    std::deque<std::vector<uint8_t>> image_store;
+    std::vector<hr_image> images;
+    hr_scene_desc desc{};
+    std::string root;
+};
+
+namespace {
+
+// --- loader.rs:21-56: split on single ' ', "v x y z" -> matrix * v, "f a[/..] b c [d]" 1-based, quad iff 5 tokens
+static bool load_obj(const std::string &path, const M44 &m, std::vector<hr_vec3> &verts, std::vector<uint64_t> &faces) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { set_error("cannot open %s", path.c_str()); return false; }
+    std::string line;
+    std::vector<std::string> tok;
+    char buf[1 << 16];
+    auto first_index = [](const std::string &t) -> long long {
+        return atoll(t.substr(0, t.find('/')).c_str()) - 1;
+    };
+    while (fgets(buf, sizeof buf, f)) {
+        line = buf;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        tok.clear();
+        size_t s = 0;
+        for (;;) {
+            size_t e = line.find(' ', s);
+            tok.push_back(line.substr(s, e == std::string::npos ? std::string::npos : e - s));
+            if (e == std::string::npos) break;
+            s = e + 1;
+        }
+        if (tok[0] == "v") {
+            if (tok.size() < 4) { set_error("%s: malformed v line", path.c_str()); fclose(f); return false; }
+            V3 local(strtod(tok[1].c_str(), nullptr), strtod(tok[2].c_str(), nullptr), strtod(tok[3].c_str(), nullptr));
+            verts.push_back((m * local).c());
+        } else if (tok[0] == "f") {
+            if (tok.size() < 4) { set_error("%s: malformed f line", path.c_str()); fclose(f); return false; }
+            long long a = first_index(tok[1]), b = first_index(tok[2]), c = first_index(tok[3]);
+            faces.push_back((uint64_t)a); faces.push_back((uint64_t)b); faces.push_back((uint64_t)c);
+            if (tok.size() == 5) {  // quad -> (0,1,2) + (0,2,3)
+                long long d = first_index(tok[4]);
+                faces.push_back((uint64_t)a); faces.push_back((uint64_t)c); faces.push_back((uint64_t)d);
+            }
+        }
+    }
+    fclose(f);
+    for (uint64_t idx : faces)
+        if (idx >= verts.size()) { set_error("%s: face index out of range", path.c_str()); return false; }
+    return true;
+}
+
+static double saturate(double v) { return std::fmin(std::fmax(v, 0.0), 1.0); }
+
+// color.rs:50-61
+static V3 hsv_to_rgb(double h, double s, double v) {
+    V3 hue(saturate(std::fabs(h * 6.0 - 3.0) - 1.0), saturate(2.0 - std::fabs(h * 6.0 - 2.0)),
+           saturate(2.0 - std::fabs(h * 6.0 - 4.0)));
+    return V3(((hue.x - 1.0) * s + 1.0) * v, ((hue.y - 1.0) * s + 1.0) * v, ((hue.z - 1.0) * s + 1.0) * v);
+}
+
+static hr_texture tex_color(V3 c) { hr_texture t{}; t.color = c.c(); t.image = -1; return t; }
+static hr_texture tex_one(double v) { return tex_color(V3(v, v, v)); }
+static hr_texture tex_image(int img, V3 tint = V3(1, 1, 1)) { hr_texture t{}; t.color = tint.c(); t.image = img; return t; }
+
+static hr_material mat(int surface, double param, hr_texture albedo, hr_texture emission, hr_texture roughness) {
+    hr_material m{};
+    m.surface = surface; m.param = param; m.albedo = albedo; m.emission = emission; m.roughness = roughness;
+    return m;
+}
+
+struct Builder {
+    hh_scene *sc;
+    bool ok = true;
+
+    int add_image_file(const std::string &rel) {
+        uint8_t *px = nullptr;
+        uint32_t w = 0, h = 0;
+        std::string p = sc->root + "/" + rel;
+        if (hh_decode_image(p.c_str(), &px, &w, &h) != HR_OK) { ok = false; return -1; }
+        sc->image_store.emplace_back(px, px + (size_t)w * h * 4);
+        free(px);
+        sc->images.push_back(hr_image{sc->image_store.back().data(), w, h});
+        return (int)sc->images.size() - 1;
+    }
+    int add_image_rgba(std::vector<uint8_t> &&px, uint32_t w, uint32_t h) {
+        sc->image_store.emplace_back(std::move(px));
+        sc->images.push_back(hr_image{sc->image_store.back().data(), w, h});
+        return (int)sc->images.size() - 1;
+    }
+    void add_sphere(V3 c, double r, hr_material m) {
+        hr_element e{};
+        e.kind = HR_SPHERE; e.material = m; e.center = c.c(); e.radius = r;
+        sc->elements.push_back(e);
+    }
+    void add_cuboid(V3 mn, V3 mx, hr_material m) {
+        hr_element e{};
+        e.kind = HR_CUBOID; e.material = m; e.aabb_min = mn.c(); e.aabb_max = mx.c();
+        sc->elements.push_back(e);
+    }
+    void add_mesh(const std::string &rel, const M44 &mtx, hr_material m) {
+        sc->vertex_store.emplace_back();
+        sc->face_store.emplace_back();
+        if (!load_obj(sc->root + "/" + rel, mtx, sc->vertex_store.back(), sc->face_store.back())) { ok = false; return; }
+        hr_element e{};
+        e.kind = HR_MESH; e.material = m;
+        e.vertexes = sc->vertex_store.back().data(); e.num_vertexes = sc->vertex_store.back().size();
+        e.faces = sc->face_store.back().data(); e.num_faces = sc->face_store.back().size() / 3;
+        sc->elements.push_back(e);
+    }
+    // scene.rs:82-87 / bvh.rs:14-18 / scene.rs:366-376: strict-inequality AABB overlap test against all elements
+    bool sphere_collides(V3 c, double r) const {
+        for (const auto &e : sc->elements) {
+            if (e.kind != HR_SPHERE) continue;
+            V3 oc(e.center);
+            double orr = e.radius;
+            bool hit = (oc.x - orr) < (c.x + r) && (oc.x + orr) > (c.x - r) && (oc.y - orr) < (c.y + r) &&
+                       (oc.y + orr) > (c.y - r) && (oc.z - orr) < (c.z + r) && (oc.z + orr) > (c.z - r);
+            if (hit) return true;
+        }
+        return false;
+    }
+    void skybox(const char *dir, V3 intensity) {
+        static const char *names[6] = {"posx.jpg", "negx.jpg", "posy.jpg", "negy.jpg", "posz.jpg", "negz.jpg"};
+        for (int i = 0; i < 6; i++) sc->desc.skybox.face_image[i] = add_image_file(std::string(dir) + "/" + names[i]);
+        sc->desc.skybox.intensity = intensity.c();
+    }
+};
+
+// main.rs:1020-1153
+static void build_rtcamp6_v3_1(Builder &b, bool with_dodecahedron) {
+    const double scene_scale = 1.0;
+    double theta = PI2 * 0.03;
+    double r = 6.5 * scene_scale;
+    hh_camera_new(V3(r * std::sin(theta), 2.0 * scene_scale, r * std::cos(theta)).c(), V3(0.0, 1.0 * scene_scale, 0.0).c(),
+                  normalize(V3(0, 1, 0)).c(), 20.0, 1, 0.03, 5.0 * scene_scale, &b.sc->desc.camera);
+
+    double radius = 0.2, floor_s = 9.0 * scene_scale;
+    // 0: light
+    b.add_sphere(V3(-0.3, 0.5 + radius, 0.0) * scene_scale, radius * scene_scale,
+                 mat(HR_DIFFUSE, 0, tex_one(0), tex_color(V3(30.0, 20.0, 4.0)), tex_one(0)));
+    // 1: bunny
+    b.add_mesh("models/bunny/bunny_wired_300.obj",
+               M44::scale_linear(1.5 * scene_scale) * M44::translate(0, 0, 0) * M44::rotate_y(0.3),
+               mat(HR_GGX, 0.8, tex_color(V3(1.0, 0.01, 0.01)), tex_one(0), tex_one(0.05)));
+    // 2: mirror
+    b.add_mesh("models/box.obj",
+               M44::translate(1.0 * scene_scale, 0.0, -3.0 * scene_scale) * M44::rotate_y(-PI / 8.0) *
+                   M44::scale(4.0 * 0.9 * scene_scale, 3.0 * 0.9 * scene_scale, 0.1 * 0.9 * scene_scale),
+               mat(HR_SPECULAR, 0, tex_one(1), tex_one(0), tex_one(0)));
+    // 3: picture frame
+    b.add_mesh("models/picture_frame.obj",
+               M44::translate(1.0 * scene_scale, 0.0, -3.0 * scene_scale) * M44::rotate_y(-PI / 8.0) *
+                   M44::scale(4.0 * scene_scale, 3.0 * scene_scale, scene_scale),
+               mat(HR_GGX, 0.9, tex_color(V3(0.33, 0.27, 0.22)), tex_one(0), tex_one(0.3)));
+    // 4: floor
+    int floor_img = b.add_image_file("textures/2d/magic-circle3.png");
+    b.add_cuboid(V3(-floor_s, -1.0, -floor_s), V3(floor_s, 0.0, floor_s),
+                 mat(HR_DIFFUSE, 0, tex_image(floor_img), tex_one(0), tex_one(1)));
+    b.skybox("textures/cube/Powerlines", V3(1, 1, 1));
+
+    // 5..10: armadillos
+    const int count = 6;
+    for (int i = 0; i < count; i++) {
+        double rr = 2.2 * scene_scale;
+        double dr = (double)i / (double)count;
+        double th = PI2 * dr;
+        double px = rr * std::sin(th), py = 0.0, pz = rr * std::cos(th);
+        double offset = 0.45;
+        double hue = (offset + dr) - std::trunc(offset + dr);  // f64::fract
+        hr_material m = (i % 2 == 0)
+                            ? mat(HR_REFRACTION, 1.5, tex_color(hsv_to_rgb(hue, 0.2, 1.0)), tex_one(0), tex_one(0.1))
+                            : mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(hue, 1.0, 1.0)), tex_one(0), tex_one(0.05 * (double)i));
+        b.add_mesh("models/armadilo_1000.obj", M44::translate(px, py, pz) * M44::rotate_y(th) * M44::scale_linear(scene_scale), m);
+    }
+    if (with_dodecahedron) {
+        // BASELINE config 5 (build-defined placement): material of main.rs:910-915
+        b.add_mesh("models/fractal_dodecahedron.obj", M44::translate(0.0, 3.2, -1.0) * M44::scale_linear(0.6),
+                   mat(HR_REFRACTION, 1.5, tex_color(V3(0.7, 0.7, 1.0)), tex_one(0), tex_one(0.1)));
+    }
+}
+
+// BASELINE config 2 (build-defined): sphere generator of main.rs:862-905
+static void build_spheres(Builder &b) {
+    const uint64_t seed[4] = {870, 2000, 304, 2};  // main.rs:805
+    Isaac64 rng;
+    rng.from_seed(seed, 4);
+    hh_camera_new(V3(-5.0, -1.0, 0.0).c(), V3(0, 0, 0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8,
+                  &b.sc->desc.camera);
+    // the reference scene uses the Ryfjallet cubemap (7.5 MB); the build ships only Powerlines, same intensity 0.5
+    b.skybox("textures/cube/Powerlines", V3(0.5, 0.5, 0.5));
+    int count = 0;
+    while (count < 100) {
+        // every attempt consumes 5 draws: px, py, pz, hue, roughness (struct-literal evaluation order)
+        double px = rng.gen_range(-0.5, 2.0), py = rng.gen_range(-2.0, 2.0), pz = rng.gen_range(-2.0, 2.0);
+        double s = 0.1;
+        double hue = rng.gen_range(0.0, 1.0);
+        double rough = rng.gen_range(0.0, 1.0);
+        if (!b.sphere_collides(V3(px, py, pz), s)) {
+            int surface = (count % 2 == 0) ? HR_DIFFUSE : HR_SPECULAR;
+            b.add_sphere(V3(px, py, pz), s, mat(surface, 0, tex_color(hsv_to_rgb(hue, 1.0, 1.0)), tex_one(0), tex_one(rough)));
+            count++;
+        }
+    }
+    count = 0;
+    while (count < 5) {
+        double px = rng.gen_range(-0.2, 0.5), py = rng.gen_range(-1.0, 1.0), pz = rng.gen_range(-1.0, 1.0);
+        double s = 0.1;
+        double hue = rng.gen_range(0.0, 1.0);
+        double rough = rng.gen_range(0.0, 1.0);
+        if (!b.sphere_collides(V3(px, py, pz), s)) {
+            b.add_sphere(V3(px, py, pz), s, mat(HR_DIFFUSE, 0, tex_one(0), tex_color(hsv_to_rgb(hue, 1.0, 1.0) * 10.0), tex_one(rough)));
+            count++;
+        }
+    }
+}
+
+// Small build-defined scene for tests: every surface type, a textured sphere (lat-long UV), textured
+// cuboid, a mesh, two NEE emitters, procedural cubemap.  No asset files needed except models/box.obj.
+static void build_cornell_mini(Builder &b) {
+    hh_camera_new(V3(0.3, 1.6, 5.5).c(), V3(0, 0.8, 0).c(), normalize(V3(0, 1, 0)).c(), 18.0, 1, 0.05, 5.4, &b.sc->desc.camera);
+    auto checker = [](uint32_t n, uint32_t cells, uint8_t lo, uint8_t hi, bool colour) {
+        std::vector<uint8_t> px((size_t)n * n * 4);
+        for (uint32_t y = 0; y < n; y++)
+            for (uint32_t x = 0; x < n; x++) {
+                bool on = ((x * cells / n) + (y * cells / n)) & 1;
+                uint8_t *o = &px[((size_t)y * n + x) * 4];
+                uint8_t v = on ? hi : lo;
+                o[0] = v; o[1] = colour ? (uint8_t)(x * 255 / n) : v; o[2] = colour ? (uint8_t)(y * 255 / n) : v; o[3] = 255;
+            }
+        return px;
+    };
+    int img_floor = b.add_image_rgba(checker(64, 8, 40, 230, false), 64, 64);
+    int img_ball = b.add_image_rgba(checker(32, 4, 60, 250, true), 32, 32);
+    int img_rough = b.add_image_rgba(checker(16, 4, 20, 120, false), 16, 16);
+    for (int f = 0; f < 6; f++) {
+        std::vector<uint8_t> px((size_t)16 * 16 * 4);
+        for (uint32_t y = 0; y < 16; y++)
+            for (uint32_t x = 0; x < 16; x++) {
+                uint8_t *o = &px[((size_t)y * 16 + x) * 4];
+                o[0] = (uint8_t)(40 + 30 * f + x * 4); o[1] = (uint8_t)(90 + y * 8); o[2] = (uint8_t)(200 - 20 * f); o[3] = 255;
+            }
+        b.sc->desc.skybox.face_image[f] = b.add_image_rgba(std::move(px), 16, 16);
+    }
+    b.sc->desc.skybox.intensity = V3(0.8, 0.9, 1.1).c();
+
+    b.add_cuboid(V3(-3, -0.5, -3), V3(3, 0, 3), mat(HR_GGX, 0.7, tex_image(img_floor), tex_one(0), tex_image(img_rough)));
+    b.add_sphere(V3(-1.2, 0.5, 0.2), 0.5, mat(HR_DIFFUSE, 0, tex_image(img_ball, V3(1.0, 0.9, 0.8)), tex_one(0), tex_one(1)));
+    b.add_sphere(V3(0.0, 0.45, -0.6), 0.45, mat(HR_SPECULAR, 0, tex_color(V3(0.95, 0.95, 0.9)), tex_one(0), tex_one(0)));
+    b.add_sphere(V3(1.1, 0.4, 0.5), 0.4, mat(HR_REFRACTION, 1.5, tex_color(V3(0.9, 1.0, 0.9)), tex_one(0), tex_one(0)));
+    b.add_sphere(V3(-0.3, 0.3, 1.2), 0.3, mat(HR_GGX_REFRACTION, 1.33, tex_color(V3(0.9, 0.9, 1.0)), tex_one(0), tex_one(0.2)));
+    b.add_sphere(V3(0.6, 1.9, 0.4), 0.25, mat(HR_DIFFUSE, 0, tex_one(0), tex_color(V3(18, 14, 9)), tex_one(0)));
+    b.add_sphere(V3(-1.6, 1.4, -0.8), 0.15, mat(HR_DIFFUSE, 0, tex_one(0), tex_image(img_ball, V3(25, 25, 40)), tex_one(0)));
+    b.add_mesh("models/box.obj", M44::translate(1.6, 0.0, -1.2) * M44::rotate_y(0.5) * M44::scale(0.8, 1.3, 0.8),
+               mat(HR_GGX, 0.6, tex_color(V3(0.8, 0.5, 0.2)), tex_one(0), tex_one(0.35)));
+    b.add_cuboid(V3(-2.6, 0.0, -2.2), V3(-1.9, 1.1, -1.6), mat(HR_DIFFUSE, 0, tex_color(V3(0.2, 0.4, 0.8)), tex_one(0), tex_one(1)));
+}
+
+}  // namespace
+
+extern "C" {
+
+void hh_camera_new(hr_vec3 eye_, hr_vec3 target_, hr_vec3 y_up_, double v_fov_deg, int32_t lens_shape, double aperture,
+                   double focus_distance, hr_camera *out) {
+    V3 eye(eye_), target(target_), y_up(y_up_);
+    double lens_radius = 0.5 * aperture;
+    double plane_half_height = std::tan(v_fov_deg * (PI / 180.0));  // camera.rs:48: tan of the FULL angle given
+    V3 forward = normalize(target - eye);
+    V3 right = normalize(cross(forward, y_up));
+    V3 up = normalize(cross(right, forward));
+    memset(out, 0, sizeof *out);
+    out->eye = eye.c(); out->right = right.c(); out->up = up.c(); out->forward = forward.c();
+    out->plane_half_right = (right * plane_half_height * focus_distance).c();
+    out->plane_half_up = (up * plane_half_height * focus_distance).c();
+    out->lens_radius = lens_radius; out->focus_distance = focus_distance; out->lens_shape = lens_shape;
+}
+
+int hh_load_obj(const char *path, const double *matrix, hr_vec3 **vertexes, uint64_t *num_vertexes, uint64_t **faces,
+                uint64_t *num_faces) {
+    if (!path || !vertexes || !num_vertexes || !faces || !num_faces) { set_error("hh_load_obj: null argument"); return HR_ERR_INVALID; }
+    M44 m = M44::identity();
+    if (matrix) memcpy(m.e, matrix, sizeof m.e);
+    std::vector<hr_vec3> v;
+    std::vector<uint64_t> f;
+    if (!load_obj(path, m, v, f)) return HR_ERR_INVALID;
+    *vertexes = (hr_vec3 *)malloc(v.size() * sizeof(hr_vec3) + 1);
+    memcpy(*vertexes, v.data(), v.size() * sizeof(hr_vec3));
+    *faces = (uint64_t *)malloc(f.size() * sizeof(uint64_t) + 1);
+    memcpy(*faces, f.data(), f.size() * sizeof(uint64_t));
+    *num_vertexes = v.size();
+    *num_faces = f.size() / 3;
+    return HR_OK;
+}
+
+int hh_scene_create(const char *name, const char *asset_root, hh_scene **out) {
+    if (!name || !asset_root || !out) { set_error("hh_scene_create: null argument"); return HR_ERR_INVALID; }
+    std::unique_ptr<hh_scene> sc(new hh_scene);
+    sc->root = asset_root;
+    Builder b{sc.get()};
+    std::string n = name;
+    for (int i = 0; i < 6; i++) sc->desc.skybox.face_image[i] = -1;
+    if (n == "rtcamp6_v3_1") build_rtcamp6_v3_1(b, false);
+    else if (n == "rtcamp6_dodeca") build_rtcamp6_v3_1(b, true);
+    else if (n == "spheres") build_spheres(b);
+    else if (n == "cornell_mini") build_cornell_mini(b);
+    else { set_error("unknown scene '%s'", name); return HR_ERR_INVALID; }
+    if (!b.ok) return HR_ERR_INVALID;
+    sc->desc.elements = sc->elements.data();
+    sc->desc.num_elements = (uint32_t)sc->elements.size();
+    sc->desc.images = sc->images.data();
+    sc->desc.num_images = (uint32_t)sc->images.size();
+    *out = sc.release();
+    return HR_OK;
+}
+
+const hr_scene_desc *hh_scene_desc(const hh_scene *scene) { return scene ? &scene->desc : nullptr; }
+void hh_scene_destroy(hh_scene *scene) { delete scene; }
+
+// test hook: first n next_u64 of StdRng::from_seed(seed) after skipping `skip` outputs
+int hh_debug_isaac64(const uint64_t *seed, int nseed, uint64_t skip, uint64_t *out, int n) {
+    Isaac64 r;
+    r.from_seed(seed, nseed);
+    for (uint64_t i = 0; i < skip; i++) r.next_u64();
+    for (int i = 0; i < n; i++) out[i] = r.next_u64();
+    return HR_OK;
+}
+
+}

@@ -1,0 +1,176 @@
+/*
+ * hanamaru_hip.h — C ABI of the MI355X back end for hanamaru-renderer's render loop.
+ *
+ * What this replaces in the reference (all citations into /root/reference/src):
+ *   - `Renderer::render`  (renderer.rs:25-46): the per-sampling, per-pixel, 2x2 sub-sample loop that
+ *     accumulates `calc_pixel` into `accumulation_buf`          -> hr_render()
+ *   - `PathTracingRenderer::calc_pixel` + `next_event_estimation` (renderer.rs:163-203, 269-296)
+ *     incl. everything below it (scene.rs / bvh.rs / material.rs / texture.rs / camera.rs:66-96)
+ *                                                               -> the HIP kernels behind hr_render()
+ *   - `Renderer::update_imgbuf` (renderer.rs:64-90): scale, tonemap.rs Reinhard, gamma, filter.rs
+ *     bilateral, color.rs quantise                              -> hr_resolve()
+ *
+ * The reference has no FFI; the seam is the `Renderer` trait (renderer.rs:20-25).  A Rust host keeps
+ * its Scene/Camera/Material builders, loader and PNG writer, fills an `hr_scene_desc` with pointers
+ * into its own `Vec<Vector3>` (Vector3 is #[repr(C)] {x,y,z: f64}, vector.rs:6-12) and calls these
+ * entry points from `Renderer::render`.  See INTEGRATION.md for the Rust `extern "C"` block.
+ *
+ * Conventions: every function returns 0 (HR_OK) or a negative hr_status; hr_last_error() gives text.
+ * No exceptions cross the boundary.  A context is bound to ONE GPU and is not thread-safe; multi-GPU
+ * is one context (one process) per GPU, sharded by sampling index (hr_render's `stride`).
+ * Host buffers passed in are copied — the caller keeps ownership.  No torch / STL types in signatures.
+ */
+#ifndef HANAMARU_HIP_H
+#define HANAMARU_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HR_ABI_VERSION 1
+
+typedef enum hr_status {
+    HR_OK = 0,
+    HR_ERR_INVALID = -1,      /* bad argument / call order */
+    HR_ERR_DEVICE = -2,       /* HIP runtime error (text in hr_last_error) */
+    HR_ERR_NO_SCENE = -3,
+    HR_ERR_NO_TARGET = -4,    /* hr_set_resolution not called */
+    HR_ERR_RNG_WINDOW = -5,   /* a path consumed more ISAAC-64 outputs than the stored window */
+    HR_ERR_UNSUPPORTED = -6
+} hr_status;
+
+/* vector.rs:6-12 — #[repr(C)] f64 triple */
+typedef struct hr_vec3 { double x, y, z; } hr_vec3;
+
+/* material.rs:9-15 SurfaceType.  `param` = f0 (GGX) or refractive_index (Refraction / GGXRefraction). */
+enum { HR_DIFFUSE = 0, HR_SPECULAR = 1, HR_REFRACTION = 2, HR_GGX = 3, HR_GGX_REFRACTION = 4 };
+
+/* texture.rs:72-75 Texture { image_texture: Option<ImageTexture>, color } */
+typedef struct hr_texture {
+    hr_vec3 color;            /* tint, multiplied with the bilinear sample (texture.rs:108-114) */
+    int32_t image;            /* index into hr_scene_desc.images, or -1 = constant colour */
+    int32_t _pad;
+} hr_texture;
+
+/* material.rs:17-23 Material */
+typedef struct hr_material {
+    int32_t surface;          /* HR_DIFFUSE ... */
+    int32_t _pad;
+    double param;
+    hr_texture albedo, emission, roughness;
+} hr_material;
+
+/* decoded image, RGBA8, row 0 = top row (image crate order, texture.rs:59-63 flips y itself) */
+typedef struct hr_image {
+    const uint8_t *rgba;
+    uint32_t width, height;
+} hr_image;
+
+/* scene.rs Intersectable implementors used by live scenes: Sphere :51, Cuboid :146, BvhMesh :236 */
+enum { HR_SPHERE = 0, HR_CUBOID = 1, HR_MESH = 2 };
+
+typedef struct hr_element {
+    int32_t kind;
+    int32_t _pad;
+    hr_material material;
+    hr_vec3 center; double radius;          /* HR_SPHERE  (scene.rs:51-55) */
+    hr_vec3 aabb_min, aabb_max;             /* HR_CUBOID  (scene.rs:146-149, bvh.rs:8-11) */
+    const hr_vec3 *vertexes;                /* HR_MESH: world-space (loader.rs:31) */
+    uint64_t num_vertexes;
+    const uint64_t *faces;                  /* 3 vertex indices per face (scene.rs:196-200, usize) */
+    uint64_t num_faces;
+} hr_element;
+
+/* camera.rs:7-29 Camera (already built by Camera::new, camera.rs:45-64) */
+typedef struct hr_camera {
+    hr_vec3 eye, right, up, forward, plane_half_right, plane_half_up;
+    double lens_radius, focus_distance;
+    int32_t lens_shape;                     /* 0 = Square, 1 = Circle (camera.rs:31-36) */
+    int32_t _pad;
+} hr_camera;
+
+/* scene.rs:268-276 Skybox: px, nx, py, ny, pz, nz */
+typedef struct hr_skybox {
+    int32_t face_image[6];
+    hr_vec3 intensity;
+} hr_skybox;
+
+typedef struct hr_scene_desc {
+    const hr_element *elements; uint32_t num_elements;   /* order = Scene.elements order (scene.rs:327-330) */
+    const hr_image *images;     uint32_t num_images;
+    hr_skybox skybox;
+    hr_camera camera;
+} hr_scene_desc;
+
+/* Work / timing counters.  Counter fields are only filled when option "counters" = 1. */
+typedef struct hr_stats {
+    uint64_t paths;            /* calc_pixel-equivalents rendered since hr_clear */
+    uint64_t rays;             /* scene.intersect-equivalents (primary + bounce + shadow) */
+    uint64_t node_tests;       /* AABB tests performed by the traversal kernel */
+    uint64_t tri_tests, sphere_tests, cuboid_tests;
+    uint64_t rng_overflow;     /* paths that ran past the stored ISAAC window */
+    double seed_kernel_ms;     /* sum of HIP-event durations of the seed kernel launches */
+    double trace_kernel_ms;    /* ... of the path-trace megakernel launches */
+    double post_kernel_ms;
+    uint64_t seed_launches, trace_launches;
+    uint64_t bvh_nodes, triangles, spheres, cuboids;
+} hr_stats;
+
+typedef struct hr_ctx hr_ctx;
+
+const char *hr_last_error(void);
+int hr_abi_version(void);
+
+int hr_create(int device_id, hr_ctx **out);
+int hr_destroy(hr_ctx *ctx);
+
+/* Scene: copies + converts to fp32 SoA, builds the device BVH, uploads. */
+int hr_upload_scene(hr_ctx *ctx, const hr_scene_desc *scene);
+
+/* Output target (ImageBuffer dims, renderer.rs:26-28).  Allocates + zeroes the fp32 RGB accumulator. */
+int hr_set_resolution(hr_ctx *ctx, uint32_t width, uint32_t height);
+/* Optional: accumulate into caller-owned DEVICE memory (W*H*3 floats), e.g. a torch tensor that
+ * torch.distributed all-reduces over RCCL.  Pass NULL to return to the internal buffer. */
+int hr_bind_accumulator(hr_ctx *ctx, float *device_rgb);
+void *hr_accumulator_device_ptr(hr_ctx *ctx);
+/* Optional: run on a caller-owned hipStream_t (opaque).  NULL = the context's own stream. */
+int hr_set_stream(hr_ctx *ctx, void *hip_stream);
+
+int hr_clear(hr_ctx *ctx);                 /* zero accumulator + stats */
+
+/* Accumulate samplings s = begin, begin+stride, ... (s < end) — 1-origin like renderer.rs:31-32.
+ * Each sampling adds the 2x2 sub-sample sum of calc_pixel to every pixel (renderer.rs:33-38,48-60).
+ * Asynchronous with respect to the host; hr_synchronize() or any read waits. */
+int hr_render(hr_ctx *ctx, uint32_t sampling_begin, uint32_t sampling_end, uint32_t stride);
+int hr_synchronize(hr_ctx *ctx);
+
+int hr_read_accumulator(hr_ctx *ctx, float *host_rgb);        /* W*H*3, row-major, top row first */
+int hr_write_accumulator(hr_ctx *ctx, const float *host_rgb); /* resume / post-chain tests */
+
+/* renderer.rs:64-90: scale by 1/(samplings*4) -> Reinhard -> gamma -> bilateral 3x3 -> u8 RGB. */
+int hr_resolve(hr_ctx *ctx, uint32_t samplings_done, uint8_t *host_rgb8);
+
+int hr_get_stats(hr_ctx *ctx, hr_stats *out);
+/* keys: "counters" (0/1), "rng_window" (8..256), "batch" (samplings per launch) */
+int hr_set_option(hr_ctx *ctx, const char *key, double value);
+
+/* ---- unit-level entry points used by the parity tests (same kernels' device functions) ---- */
+
+/* Raw ISAAC-64 outputs of the per-path generators exactly as the seed kernel stores them:
+ * for path p (= pixel-major, sub-sample minor: ((y*W + x)*4 + sy*2 + sx)) out[p*window + k] =
+ * k-th next_u64() of StdRng::from_seed([8700304, sampling, s, t]) (renderer.rs:165-168). */
+int hr_debug_draws(hr_ctx *ctx, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
+                   uint32_t window, uint64_t *host_out);
+
+/* Closest-hit query for n rays (scene.rs:385-401 minus the material fetch).
+ * rays: n * 6 floats (origin, direction).  out per ray: 8 floats
+ * { hit(0/1), distance, pos.x, pos.y, pos.z, n.x, n.y, n.z }, plus element index in out_element. */
+int hr_debug_intersect(hr_ctx *ctx, uint32_t n, const float *rays, float *out, int32_t *out_element);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,160 @@
+"""ctypes loader for oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The oracle consumes the same hr_scene_desc (plain data) the HIP library does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+COUNTER_FIELDS = ["paths", "rays_primary", "rays_bounce", "rays_shadow", "surface_hits", "draws", "tex_samples",
+                  "sky_lookups", "top_node_tests", "mesh_roots", "mesh_node_tests", "tri_tests", "tri_accepted",
+                  "sphere_tests", "cuboid_tests"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("oracle/liboracle.so not built — run `make -C oracle`")
+        L = C.CDLL(LIB_PATH)
+        L.orc_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_counters_size.restype = C.c_size_t
+        L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_calc_pixel.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
+        L.orc_path_draws.argtypes = [C.c_uint32] * 7 + [C.c_void_p, C.c_int]
+        L.orc_isaac64.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_u64_to_f64.argtypes = [C.c_uint64]
+        L.orc_u64_to_f64.restype = C.c_double
+        L.orc_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_skybox_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_image_sample_bilinear.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
+        L.orc_bvh_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_top_leaves.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_num_emissions.argtypes = [C.c_void_p]
+        L.orc_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class OracleScene:
+    def __init__(self, desc_ptr):
+        """desc_ptr: ctypes pointer to an hr_scene_desc (e.g. hanamaru_amd.Scene.desc_ptr)."""
+        L = lib()
+        h = C.c_void_p()
+        rc = L.orc_scene_create(C.cast(desc_ptr, C.c_void_p), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("orc_scene_create failed: %d" % rc)
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, w, h, s_begin, s_end, stride=1, threads=0, acc=None, counters=False):
+        """Accumulate samplings into a float64 (h, w, 3) array; returns (acc, counters dict or None)."""
+        if acc is None:
+            acc = np.zeros((h, w, 3), dtype=np.float64)
+        cbuf = None
+        if counters:
+            cbuf = (C.c_uint64 * (lib().orc_counters_size() // 8))()
+        rc = lib().orc_render(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data, cbuf)
+        if rc != 0:
+            raise RuntimeError("orc_render failed: %d" % rc)
+        cd = None
+        if counters:
+            vals = list(cbuf)
+            cd = dict(zip(COUNTER_FIELDS, vals[:len(COUNTER_FIELDS)]))
+            cd["rays_per_path_hist"] = vals[len(COUNTER_FIELDS):len(COUNTER_FIELDS) + 24]
+            cd["draws_per_path_hist"] = vals[len(COUNTER_FIELDS) + 24:len(COUNTER_FIELDS) + 64]
+        return acc, cd
+
+    def calc_pixel(self, w, h, x, y, sx, sy, sampling):
+        out = np.zeros(3, dtype=np.float64)
+        lib().orc_calc_pixel(self._h, w, h, x, y, sx, sy, sampling, out.ctypes.data)
+        return out
+
+    def intersect(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.empty((r.shape[0], 8), dtype=np.float64)
+        el = np.empty((r.shape[0],), dtype=np.int32)
+        lib().orc_intersect(self._h, r.shape[0], r.ctypes.data, out.ctypes.data, el.ctypes.data)
+        return out, el
+
+    def skybox(self, d):
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        out = np.zeros(3, dtype=np.float64)
+        lib().orc_skybox_sample(self._h, d.ctypes.data, out.ctypes.data)
+        return out
+
+    def image_bilinear(self, image, u, v):
+        out = np.zeros(3, dtype=np.float64)
+        rc = lib().orc_image_sample_bilinear(self._h, image, u, v, out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def bvh_stats(self, element):
+        st = (C.c_uint64 * 11)()
+        bb = (C.c_double * 6)()
+        rc = lib().orc_bvh_stats(self._h, element, st, bb)
+        if rc != 0:
+            return None
+        v = list(st)
+        return {"nodes": v[0], "leaves": v[1], "max_depth": v[2], "leaf_hist": v[3:11], "aabb": list(bb)}
+
+    def top_leaves(self):
+        buf = (C.c_int32 * 256)()
+        n = lib().orc_top_leaves(self._h, buf, 256)
+        leaves, cur = [], []
+        for i in range(n):
+            if buf[i] < 0:
+                leaves.append(cur)
+                cur = []
+            else:
+                cur.append(buf[i])
+        return leaves
+
+    def num_emissions(self):
+        return lib().orc_num_emissions(self._h)
+
+
+def isaac64(seed, count, skip=0):
+    s = np.asarray(seed, dtype=np.uint64)
+    out = np.empty(count, dtype=np.uint64)
+    lib().orc_isaac64(s.ctypes.data, len(s), skip, out.ctypes.data, count)
+    return out
+
+
+def path_draws(w, h, x, y, sx, sy, sampling, count):
+    out = np.empty(count, dtype=np.uint64)
+    lib().orc_path_draws(w, h, x, y, sx, sy, sampling, out.ctypes.data, count)
+    return out
+
+
+def u64_to_f64(v):
+    return lib().orc_u64_to_f64(int(v))
+
+
+def resolve(acc, samplings, want_stage=False):
+    a = np.ascontiguousarray(acc, dtype=np.float64)
+    h, w, _ = a.shape
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    stage = np.empty((h, w, 3), dtype=np.float64) if want_stage else None
+    rc = lib().orc_resolve(a.ctypes.data, w, h, samplings, out.ctypes.data, stage.ctypes.data if want_stage else None)
+    if rc != 0:
+        raise RuntimeError("orc_resolve failed: %d" % rc)
+    return (out, stage) if want_stage else out
