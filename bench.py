@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — Mpaths/s of the HIP path-tracing hot path on BASELINE.json's headline configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): the reference's live scene `rtcamp6_v3_1` at 1920x1080.  One STEP = one
+hr_render() batch of `--spp-per-step` samplings (default 16) of the whole image on every GPU = 16 x 1920 x 1080
+x 4 camera paths per GPU.  The default K = 64 steps is exactly BASELINE's 1920x1080 x 1024 samplings on one GPU.
+With N GPUs the sampling indices are sharded round-robin ((s-1) mod N == rank, one process per GPU), every
+GPU still renders `spp-per-step` samplings per step (weak scaling), and the fp32 radiance accumulators are
+summed with ONE all-reduce (RCCL) inside the timed region.  Inputs (scene, textures) are resident in HBM
+before the timed region; nothing is skipped inside it (seed kernel + trace kernel + accumulation).
+
+Extra objects on the JSON line:
+  roofline     — trace kernel: algorithmic bytes per launch (32 B/node test, 36 B/triangle test,
+                 16 B/sphere, 24 B/cuboid, counted by an instrumented run of the same kernel on the same seeds)
+                 divided by the kernel's mean launch duration (HIP events on its stream), vs 8 TB/s HBM peak.
+  cpu_baseline — the CPU oracle (f64 restatement of the reference path, oracle/) timed on this box's host cores
+                 on a bounded sample; reported, not optimised.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=4, help="samplings per kernel launch")
+    ap.add_argument("--scene", default="rtcamp6_v3_1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import hanamaru_amd as ha
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H, SPS = args.width, args.height, args.spp_per_step
+    scene = ha.Scene(args.scene)
+    r = ha.Renderer(local_rank)
+    r.upload_scene(scene)
+    r.set_resolution(W, H)
+    r.set_option("batch", args.batch)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    r.bind_accumulator(acc.data_ptr())
+    paths_per_step_gpu = W * H * 4 * SPS
+
+    def run_step(i):
+        # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; this rank takes (s-1) % world == rank
+        base = i * SPS * world + 1
+        r.render(base + rank, base + SPS * world, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- algorithmic bytes per path: instrumented run of the same kernel (outside the timed region)
+    bytes_per_path = None
+    counters = None
+    if rank == 0 and not args.no_counters:
+        r.set_option("counters", 1)
+        r.clear()
+        r.render(1, 3)
+        r.synchronize()
+        counters = r.stats()
+        r.set_option("counters", 0)
+        alg = 32 * counters["node_tests"] + 36 * counters["tri_tests"] + 16 * counters["sphere_tests"] + 24 * counters["cuboid_tests"]
+        bytes_per_path = alg / max(1, counters["paths"])
+    r.clear()
+
+    for i in range(args.warmup):
+        run_step(i)
+    r.synchronize()
+    r.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_step(i)
+    r.synchronize()
+    if dist is not None:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = r.stats()
+
+    if rank == 0:
+        total_paths = paths_per_step_gpu * world * args.steps
+        value = total_paths / elapsed / 1e6
+        out = {
+            "metric": "Mpaths/sec at 1920x1080x1024spp (rtcamp6 scene); achieved GB/s in BVH traversal",
+            "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
+            "config": {"workload": "%s %dx%d, %d samplings (x4 sub-samples) per step per GPU; K=64 steps = 1024 samplings" % (args.scene, W, H, SPS),
+                       "samplings_per_step_per_gpu": SPS, "samplings_per_launch": args.batch, "paths_per_step": paths_per_step_gpu * world,
+                       "parallelism": "spp-sharded x%d, one all-reduce" % world},
+            "rays_per_s_M": None,
+        }
+        launches = max(1, st["trace_launches"])
+        avg_ms = st["trace_kernel_ms"] / launches
+        paths_per_launch = W * H * 4 * min(args.batch, SPS)
+        roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
+                "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4)}
+        if bytes_per_path is not None and avg_ms > 0:
+            gbs = bytes_per_path * paths_per_launch / (avg_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_path": round(bytes_per_path, 1),
+                         "algorithmic_bytes_per_launch": int(bytes_per_path * paths_per_launch),
+                         "node_tests_per_ray": round(counters["node_tests"] / max(1, counters["rays"]), 2),
+                         "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
+                         "rays_per_path": round(counters["rays"] / max(1, counters["paths"]), 3)})
+            out["rays_per_s_M"] = round(value * counters["rays"] / max(1, counters["paths"]), 1)
+        out["roofline"] = roof
+
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py as orc
+            o = orc.OracleScene(scene.desc_ptr)
+            cores = os.cpu_count() or 1
+            cw, ch, cs = 480, 270, 1
+            tc0 = time.perf_counter()
+            o.render(cw, ch, 1, 2, threads=cores)
+            probe = time.perf_counter() - tc0
+            # scale the sample to roughly 10-20 s of CPU work
+            mult = int(max(1, min(64, 12.0 / max(probe, 1e-3))))
+            tc0 = time.perf_counter()
+            o.render(cw, ch, 2, 2 + mult, threads=cores)
+            dt = time.perf_counter() - tc0
+            out["cpu_baseline"] = {"value": round(cw * ch * 4 * mult / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+                                   "sample": "%s %dx%d x %d samplings (%d paths), all host cores, f64 oracle with reference-order BVH" %
+                                             (args.scene, cw, ch, mult, cw * ch * 4 * mult)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

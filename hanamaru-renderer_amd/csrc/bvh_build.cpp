@@ -1,0 +1,223 @@
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace hr {
+namespace {
+
+struct Box {
+    double mn[3], mx[3];
+    void reset() { for (int a = 0; a < 3; a++) { mn[a] = DBL_MAX; mx[a] = -DBL_MAX; } }
+    void grow(const double *bmin, const double *bmax) {
+        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], bmin[a]); mx[a] = std::max(mx[a], bmax[a]); }
+    }
+    void grow(const Box &b) { grow(b.mn, b.mx); }
+    double area() const {
+        double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct BNode {
+    Box box;
+    int left = -1, right = -1;
+    uint32_t first = 0, count = 0;
+    int type = -1, axis = 0;
+};
+
+struct Builder {
+    const std::vector<BuildPrim> &prims;
+    std::vector<uint32_t> idx;
+    std::vector<BNode> nodes;
+    int max_leaf;
+    uint32_t max_depth = 0;
+
+    Builder(const std::vector<BuildPrim> &p, int ml) : prims(p), max_leaf(ml) {
+        idx.resize(p.size());
+        for (uint32_t i = 0; i < p.size(); i++) idx[i] = i;
+    }
+    double centroid(uint32_t i, int a) const { return 0.5 * (prims[i].bmin[a] + prims[i].bmax[a]); }
+
+    int build(uint32_t first, uint32_t count, uint32_t depth) {
+        int id = (int)nodes.size();
+        nodes.emplace_back();
+        max_depth = std::max(max_depth, depth);
+        Box box, cbox;
+        box.reset(); cbox.reset();
+        bool same_type = true;
+        for (uint32_t i = first; i < first + count; i++) {
+            const BuildPrim &p = prims[idx[i]];
+            box.grow(p.bmin, p.bmax);
+            double c[3] = {centroid(idx[i], 0), centroid(idx[i], 1), centroid(idx[i], 2)};
+            cbox.grow(c, c);
+            if (p.type != prims[idx[first]].type) same_type = false;
+        }
+        nodes[id].box = box;
+        uint32_t mid = 0;
+        int axis = 0;
+        bool split = false;
+        if (!same_type) {
+            // force type-homogeneous subtrees: peel off the first prim's type
+            int t0 = prims[idx[first]].type;
+            auto it = std::stable_partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t i) { return prims[i].type == t0; });
+            mid = (uint32_t)(it - idx.begin());
+            // choose the axis along which the two groups' centroids differ most (for near/far ordering)
+            double c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+            for (uint32_t i = first; i < mid; i++) for (int a = 0; a < 3; a++) c0[a] += centroid(idx[i], a) / (mid - first);
+            for (uint32_t i = mid; i < first + count; i++) for (int a = 0; a < 3; a++) c1[a] += centroid(idx[i], a) / (first + count - mid);
+            double best = -1;
+            for (int a = 0; a < 3; a++) if (std::fabs(c1[a] - c0[a]) > best) { best = std::fabs(c1[a] - c0[a]); axis = a; }
+            if (c1[axis] < c0[axis]) {  // keep "left = lower coordinate" convention
+                std::rotate(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count);
+                mid = first + (first + count - mid);
+            }
+            split = true;
+        } else if (count > 1) {
+            // binned SAH over the three axes
+            const int NB = 32;
+            double best_cost = DBL_MAX;
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; a++) {
+                double lo = cbox.mn[a], hi = cbox.mx[a];
+                if (!(hi > lo)) continue;
+                Box bb[NB];
+                uint32_t bc[NB];
+                for (int b = 0; b < NB; b++) { bb[b].reset(); bc[b] = 0; }
+                double scale = NB / (hi - lo);
+                for (uint32_t i = first; i < first + count; i++) {
+                    int b = (int)((centroid(idx[i], a) - lo) * scale);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    bb[b].grow(prims[idx[i]].bmin, prims[idx[i]].bmax);
+                    bc[b]++;
+                }
+                double ra[NB];
+                uint32_t rc[NB];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int b = NB - 1; b > 0; b--) { acc.grow(bb[b]); cnt += bc[b]; ra[b] = acc.area(); rc[b] = cnt; }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    acc.grow(bb[b]);
+                    cnt += bc[b];
+                    if (!cnt || !rc[b + 1]) continue;
+                    double cost = acc.area() * cnt + ra[b + 1] * rc[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            double leaf_cost = box.area() * count;
+            // traversal cost 1 node ~ 1 primitive test
+            bool want_split = best_axis >= 0 && ((int)count > max_leaf || best_cost + box.area() * 1.0 < leaf_cost);
+            if (want_split) {
+                axis = best_axis;
+                double lo = cbox.mn[axis], hi = cbox.mx[axis];
+                const int NBk = 32;
+                double scale = NBk / (hi - lo);
+                auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t i) {
+                    int b = (int)((centroid(i, axis) - lo) * scale);
+                    b = std::min(std::max(b, 0), NBk - 1);
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - idx.begin());
+                split = mid > first && mid < first + count;
+            }
+            if (!split && (int)count > max_leaf) {  // degenerate: median split on the widest axis
+                axis = 0;
+                for (int a = 1; a < 3; a++) if (box.mx[a] - box.mn[a] > box.mx[axis] - box.mn[axis]) axis = a;
+                mid = first + count / 2;
+                std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
+                                 [&](uint32_t a, uint32_t b) { return centroid(a, axis) < centroid(b, axis); });
+                split = true;
+            }
+        }
+        if (!split) {
+            nodes[id].first = first; nodes[id].count = count; nodes[id].type = prims[idx[first]].type;
+            return id;
+        }
+        nodes[id].axis = axis;
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        nodes[id].left = l; nodes[id].right = r;
+        return id;
+    }
+};
+
+static float round_down(double v, int ulps) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+    for (int i = 0; i < ulps; i++) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+static float round_up(double v, int ulps) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, INFINITY);
+    for (int i = 0; i < ulps; i++) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+}  // namespace
+
+void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out) {
+    out.nodes.clear(); out.links.clear();
+    for (auto &o : out.order) o.clear();
+    out.max_depth = 0; out.num_leaves = 0;
+    if (prims.empty()) {
+        // a single empty leaf that nothing hits
+        Node n{};
+        n.bmin[0] = n.bmin[1] = n.bmin[2] = 1e30f;
+        n.bmax[0] = n.bmax[1] = n.bmax[2] = -1e30f;
+        n.leaf = 0;
+        out.nodes.push_back(n);
+        out.links.assign(8, Link{NODE_END, NODE_END});
+        return;
+    }
+    Builder b(prims, max_leaf);
+    b.build(0, (uint32_t)prims.size(), 0);
+    out.max_depth = b.max_depth;
+    size_t N = b.nodes.size();
+    // builder already allocates in DFS preorder (left first): index == memory order
+    out.nodes.resize(N);
+    // leaf-ordered primitive arrays per type
+    std::vector<uint32_t> leaf_first(N, 0);
+    for (size_t i = 0; i < N; i++) {
+        const BNode &bn = b.nodes[i];
+        if (bn.left < 0) {
+            leaf_first[i] = (uint32_t)out.order[bn.type].size();
+            for (uint32_t k = 0; k < bn.count; k++) out.order[bn.type].push_back(prims[b.idx[bn.first + k]].index);
+            out.num_leaves++;
+        }
+    }
+    for (size_t i = 0; i < N; i++) {
+        const BNode &bn = b.nodes[i];
+        Node &n = out.nodes[i];
+        for (int a = 0; a < 3; a++) { n.bmin[a] = round_down(bn.box.mn[a], 2); n.bmax[a] = round_up(bn.box.mx[a], 2); }
+        n.pad = 0;
+        n.leaf = (bn.left < 0) ? (((uint32_t)(bn.type + 1) << 28) | (bn.count << 20) | leaf_first[i]) : 0u;
+    }
+    out.links.assign(8 * N, Link{NODE_END, NODE_END});
+    for (int o = 0; o < 8; o++) {
+        Link *lk = &out.links[(size_t)o * N];
+        // iterative assignment of (hit, miss) with an explicit stack of (node, next_after_subtree)
+        std::vector<std::pair<int, uint32_t>> st;
+        st.emplace_back(0, NODE_END);
+        while (!st.empty()) {
+            auto [id, after] = st.back();
+            st.pop_back();
+            const BNode &bn = b.nodes[id];
+            lk[id].miss = after;
+            if (bn.left < 0) { lk[id].hit = after; continue; }
+            bool neg = (o >> bn.axis) & 1;  // ray travels toward -axis: the higher-coordinate child is nearer
+            int nearc = neg ? bn.right : bn.left, farc = neg ? bn.left : bn.right;
+            lk[id].hit = (uint32_t)nearc;
+            st.emplace_back(nearc, (uint32_t)farc);
+            st.emplace_back(farc, after);
+        }
+    }
+}
+
+}  // namespace hr

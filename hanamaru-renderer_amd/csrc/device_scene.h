@@ -1,0 +1,92 @@
+// Device-side scene layout (fp32, SoA-ish, all in HBM; the geometry part is ~1 MB and lives in L2).
+//
+//   nodes[]      32 B   one AABB + leaf word.  Shared by all 8 traversal orders.
+//   links[o][]    8 B   {hit, miss} successor of a node for ray-direction octant o (stackless threaded
+//                       traversal: near child first by the sign of the ray direction on the split axis).
+//   tris[]       48 B   leaf-ordered: v0, e1 = v1-v0, e2 = v2-v0 (edges formed in f64, then rounded) + element id
+//   spheres[]    16 B   centre, radius            (+ sphere_elem[])
+//   cuboids[]    32 B   min, max                  (+ element id in .w of the first float4)
+//   materials[]  64 B   per element
+//   texels[]      4 B   RGBA8, all images back to back; images[] = {offset, width, height}
+//
+// "Algorithmic bytes"  are counted as 32 B per node test, 36 B per triangle test,
+// 16 B per sphere test, 24 B per cuboid test — the information content, not the padded layout.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+#endif
+
+namespace hr {
+
+struct alignas(16) f4 { float x, y, z, w; };
+
+struct alignas(16) Node {
+    float bmin[3];
+    uint32_t leaf;    // 0 = inner; else (type+1) << 28 | count << 20 | first   (type: 0 tri, 1 sphere, 2 cuboid)
+    float bmax[3];
+    uint32_t pad;
+};
+static const uint32_t NODE_END = 0xffffffffu;
+
+struct alignas(8) Link { uint32_t hit, miss; };
+
+struct alignas(16) Tri {
+    float v0[3]; float e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z; int32_t element; float pad0, pad1;
+};
+
+struct alignas(16) Material {
+    int32_t surface; float param; int32_t albedo_img, emission_img;
+    float albedo[3]; int32_t roughness_img;
+    float emission[3]; float roughness;  // roughness tint .x (material.roughness.sample(uv).x, scene.rs:395)
+    int32_t nee_albedo_zero; int32_t pad[3];
+};
+
+struct ImageRef { uint32_t offset, width, height, pad; };
+
+struct Emitter { float c[3]; float r; int32_t element; int32_t pad[3]; };
+
+struct CameraF {
+    float eye[3], right[3], up[3], forward[3], phr[3], phu[3];
+    float lens_radius, focus_distance;
+    int32_t lens_shape;
+};
+
+struct Scene {
+    const Node *nodes;
+    const Link *links;       // [8][num_nodes]
+    const Tri *tris;
+    const f4 *spheres; const int32_t *sphere_elem;
+    const f4 *cuboids;       // 2 per cuboid: {min, element-as-int-bits}, {max, 0}
+    const Material *materials;
+    const uint32_t *texels;
+    const ImageRef *images;
+    const Emitter *emitters;
+    uint32_t num_nodes, num_tris, num_spheres, num_cuboids, num_elements, num_emitters;
+    int32_t sky_image[6];
+    float sky_intensity[3];
+    CameraF cam;
+};
+
+// One render launch covers `num_k` samplings (sampling_begin + k*stride) of the whole image.
+struct RenderParams {
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;        // 4x4-pixel tiles
+    uint32_t sampling_begin, stride, num_k;
+    uint32_t pad;
+};
+
+// draws per path handed from the seed kernel to the trace kernel: 2 lens + 9 iterations x 2
+static const int DRAWS_PER_PATH = 20;
+static const int ISAAC_TAIL = 64;     // outputs rsl[255-63 .. 255] kept per path (lens rejection window)
+
+struct Counters {
+    unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, pad;
+};
+
+}  // namespace hr

@@ -1,0 +1,155 @@
+#include "flatten.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace hr {
+
+static int ferr(std::string &err, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+}
+
+Scene HostScene::view() const {
+    Scene d;
+    memset(&d, 0, sizeof d);
+    d.nodes = nodes.data(); d.links = links.data(); d.tris = tris.data();
+    d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.cuboids = cuboids.data();
+    d.materials = materials.data(); d.texels = texels.data(); d.images = images.data(); d.emitters = emitters.data();
+    d.num_nodes = (uint32_t)nodes.size(); d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
+    d.num_cuboids = (uint32_t)(cuboids.size() / 2); d.num_elements = (uint32_t)materials.size(); d.num_emitters = (uint32_t)emitters.size();
+    for (int f = 0; f < 6; f++) d.sky_image[f] = sky_image[f];
+    for (int k = 0; k < 3; k++) d.sky_intensity[k] = sky_intensity[k];
+    d.cam = cam;
+    return d;
+}
+
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err) {
+    if (!sd) return ferr(err, HR_ERR_INVALID, "null scene");
+    if (!sd->elements || sd->num_elements == 0) return ferr(err, HR_ERR_INVALID, "scene has no elements");
+    struct TriD { double v0[3], v1[3], v2[3]; int32_t elem; };
+    std::vector<TriD> tris;
+    std::vector<f4> spheres; std::vector<int32_t> sphere_elem;
+    std::vector<f4> cuboids;
+    std::vector<BuildPrim> prims;
+    out.materials.assign(sd->num_elements, Material{});
+    out.emitters.clear();
+    auto f3 = [](float *dst, const hr_vec3 &v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; };
+    for (uint32_t ei = 0; ei < sd->num_elements; ei++) {
+        const hr_element &e = sd->elements[ei];
+        Material &m = out.materials[ei];
+        memset(&m, 0, sizeof m);
+        if (e.material.surface < HR_DIFFUSE || e.material.surface > HR_GGX_REFRACTION)
+            return ferr(err, HR_ERR_INVALID, "element %u: bad surface type %d", ei, e.material.surface);
+        for (const hr_texture *t : {&e.material.albedo, &e.material.emission, &e.material.roughness})
+            if (t->image >= (int32_t)sd->num_images) return ferr(err, HR_ERR_INVALID, "element %u: image index %d out of range", ei, t->image);
+        m.surface = e.material.surface; m.param = (float)e.material.param;
+        m.albedo_img = e.material.albedo.image < 0 ? -1 : e.material.albedo.image;
+        m.emission_img = e.material.emission.image < 0 ? -1 : e.material.emission.image;
+        m.roughness_img = e.material.roughness.image < 0 ? -1 : e.material.roughness.image;
+        f3(m.albedo, e.material.albedo.color); f3(m.emission, e.material.emission.color);
+        m.roughness = (float)e.material.roughness.color.x;
+        if (e.kind == HR_SPHERE) {
+            BuildPrim p{};
+            p.type = 1; p.index = (uint32_t)spheres.size();
+            double c3[3] = {e.center.x, e.center.y, e.center.z};
+            for (int a = 0; a < 3; a++) { p.bmin[a] = c3[a] - e.radius; p.bmax[a] = c3[a] + e.radius; }
+            prims.push_back(p);
+            spheres.push_back(f4{(float)e.center.x, (float)e.center.y, (float)e.center.z, (float)e.radius});
+            sphere_elem.push_back((int32_t)ei);
+            // Scene::emissions (scene.rs:356-358): nee_available() (spheres only, scene.rs:89) && emission tint != 0
+            if (e.material.emission.color.x != 0.0 || e.material.emission.color.y != 0.0 || e.material.emission.color.z != 0.0) {
+                Emitter em{};
+                f3(em.c, e.center); em.r = (float)e.radius; em.element = (int32_t)ei;
+                out.emitters.push_back(em);
+            }
+        } else if (e.kind == HR_CUBOID) {
+            BuildPrim p{};
+            p.type = 2; p.index = (uint32_t)(cuboids.size() / 2);
+            double mn[3] = {e.aabb_min.x, e.aabb_min.y, e.aabb_min.z}, mx[3] = {e.aabb_max.x, e.aabb_max.y, e.aabb_max.z};
+            for (int a = 0; a < 3; a++) { p.bmin[a] = mn[a]; p.bmax[a] = mx[a]; }
+            prims.push_back(p);
+            union { int32_t i; float f; } cv;
+            cv.i = (int32_t)ei;
+            cuboids.push_back(f4{(float)mn[0], (float)mn[1], (float)mn[2], cv.f});
+            cuboids.push_back(f4{(float)mx[0], (float)mx[1], (float)mx[2], 0.0f});
+        } else if (e.kind == HR_MESH) {
+            if (!e.vertexes || !e.faces) return ferr(err, HR_ERR_INVALID, "element %u: mesh without data", ei);
+            for (uint64_t fi = 0; fi < e.num_faces; fi++) {
+                uint64_t i0 = e.faces[fi * 3], i1 = e.faces[fi * 3 + 1], i2 = e.faces[fi * 3 + 2];
+                if (i0 >= e.num_vertexes || i1 >= e.num_vertexes || i2 >= e.num_vertexes)
+                    return ferr(err, HR_ERR_INVALID, "element %u face %llu: vertex index out of range", ei, (unsigned long long)fi);
+                TriD t;
+                const hr_vec3 &a = e.vertexes[i0], &b = e.vertexes[i1], &cc = e.vertexes[i2];
+                t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z;
+                t.v2[0] = cc.x; t.v2[1] = cc.y; t.v2[2] = cc.z; t.elem = (int32_t)ei;
+                BuildPrim p{};
+                p.type = 0; p.index = (uint32_t)tris.size();
+                for (int k = 0; k < 3; k++) {
+                    p.bmin[k] = std::fmin(std::fmin(t.v0[k], t.v1[k]), t.v2[k]);
+                    p.bmax[k] = std::fmax(std::fmax(t.v0[k], t.v1[k]), t.v2[k]);
+                }
+                prims.push_back(p);
+                tris.push_back(t);
+            }
+        } else {
+            return ferr(err, HR_ERR_INVALID, "element %u: unknown kind %d", ei, e.kind);
+        }
+    }
+    if (tris.size() >= (1u << 20) || spheres.size() >= (1u << 20) || cuboids.size() / 2 >= (1u << 20))
+        return ferr(err, HR_ERR_UNSUPPORTED, "more than 2^20 primitives of one type");
+
+    BuiltBvh bvh;
+    build_bvh(prims, 4, bvh);
+    out.nodes = bvh.nodes; out.links = bvh.links;
+    out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves;
+
+    out.tris.assign(tris.size(), Tri{});
+    for (size_t i = 0; i < tris.size(); i++) {
+        const TriD &s = tris[bvh.order[0][i]];
+        Tri &d = out.tris[i];
+        memset(&d, 0, sizeof d);
+        d.v0[0] = (float)s.v0[0]; d.v0[1] = (float)s.v0[1]; d.v0[2] = (float)s.v0[2];
+        // edges formed in f64, rounded once
+        d.e1x = (float)(s.v1[0] - s.v0[0]); d.e1y = (float)(s.v1[1] - s.v0[1]); d.e1z = (float)(s.v1[2] - s.v0[2]);
+        d.e2x = (float)(s.v2[0] - s.v0[0]); d.e2y = (float)(s.v2[1] - s.v0[1]); d.e2z = (float)(s.v2[2] - s.v0[2]);
+        d.element = s.elem;
+    }
+    out.spheres.resize(spheres.size()); out.sphere_elem.resize(spheres.size());
+    for (size_t i = 0; i < spheres.size(); i++) { out.spheres[i] = spheres[bvh.order[1][i]]; out.sphere_elem[i] = sphere_elem[bvh.order[1][i]]; }
+    out.cuboids.resize(cuboids.size());
+    for (size_t i = 0; i < cuboids.size() / 2; i++) { out.cuboids[2 * i] = cuboids[2 * bvh.order[2][i]]; out.cuboids[2 * i + 1] = cuboids[2 * bvh.order[2][i] + 1]; }
+
+    out.images.assign(sd->num_images, ImageRef{});
+    size_t total = 0;
+    for (uint32_t i = 0; i < sd->num_images; i++) {
+        if (!sd->images[i].rgba || !sd->images[i].width || !sd->images[i].height) return ferr(err, HR_ERR_INVALID, "image %u is empty", i);
+        out.images[i] = ImageRef{(uint32_t)total, sd->images[i].width, sd->images[i].height, 0};
+        total += (size_t)sd->images[i].width * sd->images[i].height;
+    }
+    if (total >= (1ull << 32)) return ferr(err, HR_ERR_UNSUPPORTED, "texture pool larger than 2^32 texels");
+    out.texels.resize(total ? total : 1);
+    for (uint32_t i = 0; i < sd->num_images; i++)
+        memcpy(&out.texels[out.images[i].offset], sd->images[i].rgba, (size_t)out.images[i].width * out.images[i].height * 4);
+    for (int f = 0; f < 6; f++) {
+        if (sd->skybox.face_image[f] < 0 || sd->skybox.face_image[f] >= (int32_t)sd->num_images)
+            return ferr(err, HR_ERR_INVALID, "skybox face %d has no image", f);
+        out.sky_image[f] = sd->skybox.face_image[f];
+    }
+    f3(out.sky_intensity, sd->skybox.intensity);
+    const hr_camera &cam = sd->camera;
+    memset(&out.cam, 0, sizeof out.cam);
+    f3(out.cam.eye, cam.eye); f3(out.cam.right, cam.right); f3(out.cam.up, cam.up); f3(out.cam.forward, cam.forward);
+    f3(out.cam.phr, cam.plane_half_right); f3(out.cam.phu, cam.plane_half_up);
+    out.cam.lens_radius = (float)cam.lens_radius; out.cam.focus_distance = (float)cam.focus_distance; out.cam.lens_shape = cam.lens_shape;
+    return HR_OK;
+}
+
+}  // namespace hr

@@ -1,0 +1,36 @@
+// hr_scene_desc (f64, reference-native types) -> fp32 device layout on the host: primitive gathering,
+// BVH build, leaf-order permutation, material / image / emitter tables.  Pure C++ (no HIP) so the same
+// code feeds hipMemcpy in hr_api.hip and the host emulation in tests/emu.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "device_scene.h"
+#include "hanamaru_hip.h"
+
+namespace hr {
+
+struct HostScene {
+    std::vector<Node> nodes;
+    std::vector<Link> links;
+    std::vector<Tri> tris;
+    std::vector<f4> spheres;
+    std::vector<int32_t> sphere_elem;
+    std::vector<f4> cuboids;
+    std::vector<Material> materials;
+    std::vector<ImageRef> images;
+    std::vector<Emitter> emitters;
+    std::vector<uint32_t> texels;
+    int32_t sky_image[6];
+    float sky_intensity[3];
+    CameraF cam;
+    uint32_t bvh_max_depth = 0, bvh_leaves = 0;
+    // a Scene whose pointers refer to the vectors above (valid on the host only)
+    Scene view() const;
+};
+
+// returns HR_OK or a negative hr_status; `err` receives the message
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err);
+
+}  // namespace hr

@@ -1,0 +1,681 @@
+// hr_api.hip — HIP kernels (gfx950) and the C ABI of include/hanamaru_hip.h.
+//
+// Kernels
+//   seed_isaac64_kernel   one lane = one path's ISAAC-64 generator, state in an LDS bank column
+//                         (64 lanes x 2 KiB = 128 KiB + 16 KiB fp32 tail per workgroup, 1 workgroup / CU),
+//                         resolves the lens rejection loop in f64 and emits 20 fp32 draws per path.
+//   trace_kernel          the path-tracing megakernel: one wave per 4x4-pixel tile, one lane per path,
+//                         stackless threaded-BVH traversal, finished lanes are refilled from the tile's
+//                         path queue with ballot / mbcnt prefix ranks; LDS-free except 192 B of tile sums,
+//                         so it co-resides with the LDS-hungry seed kernel of the NEXT batch.
+//   tonemap_gamma_kernel, bilateral_quantise_kernel   the post chain.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "device_scene.h"
+#include "flatten.h"
+#include "hanamaru_hip.h"
+#include "isaac_core.h"
+#include "post_core.h"
+#include "pt_core.h"
+
+using namespace hr;
+
+// ------------------------------------------------------------------------------------------ helpers
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(HR_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ kernels
+
+struct LdsMem {
+    u64 *col;  // &mem[0][lane]
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
+};
+struct LdsTail {
+    float *col;
+    __device__ __forceinline__ float ld(int k) const { return col[k * 64]; }
+    __device__ __forceinline__ void st(int k, float v) { col[k * 64] = v; }
+};
+
+static const size_t SEED_LDS_BYTES = 256 * 64 * 8 + ISAAC_TAIL * 64 * 4;  // 128 KiB + 16 KiB
+
+__device__ __forceinline__ void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint32_t &px, uint32_t &py, uint32_t &sub) {
+    uint32_t tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
+    uint32_t pix = j >> 2;
+    sub = j & 3u;
+    px = tx * 4u + (pix & 3u);
+    py = ty * 4u + (pix >> 2);
+}
+
+// draws layout: [tile][k][DRAWS_PER_PATH][64 lanes]
+__global__ __launch_bounds__(64) void seed_isaac64_kernel(RenderParams rp, int lens_shape, float *__restrict__ draws, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64 *mem = reinterpret_cast<u64 *>(smem);
+    float *tail = reinterpret_cast<float *>(smem + 256 * 64 * 8);
+    const uint32_t lane = threadIdx.x;
+    const IsaacWarm warm = isaac_warm();
+    const uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, lane, px, py, sub);
+        bool valid = px < rp.width && py < rp.height;
+        u64 s, t;
+        path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
+        LdsMem m{mem + lane};
+        LdsTail tm{tail + lane};
+        LensTail<LdsTail> lt(tm, lens_shape);
+        isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
+        if (valid) {
+            bool ok = lt.accepted >= 0 && 2 * lt.accepted + DRAWS_PER_PATH <= ISAAC_TAIL;
+            size_t base = (size_t)item * DRAWS_PER_PATH * 64 + lane;
+            int first = ok ? 2 * lt.accepted + 2 : 0;
+            draws[base] = ok ? lt.sqx : 0.0f;
+            draws[base + 64] = ok ? lt.sqy : 0.0f;
+#pragma unroll
+            for (int d = 0; d < DRAWS_PER_PATH - 2; d++) draws[base + (size_t)(2 + d) * 64] = tm.ld(first + d);
+            if (!ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+        }
+    }
+}
+
+// raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
+struct RawTail {
+    u64 *out; int window;
+    __device__ __forceinline__ void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; }
+};
+__global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
+                                                        int window, u64 *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64 *mem = reinterpret_cast<u64 *>(smem);
+    const uint32_t lane = threadIdx.x;
+    const IsaacWarm warm = isaac_warm();
+    uint32_t idx = blockIdx.x * 64 + lane;
+    bool valid = idx < num_paths;
+    uint32_t p = first_path + (valid ? idx : 0u);
+    uint32_t pix = p >> 2, sub = p & 3u;
+    u64 s, t;
+    path_seed_words(W, H, pix % W, pix / W, sub, s, t);
+    LdsMem m{mem + lane};
+    u64 dummy[ISAAC_TAIL];
+    RawTail rt{valid ? out + (size_t)idx * window : dummy, window};
+    isaac_seed_round(m, warm, 8700304ULL, (u64)sampling, s, t, rt);
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool CNT>
+__global__ __launch_bounds__(64) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ draws, float *__restrict__ accum,
+                                                   Counters *cnt) {
+    __shared__ float tile_sum[48];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    // XCD-aware mapping: block b runs on XCD b % 8; give each XCD a contiguous band of tiles so its L2
+    // sees a compact part of the floor texture / BVH.
+    const uint32_t per_xcd = (tiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= tiles) return;
+    if (lane < 48) tile_sum[lane] = 0.0f;
+    __syncthreads();
+
+    LaneCounters lc = {0, 0, 0, 0, 0};
+    uint32_t npaths = 0;
+    const uint32_t total = 64u * rp.num_k;
+    uint32_t next = 0;  // wave-uniform queue head: slot q = k * 64 + j
+    Path p;
+    p.q = PATH_IDLE;
+    const size_t tile_draw_base = (size_t)tile * rp.num_k * DRAWS_PER_PATH * 64;
+
+    for (;;) {
+        // ---- refill idle lanes from the tile's path queue (ballot + prefix rank)
+        unsigned long long idle = __ballot(p.q == PATH_IDLE);
+        if (idle && next < total) {
+            uint32_t q = next + lane_rank(idle);
+            if (p.q == PATH_IDLE && q < total) {
+                uint32_t k = q >> 6, j = q & 63u, px, py, sub;
+                tile_lane_pixel(rp, tile, j, px, py, sub);
+                if (px < rp.width && py < rp.height) {
+                    p.q = q;
+                    p.draw_base = (uint32_t)(k * DRAWS_PER_PATH * 64 + j);
+                    path_start(sc, rp, p, px, py, sub, draws + tile_draw_base);
+                    npaths++;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+        bool active = p.q != PATH_IDLE;
+        if (!__ballot(active)) {
+            if (next >= total) break;
+            continue;
+        }
+        // ---- traversal: every active lane walks its ray to completion
+        while (__ballot(active && p.ts.cur != NODE_END)) {
+            if (active && p.ts.cur != NODE_END) trace_step<CNT>(sc, p.ray, p.ts, &lc);
+        }
+        // ---- shade / NEE / next ray
+        if (active) {
+            if (path_advance<CNT>(sc, p, draws + tile_draw_base, &lc)) {
+                uint32_t pix = (p.q & 63u) >> 2;
+                atomicAdd(&tile_sum[pix * 3 + 0], p.accum.x);
+                atomicAdd(&tile_sum[pix * 3 + 1], p.accum.y);
+                atomicAdd(&tile_sum[pix * 3 + 2], p.accum.z);
+                p.q = PATH_IDLE;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane < 48) {
+        uint32_t pix = lane / 3, c = lane - pix * 3;
+        uint32_t px = (tile % rp.tiles_x) * 4u + (pix & 3u), py = (tile / rp.tiles_x) * 4u + (pix >> 2);
+        if (px < rp.width && py < rp.height) accum[((size_t)py * rp.width + px) * 3 + c] += tile_sum[lane];
+    }
+    if (CNT) {
+        // wave reduction, one atomic per counter per wave
+        unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
+        for (int i = 0; i < 6; i++) {
+            unsigned long long x = v[i];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            v[i] = x;
+        }
+        if (lane == 0) {
+            atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
+            atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
+        }
+    }
+}
+
+__global__ void intersect_debug_kernel(Scene sc, uint32_t n, const float *__restrict__ rays, float *__restrict__ out, int32_t *__restrict__ out_elem) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    ray_set(r, v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
+    TraceState ts;
+    trace_begin(ts, T_INF);
+    LaneCounters lc;
+    while (ts.cur != NODE_END) trace_step<false>(sc, r, ts, &lc);
+    float *o = out + (size_t)i * 8;
+    int32_t elem = -1;
+    if (ts.prim >= 0) {
+        Surf s;
+        hit_surface(sc, r, ts, true, s);
+        elem = s.elem;
+        o[0] = 1.0f; o[1] = ts.t; o[2] = s.pos.x; o[3] = s.pos.y; o[4] = s.pos.z; o[5] = s.n.x; o[6] = s.n.y; o[7] = s.n.z;
+    } else {
+        o[0] = 0.0f; o[1] = ts.t;
+        for (int k = 2; k < 8; k++) o[k] = 0.0f;
+    }
+    out_elem[i] = elem;
+}
+
+__global__ void tonemap_gamma_kernel(const float *__restrict__ acc, float *__restrict__ out, uint32_t n, float scale) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    tonemap_gamma(acc[i * 3], acc[i * 3 + 1], acc[i * 3 + 2], scale, &out[i * 3]);
+}
+__global__ void bilateral_quantise_kernel(const float *__restrict__ img, uint8_t *__restrict__ out, uint32_t W, uint32_t H) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    bilateral_quantise(img, W, H, x, y, &out[((size_t)y * W + x) * 3]);
+}
+
+// ------------------------------------------------------------------------------------------ context
+
+struct EventPair { hipEvent_t a, b; };
+
+struct hr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // trace / post stream (own or caller's)
+    hipStream_t own_stream = nullptr;
+    hipStream_t seed_stream = nullptr;  // seed kernel of the next batch runs here, concurrently
+    std::vector<void *> scene_allocs;
+    Scene dsc{};
+    bool have_scene = false;
+    uint32_t W = 0, H = 0;
+    float *accum_own = nullptr, *accum = nullptr;
+    float *draws[2] = {nullptr, nullptr};
+    size_t draws_cap = 0;  // floats per buffer
+    hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
+    bool trace_pending[2] = {false, false};
+    Counters *d_counters = nullptr;
+    float *post_tmp = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    bool counters = false;
+    uint32_t batch = 4;
+    int num_cus = 256;
+    std::vector<EventPair> seed_events, trace_events, post_events;
+    double seed_ms = 0, trace_ms = 0, post_ms = 0;
+    uint64_t seed_launches = 0, trace_launches = 0;
+    uint64_t paths_rendered = 0;
+    uint64_t st_nodes = 0, st_tris = 0, st_spheres = 0, st_cuboids = 0;
+    uint64_t batch_counter = 0;
+};
+
+static void free_scene(hr_ctx *c) {
+    for (void *p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->have_scene = false;
+}
+template <class T>
+static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&d, bytes));
+    c->scene_allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(d);
+    return HR_OK;
+}
+static int drain_events(hr_ctx *c) {
+    auto sum = [](std::vector<EventPair> &ev, double &acc) -> hipError_t {
+        for (auto &e : ev) {
+            float ms = 0;
+            hipError_t r = hipEventElapsedTime(&ms, e.a, e.b);
+            if (r != hipSuccess) return r;
+            acc += ms;
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        ev.clear();
+        return hipSuccess;
+    };
+    HIP_TRY(sum(c->seed_events, c->seed_ms));
+    HIP_TRY(sum(c->trace_events, c->trace_ms));
+    HIP_TRY(sum(c->post_events, c->post_ms));
+    return HR_OK;
+}
+static int sync_all(hr_ctx *c) {
+    HIP_TRY(hipStreamSynchronize(c->seed_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->trace_pending[0] = c->trace_pending[1] = false;
+    return drain_events(c);
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+const char *hr_last_error(void) { return g_err.c_str(); }
+int hr_abi_version(void) { return HR_ABI_VERSION; }
+
+int hr_create(int device_id, hr_ctx **out) {
+    if (!out) return fail(HR_ERR_INVALID, "hr_create: out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(HR_ERR_INVALID, "hr_create: device %d not in [0,%d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    hr_ctx *c = new hr_ctx;
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->seed_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->seed_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->trace_done[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(Counters)));
+    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_isaac64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
+    *out = c;
+    return HR_OK;
+}
+
+int hr_destroy(hr_ctx *c) {
+    if (!c) return HR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_scene(c);
+    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events})
+        for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->accum_own) (void)hipFree(c->accum_own);
+    for (int i = 0; i < 2; i++) {
+        if (c->draws[i]) (void)hipFree(c->draws[i]);
+        if (c->seed_done[i]) (void)hipEventDestroy(c->seed_done[i]);
+        if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
+    }
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->post_tmp) (void)hipFree(c->post_tmp);
+    if (c->d_rgb8) (void)hipFree(c->d_rgb8);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->seed_stream) (void)hipStreamDestroy(c->seed_stream);
+    delete c;
+    return HR_OK;
+}
+
+int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
+    if (!c || !sd) return fail(HR_ERR_INVALID, "hr_upload_scene: null argument");
+    if (!sd->elements || sd->num_elements == 0) return fail(HR_ERR_INVALID, "hr_upload_scene: scene has no elements");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    free_scene(c);
+
+    HostScene hs;
+    std::string ferr;
+    rc = flatten_scene(sd, hs, ferr);
+    if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());
+    Scene &d = c->dsc;
+    d = hs.view();
+    int r;
+    if ((r = upload(c, hs.nodes, &d.nodes))) return r;
+    if ((r = upload(c, hs.links, &d.links))) return r;
+    if ((r = upload(c, hs.tris, &d.tris))) return r;
+    if ((r = upload(c, hs.spheres, &d.spheres))) return r;
+    if ((r = upload(c, hs.sphere_elem, &d.sphere_elem))) return r;
+    if ((r = upload(c, hs.cuboids, &d.cuboids))) return r;
+    if ((r = upload(c, hs.materials, &d.materials))) return r;
+    if ((r = upload(c, hs.images, &d.images))) return r;
+    if ((r = upload(c, hs.emitters, &d.emitters))) return r;
+    if ((r = upload(c, hs.texels, &d.texels))) return r;
+    c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
+    c->have_scene = true;
+    return HR_OK;
+}
+
+int hr_set_resolution(hr_ctx *c, uint32_t w, uint32_t h) {
+    if (!c || !w || !h) return fail(HR_ERR_INVALID, "hr_set_resolution: bad argument");
+    if ((uint64_t)w * h > (1ull << 27)) return fail(HR_ERR_UNSUPPORTED, "resolution too large");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    bool external = c->accum && c->accum != c->accum_own;
+    if (c->accum_own) { HIP_TRY(hipFree(c->accum_own)); c->accum_own = nullptr; }
+    if (c->post_tmp) { HIP_TRY(hipFree(c->post_tmp)); c->post_tmp = nullptr; }
+    if (c->d_rgb8) { HIP_TRY(hipFree(c->d_rgb8)); c->d_rgb8 = nullptr; }
+    c->W = w; c->H = h;
+    size_t n = (size_t)w * h * 3;
+    HIP_TRY(hipMalloc((void **)&c->accum_own, n * sizeof(float)));
+    HIP_TRY(hipMemset(c->accum_own, 0, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&c->post_tmp, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&c->d_rgb8, n));
+    if (!external) c->accum = c->accum_own;
+    return HR_OK;
+}
+
+int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_bind_accumulator: null ctx");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    c->accum = device_rgb ? device_rgb : c->accum_own;
+    return HR_OK;
+}
+void *hr_accumulator_device_ptr(hr_ctx *c) { return c ? c->accum : nullptr; }
+
+int hr_set_stream(hr_ctx *c, void *s) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_set_stream: null ctx");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return HR_OK;
+}
+
+int hr_clear(hr_ctx *c) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_clear: null ctx");
+    if (!c->accum) return fail(HR_ERR_NO_TARGET, "hr_clear: no accumulator (call hr_set_resolution)");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->seed_ms = c->trace_ms = c->post_ms = 0;
+    c->seed_launches = c->trace_launches = 0;
+    c->paths_rendered = 0;
+    return HR_OK;
+}
+
+static int ensure_draws(hr_ctx *c, size_t floats) {
+    if (floats <= c->draws_cap) return HR_OK;
+    for (int i = 0; i < 2; i++) {
+        if (c->draws[i]) { HIP_TRY(hipFree(c->draws[i])); c->draws[i] = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->draws[i], floats * sizeof(float)));
+    }
+    c->draws_cap = floats;
+    return HR_OK;
+}
+
+static int launch_seed(hr_ctx *c, const RenderParams &rp, float *draws, hipStream_t st) {
+    uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
+    uint32_t grid = std::min<uint32_t>(items, (uint32_t)c->num_cus);
+    EventPair ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, st));
+    hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, draws, c->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, st));
+    c->seed_events.push_back(ev);
+    c->seed_launches++;
+    return HR_OK;
+}
+
+int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
+    if (!c || !stride) return fail(HR_ERR_INVALID, "hr_render: bad argument");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_render: no scene uploaded");
+    if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_render: hr_set_resolution not called");
+    if (s_end <= s_begin) return HR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t total_k = (s_end - s_begin + stride - 1) / stride;
+    RenderParams rp{};
+    rp.width = c->W; rp.height = c->H;
+    rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
+    rp.stride = stride;
+    uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    uint32_t batch = std::max<uint32_t>(1, c->batch);
+    int rc = ensure_draws(c, (size_t)tiles * batch * DRAWS_PER_PATH * 64);
+    if (rc) return rc;
+    for (uint32_t done = 0; done < total_k; done += batch) {
+        uint32_t nk = std::min(batch, total_k - done);
+        rp.sampling_begin = s_begin + done * stride;
+        rp.num_k = nk;
+        int slot = (int)(c->batch_counter & 1);
+        c->batch_counter++;
+        // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
+        if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(c->seed_stream, c->trace_done[slot], 0));
+        if ((rc = launch_seed(c, rp, c->draws[slot], c->seed_stream))) return rc;
+        HIP_TRY(hipEventRecord(c->seed_done[slot], c->seed_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
+        EventPair ev;
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventRecord(ev.a, c->stream));
+        uint32_t grid = ((tiles + 7u) / 8u) * 8u;
+        if (c->counters)
+            hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, c->stream, c->dsc, rp, c->draws[slot], c->accum, c->d_counters);
+        else
+            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, c->stream, c->dsc, rp, c->draws[slot], c->accum, c->d_counters);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev.b, c->stream));
+        c->trace_events.push_back(ev);
+        c->trace_launches++;
+        HIP_TRY(hipEventRecord(c->trace_done[slot], c->stream));
+        c->trace_pending[slot] = true;
+        c->paths_rendered += (uint64_t)c->W * c->H * 4 * nk;
+        if (c->trace_events.size() > 4096) {  // keep the event list bounded on very long renders
+            if ((rc = sync_all(c))) return rc;
+        }
+    }
+    return HR_OK;
+}
+
+int hr_synchronize(hr_ctx *c) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_synchronize: null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    if (h.rng_overflow) return fail(HR_ERR_RNG_WINDOW, "%llu paths needed more than %d ISAAC-64 outputs for the lens rejection loop", h.rng_overflow, ISAAC_TAIL);
+    return HR_OK;
+}
+
+int hr_read_accumulator(hr_ctx *c, float *host) {
+    if (!c || !host) return fail(HR_ERR_INVALID, "hr_read_accumulator: null argument");
+    if (!c->accum) return fail(HR_ERR_NO_TARGET, "hr_read_accumulator: no accumulator");
+    int rc = hr_synchronize(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(host, c->accum, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return HR_OK;
+}
+int hr_write_accumulator(hr_ctx *c, const float *host) {
+    if (!c || !host) return fail(HR_ERR_INVALID, "hr_write_accumulator: null argument");
+    if (!c->accum) return fail(HR_ERR_NO_TARGET, "hr_write_accumulator: no accumulator");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(c->accum, host, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyHostToDevice));
+    return HR_OK;
+}
+
+int hr_resolve(hr_ctx *c, uint32_t samplings, uint8_t *host_rgb8) {
+    if (!c || !host_rgb8 || !samplings) return fail(HR_ERR_INVALID, "hr_resolve: bad argument");
+    if (!c->accum) return fail(HR_ERR_NO_TARGET, "hr_resolve: no accumulator");
+    int rc = hr_synchronize(c);
+    if (rc) return rc;
+    uint32_t n = c->W * c->H;
+    float scale = 1.0f / (float)(samplings * 4u);
+    EventPair ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, c->stream));
+    hipLaunchKernelGGL(tonemap_gamma_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->post_tmp, n, scale);
+    hipLaunchKernelGGL(bilateral_quantise_kernel, dim3((c->W + 31) / 32, (c->H + 7) / 8), dim3(32, 8), 0, c->stream, c->post_tmp, c->d_rgb8, c->W, c->H);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, c->stream));
+    c->post_events.push_back(ev);
+    HIP_TRY(hipMemcpyAsync(host_rgb8, c->d_rgb8, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return drain_events(c);
+}
+
+int hr_get_stats(hr_ctx *c, hr_stats *out) {
+    if (!c || !out) return fail(HR_ERR_INVALID, "hr_get_stats: null argument");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->paths = c->counters ? h.paths : c->paths_rendered;
+    out->rays = h.rays; out->node_tests = h.node_tests; out->tri_tests = h.tri_tests;
+    out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow;
+    out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
+    out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
+    out->bvh_nodes = c->st_nodes; out->triangles = c->st_tris; out->spheres = c->st_spheres; out->cuboids = c->st_cuboids;
+    return HR_OK;
+}
+
+int hr_set_option(hr_ctx *c, const char *key, double value) {
+    if (!c || !key) return fail(HR_ERR_INVALID, "hr_set_option: null argument");
+    std::string k = key;
+    if (k == "counters") { c->counters = value != 0.0; return HR_OK; }
+    if (k == "batch") {
+        if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "batch must be in [1,64]");
+        int rc = sync_all(c);
+        if (rc) return rc;
+        c->batch = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "rng_window") {
+        if ((int)value != ISAAC_TAIL) return fail(HR_ERR_UNSUPPORTED, "rng_window is fixed at %d in this build", ISAAC_TAIL);
+        return HR_OK;
+    }
+    return fail(HR_ERR_INVALID, "unknown option '%s'", key);
+}
+
+int hr_debug_draws(hr_ctx *c, uint32_t sampling, uint32_t first_path, uint32_t num_paths, uint32_t window, uint64_t *host_out) {
+    if (!c || !host_out || !num_paths) return fail(HR_ERR_INVALID, "hr_debug_draws: bad argument");
+    if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_debug_draws: hr_set_resolution not called");
+    if (window == 0 || window > (uint32_t)ISAAC_TAIL) return fail(HR_ERR_INVALID, "window must be in [1,%d]", ISAAC_TAIL);
+    if ((uint64_t)first_path + num_paths > (uint64_t)c->W * c->H * 4) return fail(HR_ERR_INVALID, "path range outside the image");
+    HIP_TRY(hipSetDevice(c->device));
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)num_paths * window * 8));
+    hipLaunchKernelGGL(seed_debug_kernel, dim3((num_paths + 63) / 64), dim3(64), 256 * 64 * 8, c->stream, c->W, c->H, sampling, first_path, num_paths,
+                       (int)window, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host_out, d, (size_t)num_paths * window * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_draws: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
+    // the 20 fp32 draws per path exactly as the production seed kernel hands them to the trace kernel,
+    // re-ordered to pixel-major paths: out[((y*W + x)*4 + sub) * 20 + d]
+    if (!c || !host_out) return fail(HR_ERR_INVALID, "hr_debug_path_draws: bad argument");
+    if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_debug_path_draws: hr_set_resolution not called");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_debug_path_draws: no scene (lens shape needed)");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    RenderParams rp{};
+    rp.width = c->W; rp.height = c->H; rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
+    rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
+    uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    size_t floats = (size_t)tiles * DRAWS_PER_PATH * 64;
+    if ((rc = ensure_draws(c, floats))) return rc;
+    if ((rc = launch_seed(c, rp, c->draws[0], c->stream))) return rc;
+    std::vector<float> h(floats);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(h.data(), c->draws[0], floats * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint32_t t = 0; t < tiles; t++)
+        for (uint32_t j = 0; j < 64; j++) {
+            uint32_t tx = t % rp.tiles_x, ty = t / rp.tiles_x, pix = j >> 2, sub = j & 3;
+            uint32_t px = tx * 4 + (pix & 3), py = ty * 4 + (pix >> 2);
+            if (px >= c->W || py >= c->H) continue;
+            for (int d = 0; d < DRAWS_PER_PATH; d++)
+                host_out[(((size_t)py * c->W + px) * 4 + sub) * DRAWS_PER_PATH + d] = h[((size_t)t * DRAWS_PER_PATH + d) * 64 + j];
+        }
+    return drain_events(c);
+}
+
+int hr_debug_intersect(hr_ctx *c, uint32_t n, const float *rays, float *out, int32_t *out_element) {
+    if (!c || !rays || !out || !out_element || !n) return fail(HR_ERR_INVALID, "hr_debug_intersect: bad argument");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_debug_intersect: no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_rays = nullptr, *d_out = nullptr;
+    int32_t *d_el = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, (size_t)n * 6 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)n * 8 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_el, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(intersect_debug_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->dsc, n, d_rays, d_out, d_el);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 8 * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_element, d_el, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(d_el);
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_intersect: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+}  // extern "C"

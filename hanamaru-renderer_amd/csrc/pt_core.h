@@ -1,0 +1,433 @@
+// fp32 per-lane path-tracing core: everything below PathTracingRenderer::calc_pixel (renderer.rs:163-203).
+// Written as __host__ __device__ inline functions over the POD device scene so the identical code runs
+// in the HIP kernels (hr_api.hip) and in the host emulation used by the CPU-only tests (tests/emu).
+//
+// Structure: a path is a small state machine (`Path`) driven by three calls
+//     path_start()   — camera ray (camera.rs:83-96), iteration 1
+//     trace_step()   — ONE node visit of the stackless threaded BVH traversal (replaces bvh.rs:213-263)
+//     path_advance() — when the current ray is finished: shade / NEE / next ray (renderer.rs:174-200)
+// so that a wavefront can keep all 64 lanes in the traversal loop and refill finished lanes.
+#pragma once
+#include <math.h>
+
+#include "device_scene.h"
+
+namespace hr {
+
+struct V3f { float x, y, z; };
+HD V3f v3(float x, float y, float z) { V3f r; r.x = x; r.y = y; r.z = z; return r; }
+HD V3f v3(const float *p) { return v3(p[0], p[1], p[2]); }
+HD V3f operator+(V3f a, V3f b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HD V3f operator-(V3f a, V3f b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HD V3f operator*(V3f a, V3f b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HD V3f operator*(V3f a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+HD V3f operator*(float s, V3f a) { return v3(a.x * s, a.y * s, a.z * s); }
+HD V3f operator-(V3f a) { return v3(-a.x, -a.y, -a.z); }
+HD float dot(V3f a, V3f b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HD V3f cross(V3f a, V3f b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HD V3f normalize(V3f a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+HD V3f reflect(V3f v, V3f n) { return v - (2.0f * dot(v, n)) * n; }  // vector.rs:60-62
+HD bool is_zero(V3f a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+HD float saturatef(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+HD bool sign_neg(float v) { return signbit(v); }
+
+static const float PI_F = 3.14159265358979323846f;
+static const float PI2_F = 6.28318530717958647692f;
+static const float EPS_F = 1e-4f;      // config.rs:7-8
+static const float OFFSET_F = 1e-4f;
+static const float T_INF = 3.0e38f;    // config.rs:9 INF = 1e100 (f64); fp32 stand-in
+
+struct Ray {
+    V3f o, d, inv;
+    uint32_t oct;
+};
+HD void ray_set(Ray &r, V3f o, V3f d) {
+    r.o = o; r.d = d;
+    r.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // bvh.rs:21-25 (±inf for zero components)
+    r.oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+}
+
+struct TraceState {
+    uint32_t cur;     // node to visit next, NODE_END = finished
+    float t;          // closest distance so far
+    int32_t prim;     // leaf-ordered primitive index of the closest hit, -1 = none
+    int32_t type;     // 0 tri, 1 sphere, 2 cuboid
+    float u, v;       // barycentrics (triangles)
+};
+HD void trace_begin(TraceState &ts, float tmax) { ts.cur = 0; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; }
+
+struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests; };
+
+// bvh.rs:266-290 (Cramer's rule, two-sided, accepts t == best) with e1,e2 precomputed
+template <bool CNT>
+HD void tri_test(const Tri &tr, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
+    if (CNT) cn->tri_tests++;
+    V3f e1 = v3(tr.e1x, tr.e1y, tr.e1z), e2 = v3(tr.e2x, tr.e2y, tr.e2z);
+    V3f ri = -r.d;
+    V3f c12 = cross(e1, e2);                 // det(e1,e2,c) = (e1 x e2) . c
+    float den = dot(c12, ri);
+    if (den == 0.0f) return;
+    float inv = 1.0f / den;
+    V3f dd = r.o - v3(tr.v0);
+    V3f q = cross(dd, ri);                   // helpers: det(d,e2,ri) = -(d x ri).e2 ... written out below
+    float u = -dot(q, e2) * inv;             // det(d, e2, ri)  = d . (e2 x ri) = -(d x ri) . e2
+    if (u < 0.0f || u > 1.0f) return;
+    float v = dot(q, e1) * inv;              // det(e1, d, ri)  = e1 . (d x ri)
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = dot(c12, dd) * inv;            // det(e1, e2, d)
+    if (t < 0.0f || t > ts.t) return;
+    ts.t = t; ts.prim = index; ts.type = 0; ts.u = u; ts.v = v;
+}
+// scene.rs:58-78 (outer root only)
+template <bool CNT>
+HD void sphere_test(const f4 &s, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
+    if (CNT) cn->sphere_tests++;
+    V3f a = r.o - v3(s.x, s.y, s.z);
+    float b = dot(a, r.d);
+    float c = dot(a, a) - s.w * s.w;
+    float d = b * b - c;
+    if (!(d > 0.0f)) return;
+    float t = -b - sqrtf(d);
+    if (t > 0.0f && t < ts.t) { ts.t = t; ts.prim = index; ts.type = 1; }
+}
+// bvh.rs:20-39: returns hit flag and the reference's `distance` (tmin if sign-positive else tmax)
+HD bool slab(const float *bmin, const float *bmax, const Ray &r, float &tmin, float &tmax) {
+    float t1 = (bmin[0] - r.o.x) * r.inv.x, t2 = (bmax[0] - r.o.x) * r.inv.x;
+    float t3 = (bmin[1] - r.o.y) * r.inv.y, t4 = (bmax[1] - r.o.y) * r.inv.y;
+    float t5 = (bmin[2] - r.o.z) * r.inv.z, t6 = (bmax[2] - r.o.z) * r.inv.z;
+    tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    return tmin <= tmax && !signbit(tmax);
+}
+// scene.rs:152-158 (hit part)
+template <bool CNT>
+HD void cuboid_test(const f4 &mn, const f4 &mx, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
+    if (CNT) cn->cuboid_tests++;
+    float tmin, tmax;
+    float bmin[3] = {mn.x, mn.y, mn.z}, bmax[3] = {mx.x, mx.y, mx.z};
+    if (!slab(bmin, bmax, r, tmin, tmax)) return;
+    float dist = signbit(tmin) ? tmax : tmin;
+    if (dist < ts.t) { ts.t = dist; ts.prim = index; ts.type = 2; }
+}
+
+// One node visit of the threaded traversal.  Nodes whose entry distance exceeds the closest hit so far
+// are skipped (the reference visits them, bvh.rs:214,240 — the closest hit is the same).
+template <bool CNT>
+HD void trace_step(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    const Node nd = sc.nodes[ts.cur];
+    const Link lk = sc.links[(size_t)r.oct * sc.num_nodes + ts.cur];
+    if (CNT) cn->node_tests++;
+    float tmin, tmax;
+    bool hit = slab(nd.bmin, nd.bmax, r, tmin, tmax) && tmin <= ts.t;
+    if (!hit) { ts.cur = lk.miss; return; }
+    if (nd.leaf) {
+        uint32_t type = (nd.leaf >> 28) - 1u, count = (nd.leaf >> 20) & 0xffu, first = nd.leaf & 0xfffffu;
+        if (type == 0) {
+            for (uint32_t k = 0; k < count; k++) tri_test<CNT>(sc.tris[first + k], r, ts, (int32_t)(first + k), cn);
+        } else if (type == 1) {
+            for (uint32_t k = 0; k < count; k++) sphere_test<CNT>(sc.spheres[first + k], r, ts, (int32_t)(first + k), cn);
+        } else {
+            for (uint32_t k = 0; k < count; k++)
+                cuboid_test<CNT>(sc.cuboids[2 * (first + k)], sc.cuboids[2 * (first + k) + 1], r, ts, (int32_t)(first + k), cn);
+        }
+    }
+    ts.cur = lk.hit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// surface attributes of the closest hit
+struct Surf { V3f pos, n; float u, v; int32_t elem; };
+
+HD int32_t float_as_int(float f) { union { float f; int32_t i; } c; c.f = f; return c.i; }
+
+HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s) {
+    s.pos = r.o + r.d * ts.t;
+    s.u = ts.u; s.v = ts.v;
+    if (ts.type == 0) {
+        const Tri tr = sc.tris[ts.prim];
+        s.n = normalize(cross(v3(tr.e1x, tr.e1y, tr.e1z), v3(tr.e2x, tr.e2y, tr.e2z)));  // bvh.rs:286 (never flipped)
+        s.elem = tr.element;
+    } else if (ts.type == 1) {
+        const f4 sp = sc.spheres[ts.prim];
+        s.n = normalize(s.pos - v3(sp.x, sp.y, sp.z));
+        s.elem = sc.sphere_elem[ts.prim];
+        if (want_uv) {  // scene.rs:67-71
+            s.v = 1.0f - acosf(s.n.y) / PI_F;
+            float sg = signbit(s.n.z) ? -1.0f : 1.0f;
+            s.u = 0.5f - sg * acosf(s.n.x / sqrtf(s.n.x * s.n.x + s.n.z * s.n.z)) / PI2_F;
+        }
+    } else {
+        const f4 mn = sc.cuboids[2 * ts.prim], mx = sc.cuboids[2 * ts.prim + 1];
+        s.elem = float_as_int(mn.w);
+        V3f uvw = v3((s.pos.x - mn.x) / (mx.x - mn.x), (s.pos.y - mn.y) / (mx.y - mn.y), (s.pos.z - mn.z) / (mx.z - mn.z));
+        // scene.rs:160-182 face cascade Y+, Y-, X-, X+, Z-, Z+
+        s.n = v3(0.f, 0.f, 0.f);
+        if (fabsf(s.pos.y - mx.y) < EPS_F) { s.n = v3(0, 1, 0); s.u = uvw.x; s.v = 1.0f - uvw.z; }
+        else if (fabsf(s.pos.y - mn.y) < EPS_F) { s.n = v3(0, -1, 0); s.u = uvw.x; s.v = 1.0f - uvw.z; }
+        else if (fabsf(s.pos.x - mn.x) < EPS_F) { s.n = v3(-1, 0, 0); s.u = uvw.z; s.v = uvw.y; }
+        else if (fabsf(s.pos.x - mx.x) < EPS_F) { s.n = v3(1, 0, 0); s.u = uvw.z; s.v = uvw.y; }
+        else if (fabsf(s.pos.z - mn.z) < EPS_F) { s.n = v3(0, 0, -1); s.u = uvw.x; s.v = uvw.y; }
+        else if (fabsf(s.pos.z - mx.z) < EPS_F) { s.n = v3(0, 0, 1); s.u = uvw.x; s.v = uvw.y; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// textures — texture.rs:29-63, color.rs:18-36
+HD uint32_t f32_as_u32_sat(float v) {  // Rust `as u32`
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967040.0f) return 4294967295u;
+    return (uint32_t)v;
+}
+HD V3f texel(const Scene &sc, const ImageRef &im, uint32_t x, uint32_t y) {
+    x = x > im.width - 1 ? im.width - 1 : x;
+    uint32_t yy = im.height - y - 1u;  // wrapping
+    yy = yy > im.height - 1 ? im.height - 1 : yy;
+    uint32_t p = sc.texels[im.offset + yy * im.width + x];
+    return v3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
+}
+HD float gamma_to_linear(float v) { return powf(v, 2.2f); }
+HD V3f sample_bilinear(const Scene &sc, int32_t image, float u, float v) {
+    const ImageRef im = sc.images[image];
+    float x = u * (float)im.width, y = v * (float)im.height;
+    float x1 = floorf(x), y1 = floorf(y);
+    float x2 = x1 + 1.0f, y2 = y1 + 1.0f;
+    uint32_t ix1 = f32_as_u32_sat(x1), ix2 = f32_as_u32_sat(x2), iy1 = f32_as_u32_sat(y1), iy2 = f32_as_u32_sat(y2);
+    V3f p11 = texel(sc, im, ix1, iy1), p12 = texel(sc, im, ix1, iy2), p21 = texel(sc, im, ix2, iy1), p22 = texel(sc, im, ix2, iy2);
+    V3f g = p11 * ((x2 - x) * (y2 - y)) + p21 * ((x - x1) * (y2 - y)) + p12 * ((x2 - x) * (y - y1)) + p22 * ((x - x1) * (y - y1));
+    return v3(gamma_to_linear(g.x), gamma_to_linear(g.y), gamma_to_linear(g.z));
+}
+HD V3f tex_sample(const Scene &sc, int32_t image, V3f tint, float u, float v) {  // texture.rs:108-114
+    if (image >= 0) return sample_bilinear(sc, image, u, v) * tint;
+    return tint;
+}
+HD V3f sky_sample(const Scene &sc, V3f d) {  // scene.rs:295-319
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float u, v;
+    if (ax > ay && ax > az) {
+        if (!signbit(d.x)) { face = 0; u = -d.z / d.x; v = d.y / d.x; } else { face = 1; u = -d.z / d.x; v = -d.y / d.x; }
+    } else if (ay > ax && ay > az) {
+        if (!signbit(d.y)) { face = 2; u = d.x / d.y; v = -d.z / d.y; } else { face = 3; u = -d.x / d.y; v = -d.z / d.y; }
+    } else {
+        if (!signbit(d.z)) { face = 4; u = d.x / d.z; v = d.y / d.z; } else { face = 5; u = d.x / d.z; v = -d.y / d.z; }
+    }
+    return v3(sc.sky_intensity) * sample_bilinear(sc, sc.sky_image[face], 0.5f * (u + 1.0f), 0.5f * (v + 1.0f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// BSDFs — material.rs
+struct PointMat { int32_t surface; float param; V3f albedo, emission; float roughness; };
+
+HD void material_at(const Scene &sc, int32_t elem, float u, float v, PointMat &m) {  // scene.rs:389-396
+    const Material mt = sc.materials[elem];
+    m.surface = mt.surface; m.param = mt.param;
+    m.albedo = tex_sample(sc, mt.albedo_img, v3(mt.albedo), u, v);
+    m.emission = tex_sample(sc, mt.emission_img, v3(mt.emission), u, v);
+    m.roughness = (mt.roughness_img >= 0) ? sample_bilinear(sc, mt.roughness_img, u, v).x * mt.roughness : mt.roughness;
+}
+HD bool material_needs_uv(const Scene &sc, int32_t elem) {
+    const Material &mt = sc.materials[elem];
+    return mt.albedo_img >= 0 || mt.emission_img >= 0 || mt.roughness_img >= 0;
+}
+HD bool nee_available(int32_t surface) { return surface == 0 || surface == 3; }  // material.rs:42-51
+
+HD void tangent_basis(V3f n, V3f &t, V3f &b) {  // material.rs:202-211
+    V3f up = fabsf(n.x) > EPS_F ? v3(0, 1, 0) : v3(1, 0, 0);
+    t = normalize(cross(up, n));
+    b = cross(n, t);
+}
+HD V3f sample_diffuse(float r0, float r1, V3f n) {  // material.rs:227-248
+    V3f t, b;
+    tangent_basis(n, t, b);
+    float phi = PI2_F * r0;
+    return (t * cosf(phi) + b * sinf(phi)) * sqrtf(r1) + n * sqrtf(1.0f - r1);
+}
+HD V3f sample_ggx_half(float r0, float r1, V3f n, float alpha2) {  // material.rs:260-269
+    V3f t, b;
+    tangent_basis(n, t, b);
+    float phi = PI2_F * r0;
+    float cos_theta = sqrtf((1.0f - r1) / (1.0f + (alpha2 - 1.0f) * r1));
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    return t * (sin_theta * cosf(phi)) + b * (sin_theta * sinf(phi)) + n * cos_theta;
+}
+HD float smith_lambda(float xn, float alpha2) { float a = 1.0f / (xn * xn) - 1.0f; return 0.5f * sqrtf(1.0f + alpha2 * a) - 0.5f; }
+HD float g_smith_joint(float ln, float vn, float alpha2) { return 1.0f / (1.0f + smith_lambda(ln, alpha2) + smith_lambda(vn, alpha2)); }
+HD float f_schlick(float vh, float f0) { float x = 1.0f - vh, x2 = x * x; return f0 + (1.0f - f0) * (x * (x2 * x2)); }
+
+HD float bsdf_eval(int32_t surface, float param, float roughness, V3f view, V3f n, V3f light) {  // material.rs:53-89
+    if (surface == 0) return 1.0f / PI_F;
+    float alpha2 = roughness * roughness;
+    V3f h = normalize(light + view);
+    float ln = dot(light, n);
+    if (signbit(ln)) return 0.0f;
+    float vn = dot(view, n), vh = dot(view, h), hn = dot(h, n);
+    float tmp = 1.0f - (1.0f - alpha2) * hn * hn;
+    float d = alpha2 / (PI_F * tmp * tmp);
+    return d * g_smith_joint(ln, vn, alpha2) * f_schlick(vh, param) / (4.0f * ln * vn);
+}
+// material.rs:154-199
+HD void sample_refraction(float r0, V3f pos, V3f view, V3f n, float ior, V3f &no, V3f &nd, float &refl) {
+    bool incoming = signbit(dot(view, n));
+    V3f on = incoming ? n : -n;
+    float nnt = incoming ? 1.0f / ior : ior;
+    V3f rdir = reflect(view, on);
+    float vn = dot(view, on);
+    float k = 1.0f - nnt * nnt * (1.0f - vn * vn);  // vector.rs:64-71
+    if (k < 0.0f) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; return; }
+    V3f tdir = nnt * view - (nnt * vn + sqrtf(k)) * on;
+    if (is_zero(tdir)) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; return; }
+    float cos_i = dot(view, -on), cos_t = dot(tdir, -on);
+    float a = nnt * cos_i - cos_t, b = nnt * cos_i + cos_t, c = nnt * cos_t - cos_i, d = nnt * cos_t + cos_i;
+    float fr = 0.5f * (a * a / (b * b) + c * c / (d * d));
+    if (r0 <= fr) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; }
+    else { no = pos - OFFSET_F * on; nd = tdir; refl = nnt * nnt; }
+}
+// material.rs:91-151; returns false for "sampled below the horizon" (None)
+HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3f n, V3f &no, V3f &nd, float &refl) {
+    V3f in = -view;
+    switch (m.surface) {
+        case 0: no = pos + n * OFFSET_F; nd = sample_diffuse(r0, r1, n); refl = 1.0f; return true;
+        case 1: no = pos + n * OFFSET_F; nd = reflect(in, n); refl = 1.0f; return true;
+        case 2: sample_refraction(r0, pos, in, n, m.param, no, nd, refl); return true;
+        case 3: {
+            float alpha2 = m.roughness * m.roughness;
+            V3f h = sample_ggx_half(r0, r1, n, alpha2);
+            V3f l = reflect(in, h);
+            float ln = dot(l, n);
+            if (signbit(ln)) return false;
+            float vn = dot(view, n), vh = dot(view, h), hn = dot(h, n);
+            refl = f_schlick(vh, m.param) * saturatef(g_smith_joint(ln, vn, alpha2) * vh / (hn * vn));
+            no = pos + n * OFFSET_F; nd = l;
+            return true;
+        }
+        default: {
+            V3f h = sample_ggx_half(r0, r1, n, m.roughness * m.roughness);
+            sample_refraction(r0, pos, in, h, m.param, no, nd, refl);
+            return true;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the path state machine
+struct Path {
+    uint32_t q;           // path slot inside the tile batch, 0xffffffff = lane idle
+    uint32_t draw_base;   // index of draw 0 of this path in the draws buffer (stride 64 between draws)
+    int32_t iter;         // 1..9 (renderer.rs:174)
+    int32_t phase;        // 0 = main ray in flight, 1 = shadow ray in flight
+    Ray ray;
+    TraceState ts;
+    V3f accum, refl;
+    // valid while a shadow ray is in flight
+    V3f next_o, next_d; float cur_refl;
+    V3f albedo, emission;
+    V3f view, n; int32_t surface; float param, roughness;
+    V3f nee_sum, nee_p, shadow_dir, shadow_vec;
+    int32_t emitter;
+    float r0, r1;
+};
+static const uint32_t PATH_IDLE = 0xffffffffu;
+
+// camera.rs:83-96 with the lens sample already resolved by the seed kernel (draws 0,1 = 2u-1, 2v-1)
+HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const float *draws) {
+    float fx = (float)px, fy = (float)(rp.height - py);
+    float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
+    float m = (float)(rp.width < rp.height ? rp.width : rp.height);
+    float ncx = ((fx + ox) * 2.0f - (float)rp.width) / m, ncy = ((fy + oy) * 2.0f - (float)rp.height) / m;
+    const CameraF &c = sc.cam;
+    float lx = draws[p.draw_base] * c.lens_radius, ly = draws[p.draw_base + 64] * c.lens_radius;
+    V3f lens_pos = v3(c.right) * lx + v3(c.up) * ly;
+    V3f dir = normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward) - lens_pos);
+    ray_set(p.ray, v3(c.eye) + lens_pos, dir);
+    p.iter = 1; p.phase = 0;
+    p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
+    trace_begin(p.ts, T_INF);
+}
+
+// scene.rs:92-101 + renderer.rs:276-279: set up the shadow ray toward emitter p.emitter
+HD void nee_setup(const Scene &sc, Path &p) {
+    const Emitter em = sc.emitters[p.emitter];
+    float theta = PI2_F * p.r0, unit_z = 1.0f - 2.0f * p.r1;
+    float a = sqrtf(1.0f - unit_z * unit_z);
+    V3f sn = v3(a * cosf(theta), a * sinf(theta), unit_z);
+    p.nee_p = v3(em.c) + (em.r + OFFSET_F) * sn;
+    p.shadow_vec = p.nee_p - p.next_o;
+    p.shadow_dir = normalize(p.shadow_vec);
+    ray_set(p.ray, p.next_o, p.shadow_dir);
+    // closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4)
+    trace_begin(p.ts, sqrtf(dot(p.shadow_vec, p.shadow_vec)) + 0.03f);
+    p.phase = 1;
+    // keep the sample normal's cosine for later: recomputed in nee_finish from nee_p - centre
+}
+
+// returns true when the path is finished (accum final)
+template <bool CNT>
+HD bool path_advance(const Scene &sc, Path &p, const float *draws, LaneCounters *cn) {
+    if (CNT) cn->rays++;
+    bool hit = p.ts.prim >= 0;
+    if (p.phase == 0) {
+        p.r0 = draws[p.draw_base + 64u * (2u * (uint32_t)p.iter)];
+        p.r1 = draws[p.draw_base + 64u * (2u * (uint32_t)p.iter + 1u)];
+        if (hit) {
+            Surf s;
+            // element id is needed before we know whether uv matters; spheres: look it up first
+            int32_t elem = (p.ts.type == 0) ? sc.tris[p.ts.prim].element
+                                            : (p.ts.type == 1 ? sc.sphere_elem[p.ts.prim] : float_as_int(sc.cuboids[2 * p.ts.prim].w));
+            hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, elem), s);
+            PointMat m;
+            material_at(sc, s.elem, s.u, s.v, m);
+            p.view = -p.ray.d;
+            if (!bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, p.cur_refl)) return true;  // renderer.rs:190-193
+            p.albedo = m.albedo; p.emission = m.emission;
+            if (nee_available(m.surface) && sc.num_emitters > 0) {
+                p.n = s.n; p.surface = m.surface; p.param = m.param; p.roughness = m.roughness;
+                p.nee_sum = v3(0, 0, 0);
+                p.emitter = 0;
+                nee_setup(sc, p);
+                return false;
+            }
+        } else {
+            p.emission = sky_sample(sc, p.ray.d);  // scene.rs:398
+            p.albedo = v3(1, 1, 1);
+            p.cur_refl = 1.0f;
+        }
+    } else {
+        // renderer.rs:280-292
+        if (hit) {
+            V3f hp = p.ray.o + p.ray.d * p.ts.t;
+            V3f dp = hp - p.nee_p;
+            if (dot(dp, dp) < OFFSET_F * 4.0f) {
+                Surf s;
+                int32_t elem = (p.ts.type == 0) ? sc.tris[p.ts.prim].element
+                                                : (p.ts.type == 1 ? sc.sphere_elem[p.ts.prim] : float_as_int(sc.cuboids[2 * p.ts.prim].w));
+                const Material mt = sc.materials[elem];
+                V3f e = v3(mt.emission);
+                if (mt.emission_img >= 0) {
+                    hit_surface(sc, p.ray, p.ts, true, s);
+                    e = tex_sample(sc, mt.emission_img, e, s.u, s.v);
+                }
+                const Emitter em = sc.emitters[p.emitter];
+                V3f sn = (p.nee_p - v3(em.c)) * (1.0f / (em.r + OFFSET_F));
+                float dot_0 = fabsf(dot(p.n, p.shadow_dir)), dot_l = fabsf(dot(sn, p.shadow_dir));
+                float g = (dot_0 * dot_l) / dot(p.shadow_vec, p.shadow_vec);
+                float pdf = 1.0f / (4.0f * PI_F * em.r * em.r);
+                float w = bsdf_eval(p.surface, p.param, p.roughness, p.view, p.n, p.shadow_dir) * g / pdf;
+                p.nee_sum = p.nee_sum + e * w;
+            }
+        }
+        p.emitter++;
+        if ((uint32_t)p.emitter < sc.num_emitters) { nee_setup(sc, p); return false; }
+        p.accum = p.accum + p.refl * (p.nee_sum * p.albedo);  // renderer.rs:183-185, 295
+        hit = true;                                             // the main ray of this iteration did hit
+        p.phase = 0;
+    }
+    // renderer.rs:196-199
+    p.accum = p.accum + p.refl * p.emission;
+    p.refl = p.refl * (p.albedo * p.cur_refl);
+    if (!hit || is_zero(p.refl) || p.iter >= 9) return true;
+    p.iter++;
+    ray_set(p.ray, p.next_o, p.next_d);
+    trace_begin(p.ts, T_INF);
+    return false;
+}
+
+}  // namespace hr

@@ -1,0 +1,151 @@
+// hanamaru-hip — host driver with the reference binary's flag surface and outputs (main.rs:1226-1295,
+// renderer.rs:205-251): `hanamaru-hip -w W -h H -s S -t SEC -i SEC`.  Stand-in for the Rust host (no Rust
+// toolchain here): scene authoring + PNG writing stay on the host, the render loop calls the C ABI.
+// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hanamaru_hip.h"
+#include "hanamaru_host.h"
+
+static FILE *g_log = nullptr;
+static void tee(const char *fmt, ...) {  // main.rs:47-51
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    printf("%s\n", buf);
+    if (g_log) { fputs(buf, g_log); fputc('\n', g_log); }
+}
+static double now_sec() {
+    using namespace std::chrono;
+    return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
+}
+#define CHECK_HR(expr)                                                          \
+    do {                                                                        \
+        int rc_ = (expr);                                                       \
+        if (rc_ != 0) { fprintf(stderr, "%s: %s\n", #expr, hr_last_error()); return 1; } \
+    } while (0)
+
+static void usage(const char *prog) {
+    printf("Usage: %s [options]\n\nOptions:\n"
+           "        --help          print this help menu\n"
+           "    -d, --debug         use debug mode (not supported by the HIP back end)\n"
+           "    -w, --width WIDTH   output resolution width\n"
+           "    -h, --height HEIGHT output resolution height\n"
+           "    -s, --sampling SAMPLING\n                        sampling limit\n"
+           "    -t, --time TIME     time limit sec\n"
+           "    -i, --interval INTERVAL\n                        report interval sec\n"
+           "        --scene NAME    rtcamp6_v3_1 (default) | spheres | rtcamp6_dodeca | cornell_mini\n"
+           "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
+           "        --batch N       samplings per kernel launch (default 4)\n",
+           prog);
+}
+
+int main(int argc, char **argv) {
+    uint32_t width = 1920, height = 1080, sampling = 1000;  // main.rs:1249-1251
+    double time_limit = 123.0, interval = 15.0;              // main.rs:1255-1256
+    std::string scene_name = "rtcamp6_v3_1", assets;
+    int batch = 4;
+    bool debug = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { fprintf(stderr, "Argument to option '%s' missing.\n", name); exit(1); }
+            return argv[++i];
+        };
+        if (a == "--help") { usage(argv[0]); return 0; }
+        else if (a == "-d" || a == "--debug") debug = true;
+        else if (a == "-w" || a == "--width") width = (uint32_t)strtoul(val("w"), nullptr, 10);
+        else if (a == "-h" || a == "--height") height = (uint32_t)strtoul(val("h"), nullptr, 10);
+        else if (a == "-s" || a == "--sampling") sampling = (uint32_t)strtoul(val("s"), nullptr, 10);
+        else if (a == "-t" || a == "--time") time_limit = strtod(val("t"), nullptr);
+        else if (a == "-i" || a == "--interval") interval = strtod(val("i"), nullptr);
+        else if (a == "--scene") scene_name = val("scene");
+        else if (a == "--assets") assets = val("assets");
+        else if (a == "--batch") batch = atoi(val("batch"));
+        else { fprintf(stderr, "Unrecognized option: '%s'.\n", a.c_str()); return 1; }
+    }
+    if (debug) { fprintf(stderr, "debug renderer (renderer.rs:101-146) is out of scope for the HIP back end\n"); return 1; }
+    if (assets.empty()) {
+        FILE *probe = fopen("assets/models/box.obj", "rb");
+        if (probe) { fclose(probe); assets = "assets"; } else assets = ".";
+    }
+    g_log = fopen("result.txt", "w");
+    double total_begin = now_sec();
+    tee("num threads: %d.", 1);  // main.rs:1261 prints rayon's pool size; here: one host thread drives one GPU
+    tee("resolution: %ux%u.", width, height);
+    tee("max sampling: %ux%u spp.", sampling, 4u);
+    tee("time limit: %.2f sec.", time_limit);
+    tee("report interval: %.2f sec.", interval);
+
+    double init_begin = now_sec();
+    hh_scene *scene = nullptr;
+    if (hh_scene_create(scene_name.c_str(), assets.c_str(), &scene) != 0) { fprintf(stderr, "scene: %s\n", hh_last_error()); return 1; }
+    hr_ctx *ctx = nullptr;
+    CHECK_HR(hr_create(0, &ctx));
+    CHECK_HR(hr_upload_scene(ctx, hh_scene_desc(scene)));
+    CHECK_HR(hr_set_resolution(ctx, width, height));
+    CHECK_HR(hr_set_option(ctx, "batch", batch));
+    tee("init scene: %.2f sec.", now_sec() - init_begin);
+
+    // Renderer::render + report_progress (renderer.rs:25-46, 205-251) at batch granularity
+    std::vector<uint8_t> rgb((size_t)width * height * 3);
+    double begin = now_sec(), last_progress = begin, last_image = begin;
+    uint32_t counter = 0, sampled = 0;
+    auto save = [&](uint32_t s) -> int {
+        char path[32];
+        snprintf(path, sizeof path, "%03u.png", counter);
+        double t0 = now_sec();
+        if (hr_resolve(ctx, s, rgb.data()) != 0) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
+        printf("update_imgbuf: %.3f sec\n", now_sec() - t0);
+        return hh_write_png_rgb8(path, rgb.data(), width, height);
+    };
+    for (uint32_t s = 1; s <= sampling;) {
+        uint32_t e = s + (uint32_t)batch;
+        if (e > sampling + 1) e = sampling + 1;
+        CHECK_HR(hr_render(ctx, s, e, 1));
+        CHECK_HR(hr_synchronize(ctx));
+        sampled = e - 1;
+        double now = now_sec();
+        double used = now - begin, last = now - last_progress;
+        printf("rendering: %ux4 sampled (last %.3f sec). total: %.3f sec (%.2f %%).\n", sampled, last, used, used / time_limit * 100.0);
+        bool stop = false;
+        if (used + last * 1.1 > time_limit) { printf("reached time limit\n"); stop = true; }
+        else if (sampled >= sampling) { printf("reached max sampling\n"); stop = true; }
+        if (stop) {
+            printf("output final image: %03u.png\n", counter);
+            printf("remain: %.3f sec.\n", time_limit - used);
+            if (save(sampled)) return 1;
+            break;
+        }
+        if (now - last_image >= interval) {
+            printf("output progress image: %03u.png\n", counter);
+            if (save(sampled)) return 1;
+            counter++;
+            last_image = now;
+        }
+        last_progress = now;
+        s = e;
+    }
+    if (hh_write_png_rgb8("result.png", rgb.data(), width, height) != 0) { fprintf(stderr, "png: %s\n", hh_last_error()); return 1; }
+    tee("sampled: %ux%u spp.", sampled, 4u);
+    hr_stats st;
+    if (hr_get_stats(ctx, &st) == 0) {
+        double sec = st.trace_kernel_ms * 1e-3;
+        tee("gpu: %.3f Mpaths/s wall, trace kernel %.3f s, seed kernel %.3f s.", (double)st.paths / (now_sec() - begin) * 1e-6, sec, st.seed_kernel_ms * 1e-3);
+    }
+    double total = now_sec() - total_begin;
+    double used_percent = total / time_limit * 100.0;
+    tee("total %g sec. used %.2f %% (x %.2f)", total, used_percent, 100.0 / used_percent);
+    hr_destroy(ctx);
+    hh_scene_destroy(scene);
+    if (g_log) fclose(g_log);
+    return 0;
+}

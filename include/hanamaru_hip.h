@@ -165,6 +165,11 @@ int hr_set_option(hr_ctx *ctx, const char *key, double value);
 int hr_debug_draws(hr_ctx *ctx, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
                    uint32_t window, uint64_t *host_out);
 
+/* The DRAWS_PER_PATH (=20) fp32 draws the seed kernel hands to the trace kernel for every path of one
+ * sampling: out[((y*W + x)*4 + sub)*20 + d]; d=0,1 = accepted lens sample (2u-1, 2v-1) after the rejection
+ * loop of camera.rs:66-81, d=2.. = the (f64,f64) pairs of renderer.rs:175 in order. */
+int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
+
 /* Closest-hit query for n rays (scene.rs:385-401 minus the material fetch).
  * rays: n * 6 floats (origin, direction).  out per ray: 8 floats
  * { hit(0/1), distance, pos.x, pos.y, pos.z, n.x, n.y, n.z }, plus element index in out_element. */

@@ -1,0 +1,81 @@
+"""ctypes loader for tests/emu/libhr_emu.so (host emulation of the kernels' per-lane code; tests only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhr_emu.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        L.emu_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.emu_scene_destroy.argtypes = [C.c_void_p]
+        L.emu_scene_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_path_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
+        L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
+        L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class EmuScene:
+    def __init__(self, desc_ptr):
+        h = C.c_void_p()
+        rc = lib().emu_scene_create(C.cast(desc_ptr, C.c_void_p), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("emu_scene_create failed: %d" % rc)
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().emu_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def stats(self):
+        out = (C.c_uint64 * 7)()
+        lib().emu_scene_stats(self._h, out)
+        return dict(zip(["nodes", "leaves", "max_depth", "tris", "spheres", "cuboids", "emitters"], list(out)))
+
+    def render(self, w, h, s_begin, s_end, stride=1, threads=0, acc=None):
+        if acc is None:
+            acc = np.zeros((h, w, 3), dtype=np.float32)
+        cn = (C.c_uint64 * 6)()
+        lib().emu_render(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data, cn)
+        return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests"], list(cn)))
+
+    def intersect(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.empty((r.shape[0], 8), dtype=np.float32)
+        el = np.empty((r.shape[0],), dtype=np.int32)
+        lib().emu_intersect(self._h, r.shape[0], r.ctypes.data, out.ctypes.data, el.ctypes.data)
+        return out, el
+
+
+def path_draws(w, h, x, y, sub, sampling, lens_shape=1):
+    out = np.empty(20, dtype=np.float32)
+    rc = lib().emu_path_draws(w, h, x, y, sub, sampling, lens_shape, out.ctypes.data)
+    return out, rc == 0
+
+
+def raw_draws(w, h, x, y, sub, sampling, window=64):
+    out = np.empty(window, dtype=np.uint64)
+    lib().emu_raw_draws(w, h, x, y, sub, sampling, window, out.ctypes.data)
+    return out
+
+
+def resolve(acc, samplings):
+    a = np.ascontiguousarray(acc, dtype=np.float32)
+    h, w, _ = a.shape
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    lib().emu_resolve(a.ctypes.data, w, h, samplings, out.ctypes.data)
+    return out

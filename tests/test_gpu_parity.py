@@ -1,0 +1,189 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
+include/hanamaru_hip.h; the f64 oracle is the checker.
+
+Tolerances (stated once, used everywhere):
+  * integer work (ISAAC-64 outputs, seed words): bit-exact.
+  * fp32 draws handed to the trace kernel: equal to the oracle's f64 draws rounded once to fp32.
+  * closest-hit queries: same element; |t_gpu - t_ref| <= 2e-5 * max(1, t_ref).
+  * radiance accumulator, per channel: |gpu - oracle| <= 1e-2 * max(1, |oracle|) for >= 99.5 % of channels
+    (an fp32 rounding difference can flip a branch — Fresnel coin, hit/miss at a silhouette — and then that
+    one path decorrelates completely), and the image mean agrees to 2e-3 relative.
+  * 8-bit image after the post chain, fed the SAME accumulator: <= 1 LSB on every channel, > 99 % exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL_REL = 1e-2
+FRAC_OK = 0.995
+
+
+def _compare(acc, ref):
+    rel = np.abs(acc.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    return float((rel <= ATOL_REL).mean()), float(acc.mean()), float(ref.mean())
+
+
+def test_isaac64_raw_outputs_bit_exact(gpu, scenes, orc):
+    sc, _ = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    for (w, h, sampling) in [(480, 270, 1), (33, 17, 7), (1920, 1080, 1024)]:
+        gpu.set_resolution(w, h)
+        n = min(w * h * 4, 256)
+        first = (w * h * 4 - n) if sampling == 7 else 0
+        got = gpu.debug_draws(sampling, first, n, 64)
+        for i in range(0, n, 17):
+            p = first + i
+            pix, sub = p >> 2, p & 3
+            ref = orc.path_draws(w, h, pix % w, pix // w, sub & 1, sub >> 1, sampling, 64)
+            assert np.array_equal(got[i], ref), (w, h, sampling, p)
+
+
+def test_path_draws_match_oracle_after_lens_rejection(gpu, scenes, orc):
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    w, h, sampling = 64, 36, 3
+    gpu.set_resolution(w, h)
+    import ctypes as C
+    out = np.empty((h, w, 4, 20), dtype=np.float32)
+    rc = gpu.L.hr_debug_path_draws(gpu._h, sampling, C.c_void_p(out.ctypes.data))
+    assert rc == 0, gpu.L.hr_last_error()
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        x, y, sub = int(rng.integers(w)), int(rng.integers(h)), int(rng.integers(4))
+        raw = orc.path_draws(w, h, x, y, sub & 1, sub >> 1, sampling, 64)
+        f = [orc.u64_to_f64(v) for v in raw]
+        j = 0
+        while not ((2 * f[2 * j] - 1) ** 2 + (2 * f[2 * j + 1] - 1) ** 2 < 1.0):
+            j += 1
+        exp = [2 * f[2 * j] - 1, 2 * f[2 * j + 1] - 1] + f[2 * j + 2:2 * j + 20]
+        assert np.array_equal(out[y, x, sub], np.asarray(exp, dtype=np.float64).astype(np.float32)), (x, y, sub)
+
+
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "cornell_mini", "spheres"])
+def test_closest_hit_matches_oracle(gpu, scenes, name):
+    sc, o = scenes(name)
+    gpu.upload_scene(sc)
+    rng = np.random.default_rng(7)
+    n = 4000
+    cam = sc.desc.camera
+    eye = np.array(cam.eye.tuple())
+    org = eye + rng.normal(size=(n, 3)) * 0.3
+    tgt = rng.uniform(-2.5, 2.5, size=(n, 3)) * np.array([1.0, 0.6, 1.0]) + np.array([0, 0.8, 0])
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays32 = np.concatenate([org, d], axis=1).astype(np.float32)
+    got, gel = gpu.debug_intersect(rays32)
+    ref, rel = o.intersect(rays32.astype(np.float64))
+    same_hit = got[:, 0] == ref[:, 0]
+    assert same_hit.mean() > 0.999
+    both = same_hit & (ref[:, 0] == 1)
+    assert (gel[both] == rel[both]).mean() > 0.998
+    ok = both & (gel == rel)
+    terr = np.abs(got[ok, 1] - ref[ok, 1]) / np.maximum(1.0, ref[ok, 1])
+    assert terr.max() < 2e-5, terr.max()
+    nerr = np.abs(got[ok, 5:8] - ref[ok, 5:8]).max(axis=1)
+    assert np.quantile(nerr, 0.999) < 1e-4
+
+
+@pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 160, 90, 4), ("cornell_mini", 96, 64, 4), ("spheres", 128, 72, 2),
+                                         ("rtcamp6_dodeca", 98, 55, 2)])
+def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
+    sc, o = scenes(name)
+    gpu.upload_scene(sc)
+    gpu.set_resolution(w, h)
+    gpu.set_option("batch", 3)
+    gpu.render(1, s + 1)
+    acc = gpu.read_accumulator()
+    ref, _ = o.render(w, h, 1, s + 1, threads=0)
+    frac, m_gpu, m_ref = _compare(acc, ref)
+    assert frac >= FRAC_OK, (frac, m_gpu, m_ref)
+    assert abs(m_gpu - m_ref) <= 2e-3 * max(1.0, abs(m_ref)), (m_gpu, m_ref)
+
+
+def test_golden_accumulator(gpu, scenes):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rtcamp6_64x36_s2.npz"))
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(64, 36)
+    gpu.render(1, 3)
+    frac, m_gpu, m_ref = _compare(gpu.read_accumulator(), g["acc"].astype(np.float64))
+    assert frac >= FRAC_OK and abs(m_gpu - m_ref) <= 2e-3 * max(1.0, m_ref)
+
+
+def test_sharding_and_batching_are_exact_partitions(gpu, scenes):
+    """Size-independent properties: samplings are independent units, so any partition of the sampling
+    range (batch size, stride sharding as used across GPUs) must give the same sum up to fp32 order."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(120, 68)
+    gpu.set_option("batch", 8)
+    gpu.render(1, 9)
+    whole = gpu.read_accumulator().astype(np.float64)
+    gpu.clear()
+    gpu.set_option("batch", 1)
+    for rank in range(4):
+        gpu.render(1 + rank, 9, 4)
+    parts = gpu.read_accumulator().astype(np.float64)
+    assert np.abs(whole - parts).max() <= 1e-4 * max(1.0, np.abs(whole).max())
+    # determinism of a repeat
+    gpu.clear()
+    gpu.set_option("batch", 8)
+    gpu.render(1, 9)
+    again = gpu.read_accumulator().astype(np.float64)
+    assert np.abs(whole - again).max() <= 1e-5 * max(1.0, np.abs(whole).max())
+    gpu.set_option("batch", 4)
+
+
+def test_full_size_properties(gpu, scenes):
+    """BASELINE size (1920x1080): path count, every pixel touched, mean radiance agrees with a low-res
+    oracle render of the same scene (the image mean is resolution independent to first order)."""
+    sc, o = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(1920, 1080)
+    gpu.set_option("counters", 1)
+    gpu.clear()
+    gpu.render(1, 3)
+    acc = gpu.read_accumulator()
+    st = gpu.stats()
+    gpu.set_option("counters", 0)
+    assert st["paths"] == 1920 * 1080 * 4 * 2
+    assert st["rng_overflow"] == 0
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    assert (acc.sum(axis=2) > 0).mean() > 0.99
+    assert 2.5 < st["rays"] / st["paths"] < 3.6          # 3.05 rays per path
+    ref, _ = o.render(240, 135, 1, 3, threads=0)
+    assert abs(acc.mean() - ref.mean()) < 0.05 * ref.mean()
+
+
+def test_post_chain_matches_oracle(gpu, scenes, orc):
+    sc, o = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    for (w, h) in [(96, 64), (8, 5), (1, 1), (3, 1)]:
+        ref, _ = o.render(w, h, 1, 3, threads=0)
+        gpu.set_resolution(w, h)
+        gpu.write_accumulator(ref.astype(np.float32))
+        img = gpu.resolve(2)
+        exp = orc.resolve(ref.astype(np.float32).astype(np.float64), 2)
+        diff = np.abs(img.astype(int) - exp.astype(int))
+        assert diff.max() <= 1, (w, h, diff.max())
+        assert (diff == 0).mean() > 0.99 or w * h < 50
+
+
+def test_error_paths(ha):
+    r = ha.Renderer(0)
+    with pytest.raises(ha.HipError) as e:
+        r.render(1, 2)
+    assert e.value.code == -3          # no scene
+    sc = ha.Scene("cornell_mini")
+    r.upload_scene(sc)
+    with pytest.raises(ha.HipError) as e:
+        r.render(1, 2)
+    assert e.value.code == -4          # no target
+    r.set_resolution(4, 4)
+    r.render(5, 5)                     # empty range is a no-op
+    assert not r.read_accumulator().any()
+    with pytest.raises(ha.HipError):
+        r.set_option("nonsense", 1)
+    r.close()
