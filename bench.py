@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--batch", type=int, default=4, help="samplings per kernel launch")
     ap.add_argument("--scene", default="rtcamp6_v3_1")
+    ap.add_argument("--adv-den", type=int, default=0, help="trace kernel early-exit denominator (0 = library default)")
+    ap.add_argument("--leaf-den", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -69,6 +71,10 @@ def main():
     r.upload_scene(scene)
     r.set_resolution(W, H)
     r.set_option("batch", args.batch)
+    if args.adv_den:
+        r.set_option("adv_den", args.adv_den)
+    if args.leaf_den:
+        r.set_option("leaf_den", args.leaf_den)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
     paths_per_step_gpu = W * H * 4 * SPS

@@ -163,57 +163,54 @@ static float round_up(double v, int ulps) {
 }  // namespace
 
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out) {
-    out.nodes.clear(); out.links.clear();
+    out.nodes.clear();
     for (auto &o : out.order) o.clear();
-    out.max_depth = 0; out.num_leaves = 0;
+    out.max_depth = 0; out.num_leaves = 0; out.num_nodes = 0;
     if (prims.empty()) {
-        // a single empty leaf that nothing hits
+        // a single box that nothing hits
         Node n{};
         n.bmin[0] = n.bmin[1] = n.bmin[2] = 1e30f;
         n.bmax[0] = n.bmax[1] = n.bmax[2] = -1e30f;
-        n.leaf = 0;
-        out.nodes.push_back(n);
-        out.links.assign(8, Link{NODE_END, NODE_END});
+        n.a = NODE_END; n.b = NODE_END;
+        out.nodes.assign(8, n);
+        out.num_nodes = 1;
         return;
     }
     Builder b(prims, max_leaf);
     b.build(0, (uint32_t)prims.size(), 0);
     out.max_depth = b.max_depth;
     size_t N = b.nodes.size();
-    // builder already allocates in DFS preorder (left first): index == memory order
-    out.nodes.resize(N);
-    // leaf-ordered primitive arrays per type
-    std::vector<uint32_t> leaf_first(N, 0);
+    out.num_nodes = (uint32_t)N;
+    // the builder allocates in DFS preorder (left first): index == memory order
+    std::vector<uint32_t> leaf_word(N, 0);
     for (size_t i = 0; i < N; i++) {
         const BNode &bn = b.nodes[i];
         if (bn.left < 0) {
-            leaf_first[i] = (uint32_t)out.order[bn.type].size();
+            uint32_t first = (uint32_t)out.order[bn.type].size();
             for (uint32_t k = 0; k < bn.count; k++) out.order[bn.type].push_back(prims[b.idx[bn.first + k]].index);
+            leaf_word[i] = ((uint32_t)(bn.type + 1) << 28) | (bn.count << 20) | first;
             out.num_leaves++;
         }
     }
-    for (size_t i = 0; i < N; i++) {
-        const BNode &bn = b.nodes[i];
-        Node &n = out.nodes[i];
-        for (int a = 0; a < 3; a++) { n.bmin[a] = round_down(bn.box.mn[a], 2); n.bmax[a] = round_up(bn.box.mx[a], 2); }
-        n.pad = 0;
-        n.leaf = (bn.left < 0) ? (((uint32_t)(bn.type + 1) << 28) | (bn.count << 20) | leaf_first[i]) : 0u;
-    }
-    out.links.assign(8 * N, Link{NODE_END, NODE_END});
+    out.nodes.assign(8 * N, Node{});
     for (int o = 0; o < 8; o++) {
-        Link *lk = &out.links[(size_t)o * N];
-        // iterative assignment of (hit, miss) with an explicit stack of (node, next_after_subtree)
+        Node *nd = &out.nodes[(size_t)o * N];
+        for (size_t i = 0; i < N; i++) {
+            const BNode &bn = b.nodes[i];
+            for (int a = 0; a < 3; a++) { nd[i].bmin[a] = round_down(bn.box.mn[a], 2); nd[i].bmax[a] = round_up(bn.box.mx[a], 2); }
+        }
+        // iterative assignment of the successors with an explicit stack of (node, next_after_subtree)
         std::vector<std::pair<int, uint32_t>> st;
         st.emplace_back(0, NODE_END);
         while (!st.empty()) {
             auto [id, after] = st.back();
             st.pop_back();
             const BNode &bn = b.nodes[id];
-            lk[id].miss = after;
-            if (bn.left < 0) { lk[id].hit = after; continue; }
+            nd[id].b = after;
+            if (bn.left < 0) { nd[id].a = leaf_word[id]; continue; }
             bool neg = (o >> bn.axis) & 1;  // ray travels toward -axis: the higher-coordinate child is nearer
             int nearc = neg ? bn.right : bn.left, farc = neg ? bn.left : bn.right;
-            lk[id].hit = (uint32_t)nearc;
+            nd[id].a = (uint32_t)nearc;
             st.emplace_back(nearc, (uint32_t)farc);
             st.emplace_back(farc, after);
         }

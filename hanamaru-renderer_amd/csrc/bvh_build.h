@@ -17,8 +17,8 @@ struct BuildPrim {
 };
 
 struct BuiltBvh {
-    std::vector<Node> nodes;
-    std::vector<Link> links;          // 8 * nodes.size()
+    std::vector<Node> nodes;          // 8 * num_nodes, octant-major: box + (hit | leaf word, miss)
+    uint32_t num_nodes = 0;
     std::vector<uint32_t> order[3];   // per type: leaf-ordered -> caller index
     uint32_t max_depth = 0, num_leaves = 0;
 };

@@ -1,8 +1,8 @@
 // Device-side scene layout (fp32, SoA-ish, all in HBM; the geometry part is ~1 MB and lives in L2).
 //
-//   nodes[]      32 B   one AABB + leaf word.  Shared by all 8 traversal orders.
-//   links[o][]    8 B   {hit, miss} successor of a node for ray-direction octant o (stackless threaded
-//                       traversal: near child first by the sign of the ray direction on the split axis).
+//   nodes[o][]   32 B   one AABB + the two successors of the node for ray-direction octant o (stackless
+//                       threaded traversal, near child first by the sign of the ray direction on the split
+//                       axis).  One record = two 16-byte loads; the 8 octant copies (8 x ~350 KB) stay in L2.
 //   tris[]       48 B   leaf-ordered: v0, e1 = v1-v0, e2 = v2-v0 (edges formed in f64, then rounded) + element id
 //   spheres[]    16 B   centre, radius            (+ sphere_elem[])
 //   cuboids[]    32 B   min, max                  (+ element id in .w of the first float4)
@@ -26,10 +26,11 @@ struct alignas(16) f4 { float x, y, z, w; };
 
 struct alignas(16) Node {
     float bmin[3];
-    uint32_t leaf;    // 0 = inner; else (type+1) << 28 | count << 20 | first   (type: 0 tri, 1 sphere, 2 cuboid)
+    uint32_t a;       // box hit -> inner: next node; leaf: (type+1) << 28 | count << 20 | first  (type: 0 tri, 1 sphere, 2 cuboid)
     float bmax[3];
-    uint32_t pad;
+    uint32_t b;       // box missed (or leaf done) -> next node in this octant's order, NODE_END = finished
 };
+HD bool node_word_is_leaf(uint32_t a) { return (a >> 28) != 0u && a != 0xffffffffu; }
 static const uint32_t NODE_END = 0xffffffffu;
 
 struct alignas(8) Link { uint32_t hit, miss; };
@@ -58,8 +59,7 @@ struct CameraF {
 };
 
 struct Scene {
-    const Node *nodes;
-    const Link *links;       // [8][num_nodes]
+    const Node *nodes;       // [8][num_nodes], octant-major
     const Tri *tris;
     const f4 *spheres; const int32_t *sphere_elem;
     const f4 *cuboids;       // 2 per cuboid: {min, element-as-int-bits}, {max, 0}
@@ -78,12 +78,16 @@ struct RenderParams {
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;        // 4x4-pixel tiles
     uint32_t sampling_begin, stride, num_k;
-    uint32_t pad;
+    uint32_t adv_den;                 // trace kernel: leave the traversal loop when 1/adv_den of the live lanes are done
+    uint32_t leaf_den;                // trace kernel: run the leaf phase when 1/leaf_den of the traversing lanes parked a leaf
+    uint32_t pad[3];
 };
 
-// draws per path handed from the seed kernel to the trace kernel: 2 lens + 9 iterations x 2
-static const int DRAWS_PER_PATH = 20;
-static const int ISAAC_TAIL = 64;     // outputs rsl[255-63 .. 255] kept per path (lens rejection window)
+// Hand-off from the seed kernel to the trace kernel, per path: the last ISAAC_TAIL raw generator outputs
+// (draw k = k-th next_u64) as [item][k][64 lanes] u64, plus the index of the accepted lens attempt.
+// A path consumes draws 2*a, 2*a+1 (lens) and 2*(a+i), 2*(a+i)+1 for iteration i = 1..9.
+static const int ISAAC_TAIL = 64;
+static const int DRAWS_PER_PATH = 20; // what a path can consume at most (debug API)
 
 struct Counters {
     unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, pad;

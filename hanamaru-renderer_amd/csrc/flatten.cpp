@@ -20,10 +20,10 @@ static int ferr(std::string &err, int code, const char *fmt, ...) {
 Scene HostScene::view() const {
     Scene d;
     memset(&d, 0, sizeof d);
-    d.nodes = nodes.data(); d.links = links.data(); d.tris = tris.data();
+    d.nodes = nodes.data(); d.tris = tris.data();
     d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.cuboids = cuboids.data();
     d.materials = materials.data(); d.texels = texels.data(); d.images = images.data(); d.emitters = emitters.data();
-    d.num_nodes = (uint32_t)nodes.size(); d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
+    d.num_nodes = num_nodes; d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
     d.num_cuboids = (uint32_t)(cuboids.size() / 2); d.num_elements = (uint32_t)materials.size(); d.num_emitters = (uint32_t)emitters.size();
     for (int f = 0; f < 6; f++) d.sky_image[f] = sky_image[f];
     for (int k = 0; k < 3; k++) d.sky_intensity[k] = sky_intensity[k];
@@ -108,7 +108,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err) {
 
     BuiltBvh bvh;
     build_bvh(prims, 4, bvh);
-    out.nodes = bvh.nodes; out.links = bvh.links;
+    out.nodes = bvh.nodes; out.num_nodes = bvh.num_nodes;
     out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves;
 
     out.tris.assign(tris.size(), Tri{});

@@ -12,8 +12,8 @@
 namespace hr {
 
 struct HostScene {
-    std::vector<Node> nodes;
-    std::vector<Link> links;
+    std::vector<Node> nodes;   // [8][num_nodes]
+    uint32_t num_nodes = 0;
     std::vector<Tri> tris;
     std::vector<f4> spheres;
     std::vector<int32_t> sphere_elem;

@@ -53,13 +53,14 @@ struct LdsMem {
     __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
     __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
 };
-struct LdsTail {
-    float *col;
-    __device__ __forceinline__ float ld(int k) const { return col[k * 64]; }
-    __device__ __forceinline__ void st(int k, float v) { col[k * 64] = v; }
+// global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
+struct GlobalTail {
+    u64 *col;  // &tail[item][0][lane]
+    __device__ __forceinline__ u64 ld(int k) const { return col[k * 64]; }
+    __device__ __forceinline__ void st(int k, u64 v) { col[k * 64] = v; }
 };
 
-static const size_t SEED_LDS_BYTES = 256 * 64 * 8 + ISAAC_TAIL * 64 * 4;  // 128 KiB + 16 KiB
+static const size_t SEED_LDS_BYTES = 256 * 64 * 8;  // 128 KiB: mem[256][64 lanes] u64
 
 __device__ __forceinline__ void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint32_t &px, uint32_t &py, uint32_t &sub) {
     uint32_t tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
@@ -69,12 +70,14 @@ __device__ __forceinline__ void tile_lane_pixel(const RenderParams &rp, uint32_t
     py = ty * 4u + (pix >> 2);
 }
 
-// draws layout: [tile][k][DRAWS_PER_PATH][64 lanes]
-__global__ __launch_bounds__(64) void seed_isaac64_kernel(RenderParams rp, int lens_shape, float *__restrict__ draws, Counters *cnt) {
+// tails layout: [tile][k_sampling][ISAAC_TAIL][64 lanes] u64;  lens layout: [tile][k_sampling][64 lanes] u32
+__global__ __launch_bounds__(64) void seed_isaac64_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ tails, uint32_t *__restrict__ lens,
+                                                          Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64 *mem = reinterpret_cast<u64 *>(smem);
-    float *tail = reinterpret_cast<float *>(smem + 256 * 64 * 8);
     const uint32_t lane = threadIdx.x;
+    // one latency-bound wave per CU next to the trace kernel's waves: always win issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const IsaacWarm warm = isaac_warm();
     const uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -85,19 +88,13 @@ __global__ __launch_bounds__(64) void seed_isaac64_kernel(RenderParams rp, int l
         u64 s, t;
         path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
         LdsMem m{mem + lane};
-        LdsTail tm{tail + lane};
-        LensTail<LdsTail> lt(tm, lens_shape);
+        GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + lane};
+        RawLensTail<GlobalTail> lt(gt, lens_shape);
         isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
-        if (valid) {
-            bool ok = lt.accepted >= 0 && 2 * lt.accepted + DRAWS_PER_PATH <= ISAAC_TAIL;
-            size_t base = (size_t)item * DRAWS_PER_PATH * 64 + lane;
-            int first = ok ? 2 * lt.accepted + 2 : 0;
-            draws[base] = ok ? lt.sqx : 0.0f;
-            draws[base + 64] = ok ? lt.sqy : 0.0f;
-#pragma unroll
-            for (int d = 0; d < DRAWS_PER_PATH - 2; d++) draws[base + (size_t)(2 + d) * 64] = tm.ld(first + d);
-            if (!ok) atomicAdd(&cnt->rng_overflow, 1ULL);
-        }
+        lt.lens_slow();
+        bool ok = lt.in_window();
+        lens[(size_t)item * 64 + lane] = ok ? (uint32_t)lt.accepted : 0u;
+        if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
     }
 }
 
@@ -128,19 +125,26 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// One workgroup = 4 waves = 4 independent tiles (a single-wave workgroup caps residency at ~8 waves per CU).
+// No barriers: every wave owns its 48 floats of LDS and runs on its own.
+static const int TRACE_WAVES = 4;
+
 template <bool CNT>
-__global__ __launch_bounds__(64) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ draws, float *__restrict__ accum,
-                                                   Counters *cnt) {
-    __shared__ float tile_sum[48];
-    const uint32_t lane = threadIdx.x;
+__global__ __launch_bounds__(64 * TRACE_WAVES) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails, const uint32_t *__restrict__ lens,
+                                                                 float *__restrict__ accum, Counters *cnt) {
+    __shared__ float tile_sum_all[TRACE_WAVES][48];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float *tile_sum = tile_sum_all[wave];
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
-    // XCD-aware mapping: block b runs on XCD b % 8; give each XCD a contiguous band of tiles so its L2
-    // sees a compact part of the floor texture / BVH.
-    const uint32_t per_xcd = (tiles + 7u) / 8u;
-    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= tiles) return;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order).  Tiles differ in cost by an order of magnitude
+    // (sky vs. the wire-frame bunny), so neighbouring tile groups are dealt round-robin to the XCDs: every
+    // XCD sees the same mix of cheap and expensive image regions.  (A contiguous band per XCD was measured
+    // ~40 % slower: the XCDs holding the bunny finish last.)  The scene (~4 MB) is resident in every XCD's L2.
+    const uint32_t groups = (tiles + TRACE_WAVES - 1) / TRACE_WAVES;
+    const uint32_t group = blockIdx.x;
+    const uint32_t tile = group * TRACE_WAVES + wave;
+    if (group >= groups || tile >= tiles) return;
     if (lane < 48) tile_sum[lane] = 0.0f;
-    __syncthreads();
 
     LaneCounters lc = {0, 0, 0, 0, 0};
     uint32_t npaths = 0;
@@ -148,10 +152,24 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene sc, RenderParams rp, co
     uint32_t next = 0;  // wave-uniform queue head: slot q = k * 64 + j
     Path p;
     p.q = PATH_IDLE;
-    const size_t tile_draw_base = (size_t)tile * rp.num_k * DRAWS_PER_PATH * 64;
+    p.ts.cur = NODE_END; p.ts.leaf = 0;
+    const u64 *tile_tails = tails + (size_t)tile * rp.num_k * ISAAC_TAIL * 64;
+    const uint32_t *tile_lens = lens + (size_t)tile * rp.num_k * 64;
+    const uint32_t adv_den = rp.adv_den ? rp.adv_den : 4u;
+    const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
 
     for (;;) {
-        // ---- refill idle lanes from the tile's path queue (ballot + prefix rank)
+        // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
+        if (p.q != PATH_IDLE && trace_done(p.ts)) {
+            if (path_advance<CNT>(sc, p, tile_tails, &lc)) {
+                uint32_t pix = (p.q & 63u) >> 2;
+                atomicAdd(&tile_sum[pix * 3 + 0], p.accum.x);
+                atomicAdd(&tile_sum[pix * 3 + 1], p.accum.y);
+                atomicAdd(&tile_sum[pix * 3 + 2], p.accum.z);
+                p.q = PATH_IDLE;
+            }
+        }
+        // ---- B: refill idle lanes from the tile's path queue (ballot + prefix rank = live-lane compaction)
         unsigned long long idle = __ballot(p.q == PATH_IDLE);
         if (idle && next < total) {
             uint32_t q = next + lane_rank(idle);
@@ -160,34 +178,37 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene sc, RenderParams rp, co
                 tile_lane_pixel(rp, tile, j, px, py, sub);
                 if (px < rp.width && py < rp.height) {
                     p.q = q;
-                    p.draw_base = (uint32_t)(k * DRAWS_PER_PATH * 64 + j);
-                    path_start(sc, rp, p, px, py, sub, draws + tile_draw_base);
+                    p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
+                    p.lens_a = tile_lens[k * 64 + j];
+                    path_start(sc, rp, p, px, py, sub, tile_tails);
                     npaths++;
                 }
             }
             next += (uint32_t)__popcll(idle);
         }
-        bool active = p.q != PATH_IDLE;
-        if (!__ballot(active)) {
+        const bool active = p.q != PATH_IDLE;
+        const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+        if (!n_active) {
             if (next >= total) break;
             continue;
         }
-        // ---- traversal: every active lane walks its ray to completion
-        while (__ballot(active && p.ts.cur != NODE_END)) {
-            if (active && p.ts.cur != NODE_END) trace_step<CNT>(sc, p.ray, p.ts, &lc);
-        }
-        // ---- shade / NEE / next ray
-        if (active) {
-            if (path_advance<CNT>(sc, p, draws + tile_draw_base, &lc)) {
-                uint32_t pix = (p.q & 63u) >> 2;
-                atomicAdd(&tile_sum[pix * 3 + 0], p.accum.x);
-                atomicAdd(&tile_sum[pix * 3 + 1], p.accum.y);
-                atomicAdd(&tile_sum[pix * 3 + 2], p.accum.z);
-                p.q = PATH_IDLE;
+        // ---- C: traversal as two well-filled phases.  Box phase: lanes walk nodes until 1/leaf_den of the
+        //         traversing lanes have parked a leaf; leaf phase: those lanes test their primitives together.
+        //         The whole of C is left as soon as 1/adv_den of the live lanes wait for phase A.
+        for (;;) {
+            const bool trav = active && !trace_done(p.ts);
+            const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
+            if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
+            for (;;) {
+                const bool go = trav && p.ts.leaf == 0 && p.ts.cur != NODE_END;
+                const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
+                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
+                if (!n_go || n_leaf * leaf_den >= n_trav) break;
+                if (go) trace_node<CNT>(sc, p.ray, p.ts, &lc);
             }
+            if (trav && p.ts.leaf != 0) trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
         }
     }
-    __syncthreads();
     if (lane < 48) {
         uint32_t pix = lane / 3, c = lane - pix * 3;
         uint32_t px = (tile % rp.tiles_x) * 4u + (pix & 3u), py = (tile / rp.tiles_x) * 4u + (pix >> 2);
@@ -256,8 +277,9 @@ struct hr_ctx {
     bool have_scene = false;
     uint32_t W = 0, H = 0;
     float *accum_own = nullptr, *accum = nullptr;
-    float *draws[2] = {nullptr, nullptr};
-    size_t draws_cap = 0;  // floats per buffer
+    u64 *tails[2] = {nullptr, nullptr};
+    uint32_t *lens[2] = {nullptr, nullptr};
+    size_t draws_cap = 0;  // items (tile x sampling) per buffer
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
     bool trace_pending[2] = {false, false};
     Counters *d_counters = nullptr;
@@ -265,6 +287,7 @@ struct hr_ctx {
     uint8_t *d_rgb8 = nullptr;
     bool counters = false;
     uint32_t batch = 4;
+    uint32_t adv_den = 4, leaf_den = 2;
     int num_cus = 256;
     std::vector<EventPair> seed_events, trace_events, post_events;
     double seed_ms = 0, trace_ms = 0, post_ms = 0;
@@ -356,7 +379,8 @@ int hr_destroy(hr_ctx *c) {
         for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (int i = 0; i < 2; i++) {
-        if (c->draws[i]) (void)hipFree(c->draws[i]);
+        if (c->tails[i]) (void)hipFree(c->tails[i]);
+        if (c->lens[i]) (void)hipFree(c->lens[i]);
         if (c->seed_done[i]) (void)hipEventDestroy(c->seed_done[i]);
         if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
     }
@@ -385,7 +409,6 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     d = hs.view();
     int r;
     if ((r = upload(c, hs.nodes, &d.nodes))) return r;
-    if ((r = upload(c, hs.links, &d.links))) return r;
     if ((r = upload(c, hs.tris, &d.tris))) return r;
     if ((r = upload(c, hs.spheres, &d.spheres))) return r;
     if ((r = upload(c, hs.sphere_elem, &d.sphere_elem))) return r;
@@ -451,24 +474,27 @@ int hr_clear(hr_ctx *c) {
     return HR_OK;
 }
 
-static int ensure_draws(hr_ctx *c, size_t floats) {
-    if (floats <= c->draws_cap) return HR_OK;
+static int ensure_draws(hr_ctx *c, size_t items) {
+    if (items <= c->draws_cap) return HR_OK;
     for (int i = 0; i < 2; i++) {
-        if (c->draws[i]) { HIP_TRY(hipFree(c->draws[i])); c->draws[i] = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->draws[i], floats * sizeof(float)));
+        if (c->tails[i]) { HIP_TRY(hipFree(c->tails[i])); c->tails[i] = nullptr; }
+        if (c->lens[i]) { HIP_TRY(hipFree(c->lens[i])); c->lens[i] = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->tails[i], items * ISAAC_TAIL * 64 * sizeof(u64)));
+        HIP_TRY(hipMalloc((void **)&c->lens[i], items * 64 * sizeof(uint32_t)));
     }
-    c->draws_cap = floats;
+    c->draws_cap = items;
     return HR_OK;
 }
 
-static int launch_seed(hr_ctx *c, const RenderParams &rp, float *draws, hipStream_t st) {
+static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
     uint32_t grid = std::min<uint32_t>(items, (uint32_t)c->num_cus);
     EventPair ev;
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
-    hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, draws, c->d_counters);
+    hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot], c->lens[slot],
+                       c->d_counters);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, st));
     c->seed_events.push_back(ev);
@@ -487,9 +513,11 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.width = c->W; rp.height = c->H;
     rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
     rp.stride = stride;
+    rp.adv_den = c->adv_den;
+    rp.leaf_den = c->leaf_den;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     uint32_t batch = std::max<uint32_t>(1, c->batch);
-    int rc = ensure_draws(c, (size_t)tiles * batch * DRAWS_PER_PATH * 64);
+    int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
@@ -499,18 +527,21 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         c->batch_counter++;
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(c->seed_stream, c->trace_done[slot], 0));
-        if ((rc = launch_seed(c, rp, c->draws[slot], c->seed_stream))) return rc;
+        if ((rc = launch_seed(c, rp, slot, c->seed_stream))) return rc;
         HIP_TRY(hipEventRecord(c->seed_done[slot], c->seed_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
         EventPair ev;
         HIP_TRY(hipEventCreate(&ev.a));
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, c->stream));
-        uint32_t grid = ((tiles + 7u) / 8u) * 8u;
+        uint32_t groups = (tiles + TRACE_WAVES - 1) / TRACE_WAVES;
+        uint32_t grid = groups;
         if (c->counters)
-            hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, c->stream, c->dsc, rp, c->draws[slot], c->accum, c->d_counters);
+            hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64 * TRACE_WAVES), 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot],
+                               c->accum, c->d_counters);
         else
-            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, c->stream, c->dsc, rp, c->draws[slot], c->accum, c->d_counters);
+            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64 * TRACE_WAVES), 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot],
+                               c->accum, c->d_counters);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, c->stream));
         c->trace_events.push_back(ev);
@@ -601,6 +632,16 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->batch = (uint32_t)value;
         return HR_OK;
     }
+    if (k == "adv_den") {
+        if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "adv_den must be in [1,64]");
+        c->adv_den = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "leaf_den") {
+        if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "leaf_den must be in [1,64]");
+        c->leaf_den = (uint32_t)value;
+        return HR_OK;
+    }
     if (k == "rng_window") {
         if ((int)value != ISAAC_TAIL) return fail(HR_ERR_UNSUPPORTED, "rng_window is fixed at %d in this build", ISAAC_TAIL);
         return HR_OK;
@@ -639,19 +680,24 @@ int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
     rp.width = c->W; rp.height = c->H; rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
     rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
-    size_t floats = (size_t)tiles * DRAWS_PER_PATH * 64;
-    if ((rc = ensure_draws(c, floats))) return rc;
-    if ((rc = launch_seed(c, rp, c->draws[0], c->stream))) return rc;
-    std::vector<float> h(floats);
+    if ((rc = ensure_draws(c, tiles))) return rc;
+    if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
+    std::vector<u64> h((size_t)tiles * ISAAC_TAIL * 64);
+    std::vector<uint32_t> hl((size_t)tiles * 64);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(h.data(), c->draws[0], floats * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), c->tails[0], h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hl.data(), c->lens[0], hl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t t = 0; t < tiles; t++)
         for (uint32_t j = 0; j < 64; j++) {
             uint32_t tx = t % rp.tiles_x, ty = t / rp.tiles_x, pix = j >> 2, sub = j & 3;
             uint32_t px = tx * 4 + (pix & 3), py = ty * 4 + (pix >> 2);
             if (px >= c->W || py >= c->H) continue;
-            for (int d = 0; d < DRAWS_PER_PATH; d++)
-                host_out[(((size_t)py * c->W + px) * 4 + sub) * DRAWS_PER_PATH + d] = h[((size_t)t * DRAWS_PER_PATH + d) * 64 + j];
+            const u64 *col = &h[(size_t)t * ISAAC_TAIL * 64 + j];
+            uint32_t a = hl[(size_t)t * 64 + j];
+            float *o = &host_out[(((size_t)py * c->W + px) * 4 + sub) * DRAWS_PER_PATH];
+            o[0] = draw_lens_f32(col[(2 * a) * 64]);
+            o[1] = draw_lens_f32(col[(2 * a + 1) * 64]);
+            for (uint32_t d = 2; d < (uint32_t)DRAWS_PER_PATH; d++) o[d] = draw_f32(col[(2 * a + d) * 64]);
         }
     return drain_events(c);
 }

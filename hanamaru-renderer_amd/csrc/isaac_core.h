@@ -68,37 +68,63 @@ HD void isaac_seed_round(Mem &mem, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u
         mem.st(i, a); mem.st(i + 1, b); mem.st(i + 2, c); mem.st(i + 3, d);
         mem.st(i + 4, e); mem.st(i + 5, f); mem.st(i + 6, g); mem.st(i + 7, h);
     }
-    // one isaac64() round: a = b = 0, c = 1  ->  aa = 0, bb = 1
+    // one isaac64() round: a = b = 0, c = 1  ->  aa = 0, bb = 1.
+    // Step n (0..255) reads x = mem[n] and mem[(n+128)&255], gathers mem[(x>>3)&255], stores y to mem[n],
+    // gathers mem[(y>>11)&255].  The only serial chain is bb -> y -> second gather -> bb; everything else
+    // (x two steps ahead, the +128 operand and the first gather of the NEXT step) is issued in the same
+    // batch as the second gather, so a step costs one LDS round trip.  The two halves of the reference
+    // loop are kept as two loops so that every static index is affine in the loop counter (no "& 255").
     u64 aa = 0, bb = 1;
-    // software-pipelined: the first gather of step i+1 is issued before the second gather of step i is consumed
-    u64 x = mem.ld(0);
+    u64 x = mem.ld(0), xn = mem.ld(1), m2v = mem.ld(128);
     u64 g1 = mem.ld((int)((x >> 3) & 255));
-    for (int half = 0; half < 2; half++) {
-        const int mr = half ? 128 : 0, m2 = half ? 0 : 128;
-        HR_NOUNROLL
-        for (int base = 0; base < 128; base += 4) {
-#define HR_ISAAC_STEP(J, MIXEXPR)                                         \
+#define HR_ISAAC_STEP(N, MIXEXPR, XNN_IDX, M2N_IDX, TAIL)                 \
     {                                                                     \
-        const int i = base + J;                                           \
         u64 mixv = MIXEXPR;                                               \
-        aa = mixv + mem.ld(i + m2);                                       \
+        aa = mixv + m2v;                                                  \
         u64 y = g1 + aa + bb;                                             \
-        mem.st(i + mr, y);                                                \
+        mem.st(N, y);                                                     \
         u64 g2 = mem.ld((int)((y >> 11) & 255));                          \
-        int nxt = (i + mr + 1) & 255; /* wraps to 0 after the last step (unused) */ \
-        u64 xn = mem.ld(nxt);                                             \
         g1 = mem.ld((int)((xn >> 3) & 255));                              \
+        u64 xnn = mem.ld(XNN_IDX);                                        \
+        m2v = mem.ld(M2N_IDX);                                            \
         bb = g2 + x;                                                      \
-        if (i + mr >= 256 - ISAAC_TAIL) tail.put(i + mr, bb);             \
-        x = xn;                                                           \
+        if (TAIL) tail.put(N, bb);                                        \
+        x = xn; xn = xnn;                                                 \
     }
-            HR_ISAAC_STEP(0, ~(aa ^ (aa << 21)))
-            HR_ISAAC_STEP(1, aa ^ (aa >> 5))
-            HR_ISAAC_STEP(2, aa ^ (aa << 12))
-            HR_ISAAC_STEP(3, aa ^ (aa >> 33))
+    // first half: n in [0,128): x from mem[n..], +128 operand from mem[n+128..]; the last group is peeled
+    // because its "next" +128 operand is mem[0]
+    HR_NOUNROLL
+    for (int n = 0; n < 124; n += 4) {
+        HR_ISAAC_STEP(n, ~(aa ^ (aa << 21)), n + 2, n + 129, false)
+        HR_ISAAC_STEP(n + 1, aa ^ (aa >> 5), n + 3, n + 130, false)
+        HR_ISAAC_STEP(n + 2, aa ^ (aa << 12), n + 4, n + 131, false)
+        HR_ISAAC_STEP(n + 3, aa ^ (aa >> 33), n + 5, n + 132, false)
+    }
+    HR_ISAAC_STEP(124, ~(aa ^ (aa << 21)), 126, 253, false)
+    HR_ISAAC_STEP(125, aa ^ (aa >> 5), 127, 254, false)
+    HR_ISAAC_STEP(126, aa ^ (aa << 12), 128, 255, false)
+    HR_ISAAC_STEP(127, aa ^ (aa >> 33), 129, 0, false)
+    // second half: n in [128,256): +128 operand from mem[n-128..]
+    HR_NOUNROLL
+    for (int n = 128; n < 256 - ISAAC_TAIL; n += 4) {
+        HR_ISAAC_STEP(n, ~(aa ^ (aa << 21)), n + 2, n - 127, false)
+        HR_ISAAC_STEP(n + 1, aa ^ (aa >> 5), n + 3, n - 126, false)
+        HR_ISAAC_STEP(n + 2, aa ^ (aa << 12), n + 4, n - 125, false)
+        HR_ISAAC_STEP(n + 3, aa ^ (aa >> 33), n + 5, n - 124, false)
+    }
+    HR_NOUNROLL
+    for (int n = 256 - ISAAC_TAIL; n < 252; n += 4) {
+        HR_ISAAC_STEP(n, ~(aa ^ (aa << 21)), n + 2, n - 127, true)
+        HR_ISAAC_STEP(n + 1, aa ^ (aa >> 5), n + 3, n - 126, true)
+        HR_ISAAC_STEP(n + 2, aa ^ (aa << 12), n + 4, n - 125, true)
+        HR_ISAAC_STEP(n + 3, aa ^ (aa >> 33), n + 5, n - 124, true)
+    }
+    // last group: the look-ahead loads past the end are never used; point them at valid slots
+    HR_ISAAC_STEP(252, ~(aa ^ (aa << 21)), 254, 125, true)
+    HR_ISAAC_STEP(253, aa ^ (aa >> 5), 255, 126, true)
+    HR_ISAAC_STEP(254, aa ^ (aa << 12), 255, 127, true)
+    HR_ISAAC_STEP(255, aa ^ (aa >> 33), 255, 127, true)
 #undef HR_ISAAC_STEP
-        }
-    }
 }
 
 // renderer.rs:34-36,53-54 + 165-167: per-path seed words s, t from the pixel / sub-sample (f64, exact)
@@ -113,30 +139,44 @@ HD void path_seed_words(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     t = (u64)((4.0 + ncy) * 100304.0);
 }
 
-// Tail sink used by the production seed kernel: keeps fp32 draws + resolves the lens rejection loop
-// (camera.rs:66-81) in f64 on the fly.  Draw k = step 255-k; lens attempt j uses draws (2j, 2j+1).
-// Steps arrive in increasing order, i.e. v (odd k) before u (even k), attempts in decreasing j, so the
-// last accepted attempt seen is the first one the reference's loop would accept.
-template <class TailMem>  // void st(int k, float v); float ld(int k)
-struct LensTail {
-    TailMem &tm;
+// camera.rs:66-81: does lens attempt (u, v) pass the rejection test?  f64, exactly as the reference.
+HD bool lens_accept(u64 raw_u, u64 raw_v, int lens_shape) {
+    double x = 2.0 * isaac_to_f64(raw_u) - 1.0, y = 2.0 * isaac_to_f64(raw_v) - 1.0;
+    return lens_shape == 0 || (x * x + y * y < 1.0);
+}
+
+// Tail sink of the production seed kernel.  Draw k (= the k-th next_u64 of the path) is the output of
+// step 255-k; it is stored RAW (the trace kernel converts the few it consumes).  Lens attempt j uses
+// draws (2j, 2j+1); the first LENS_FAST attempts are judged on the fly (steps arrive v before u, attempts
+// in decreasing j, so the last accepted one seen is the first the reference's loop would accept); the
+// rare path that rejects all of them is resolved afterwards by lens_slow() from the stored outputs.
+static const int LENS_FAST = 8;
+template <class Store>  // void st(int k, u64 v); u64 ld(int k)
+struct RawLensTail {
+    Store &store;
     int lens_shape;
-    int accepted;      // attempt index, -1 = none yet
-    float sqx, sqy;    // (2u-1, 2v-1) of the accepted attempt, rounded once from f64
-    double pend_v;
-    HD LensTail(TailMem &t, int shape) : tm(t), lens_shape(shape), accepted(-1), sqx(0.f), sqy(0.f), pend_v(0.0) {}
+    int accepted;  // attempt index, -1 = none among the first LENS_FAST
+    u64 pend_v;
+    HD RawLensTail(Store &s, int shape) : store(s), lens_shape(shape), accepted(-1), pend_v(0) {}
     HD void put(int step, u64 value) {
         int k = 255 - step;
-        double dv = isaac_to_f64(value);
-        tm.st(k, (float)dv);
-        if (k & 1) {
-            pend_v = dv;
-        } else {
-            double x = 2.0 * dv - 1.0, y = 2.0 * pend_v - 1.0;
-            bool ok = (lens_shape == 0) || (x * x + y * y < 1.0);
-            if (ok) { accepted = k >> 1; sqx = (float)x; sqy = (float)y; }
+        store.st(k, value);
+        if (k < 2 * LENS_FAST) {
+            if (k & 1) pend_v = value;
+            else if (lens_accept(value, pend_v, lens_shape)) accepted = k >> 1;
         }
     }
+    HD void lens_slow() {
+        if (accepted >= 0) return;
+        for (int j = LENS_FAST; j < ISAAC_TAIL / 2; j++)
+            if (lens_accept(store.ld(2 * j), store.ld(2 * j + 1), lens_shape)) { accepted = j; return; }
+    }
+    // a path consumes draws up to index 2*(accepted + 9) + 1
+    HD bool in_window() const { return accepted >= 0 && 2 * (accepted + 9) + 1 < ISAAC_TAIL; }
 };
+
+// raw draw -> the fp32 value the trace kernel computes with (one rounding from the reference's f64)
+HD float draw_f32(u64 raw) { return (float)isaac_to_f64(raw); }
+HD float draw_lens_f32(u64 raw) { return (float)(2.0 * isaac_to_f64(raw) - 1.0); }
 
 }  // namespace hr

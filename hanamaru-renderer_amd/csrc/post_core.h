@@ -5,6 +5,12 @@
 
 #include "device_scene.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_POST_POWF(x, y) __builtin_amdgcn_exp2f((y) * __builtin_amdgcn_logf(x))
+#else
+#define HR_POST_POWF(x, y) powf((x), (y))
+#endif
+
 namespace hr {
 
 HD void tonemap_gamma(float r, float g, float b, float scale, float *out) {
@@ -13,9 +19,9 @@ HD void tonemap_gamma(float r, float g, float b, float scale, float *out) {
     float lum = 0.22f * cr + 0.707f * cg + 0.071f * cb;  // color.rs:63-65
     float k = (lum / (white * white) + 1.0f) / (lum + 1.0f);
     const float inv_gamma = 1.0f / 2.2f;
-    out[0] = powf(fminf(fmaxf(cr * k, 0.0f), 1.0f), inv_gamma);
-    out[1] = powf(fminf(fmaxf(cg * k, 0.0f), 1.0f), inv_gamma);
-    out[2] = powf(fminf(fmaxf(cb * k, 0.0f), 1.0f), inv_gamma);
+    out[0] = HR_POST_POWF(fminf(fmaxf(cr * k, 0.0f), 1.0f), inv_gamma);
+    out[1] = HR_POST_POWF(fminf(fmaxf(cg * k, 0.0f), 1.0f), inv_gamma);
+    out[2] = HR_POST_POWF(fminf(fmaxf(cb * k, 0.0f), 1.0f), inv_gamma);
 }
 
 HD float gaussianf(float x, float sigma) { return expf(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * 3.14159265358979f * sigma * sigma); }

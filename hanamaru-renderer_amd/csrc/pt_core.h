@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "device_scene.h"
+#include "isaac_core.h"
 
 namespace hr {
 
@@ -31,6 +32,17 @@ HD bool is_zero(V3f a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 HD float saturatef(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 HD bool sign_neg(float v) { return signbit(v); }
 
+// Transcendentals.  On the device the hardware forms are used: v_exp_f32(y * v_log_f32(x)) for x^y and
+// v_sin_f32 / v_cos_f32, which take their argument in REVOLUTIONS — exactly the 2*pi*r0 the samplers need,
+// so no range reduction is involved.  The host emulation uses libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_POWF(x, y) __builtin_amdgcn_exp2f((y) * __builtin_amdgcn_logf(x))
+#define HR_SINCOS_2PI(r, s, c) do { (s) = __builtin_amdgcn_sinf(r); (c) = __builtin_amdgcn_cosf(r); } while (0)
+#else
+#define HR_POWF(x, y) powf((x), (y))
+#define HR_SINCOS_2PI(r, s, c) do { float ph_ = 6.28318530717958647692f * (r); (s) = sinf(ph_); (c) = cosf(ph_); } while (0)
+#endif
+
 static const float PI_F = 3.14159265358979323846f;
 static const float PI2_F = 6.28318530717958647692f;
 static const float EPS_F = 1e-4f;      // config.rs:7-8
@@ -39,7 +51,7 @@ static const float T_INF = 3.0e38f;    // config.rs:9 INF = 1e100 (f64); fp32 st
 
 struct Ray {
     V3f o, d, inv;
-    uint32_t oct;
+    uint32_t oct;     // direction octant (bit k set = component k negative)
 };
 HD void ray_set(Ray &r, V3f o, V3f d) {
     r.o = o; r.d = d;
@@ -53,8 +65,10 @@ struct TraceState {
     int32_t prim;     // leaf-ordered primitive index of the closest hit, -1 = none
     int32_t type;     // 0 tri, 1 sphere, 2 cuboid
     float u, v;       // barycentrics (triangles)
+    uint32_t leaf;    // pending leaf word (node visited, primitives not yet tested), 0 = none
 };
-HD void trace_begin(TraceState &ts, float tmax) { ts.cur = 0; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; }
+HD void trace_begin(TraceState &ts, float tmax) { ts.cur = 0; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; ts.leaf = 0; }
+HD bool trace_done(const TraceState &ts) { return ts.cur == NODE_END && ts.leaf == 0; }
 
 struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests; };
 
@@ -78,14 +92,16 @@ HD void tri_test(const Tri &tr, const Ray &r, TraceState &ts, int32_t index, Lan
     if (t < 0.0f || t > ts.t) return;
     ts.t = t; ts.prim = index; ts.type = 0; ts.u = u; ts.v = v;
 }
-// scene.rs:58-78 (outer root only)
+// scene.rs:58-78 (outer root only).  Same roots as the reference's b^2 - c form, but the discriminant is
+// taken from the perpendicular offset of the centre (r^2 - |a - b d|^2), which does not cancel in fp32
+// when the origin is many radii away (the f64 reference does not need this).
 template <bool CNT>
 HD void sphere_test(const f4 &s, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
     if (CNT) cn->sphere_tests++;
     V3f a = r.o - v3(s.x, s.y, s.z);
     float b = dot(a, r.d);
-    float c = dot(a, a) - s.w * s.w;
-    float d = b * b - c;
+    V3f perp = a - b * r.d;
+    float d = s.w * s.w - dot(perp, perp);
     if (!(d > 0.0f)) return;
     float t = -b - sqrtf(d);
     if (t > 0.0f && t < ts.t) { ts.t = t; ts.prim = index; ts.type = 1; }
@@ -110,28 +126,45 @@ HD void cuboid_test(const f4 &mn, const f4 &mx, const Ray &r, TraceState &ts, in
     if (dist < ts.t) { ts.t = dist; ts.prim = index; ts.type = 2; }
 }
 
-// One node visit of the threaded traversal.  Nodes whose entry distance exceeds the closest hit so far
-// are skipped (the reference visits them, bvh.rs:214,240 — the closest hit is the same).
+// The traversal is split in two so that a wavefront can run them as separate, well-filled phases
+// ("while-while"): trace_node() is ONE box test of the stackless threaded walk and parks a hit leaf in
+// ts.leaf; trace_leaf() tests that leaf's primitives.  Nodes whose entry distance exceeds the closest hit
+// so far are skipped (the reference visits them, bvh.rs:214,240 — the closest hit is the same).
 template <bool CNT>
-HD void trace_step(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
-    const Node nd = sc.nodes[ts.cur];
-    const Link lk = sc.links[(size_t)r.oct * sc.num_nodes + ts.cur];
+HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
     if (CNT) cn->node_tests++;
     float tmin, tmax;
-    bool hit = slab(nd.bmin, nd.bmax, r, tmin, tmax) && tmin <= ts.t;
-    if (!hit) { ts.cur = lk.miss; return; }
-    if (nd.leaf) {
-        uint32_t type = (nd.leaf >> 28) - 1u, count = (nd.leaf >> 20) & 0xffu, first = nd.leaf & 0xfffffu;
-        if (type == 0) {
-            for (uint32_t k = 0; k < count; k++) tri_test<CNT>(sc.tris[first + k], r, ts, (int32_t)(first + k), cn);
-        } else if (type == 1) {
-            for (uint32_t k = 0; k < count; k++) sphere_test<CNT>(sc.spheres[first + k], r, ts, (int32_t)(first + k), cn);
-        } else {
-            for (uint32_t k = 0; k < count; k++)
-                cuboid_test<CNT>(sc.cuboids[2 * (first + k)], sc.cuboids[2 * (first + k) + 1], r, ts, (int32_t)(first + k), cn);
+    const bool hit = slab(nd.bmin, nd.bmax, r, tmin, tmax) && tmin <= ts.t;
+    const bool leaf = node_word_is_leaf(nd.a);
+    ts.cur = (hit && !leaf) ? nd.a : nd.b;
+    ts.leaf = (hit && leaf) ? nd.a : 0u;
+}
+template <bool CNT>
+HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    const uint32_t type = (ts.leaf >> 28) - 1u, count = (ts.leaf >> 20) & 0xffu, first = ts.leaf & 0xfffffu;
+    ts.leaf = 0;
+    if (type == 0) {
+        // two triangles per round so their loads are in flight together
+        for (uint32_t k = 0; k < count; k += 2) {
+            const Tri ta = sc.tris[first + k];
+            const bool two = k + 1 < count;
+            const Tri tb = sc.tris[first + (two ? k + 1 : k)];
+            tri_test<CNT>(ta, r, ts, (int32_t)(first + k), cn);
+            if (two) tri_test<CNT>(tb, r, ts, (int32_t)(first + k + 1), cn);
         }
+    } else if (type == 1) {
+        for (uint32_t k = 0; k < count; k++) sphere_test<CNT>(sc.spheres[first + k], r, ts, (int32_t)(first + k), cn);
+    } else {
+        for (uint32_t k = 0; k < count; k++)
+            cuboid_test<CNT>(sc.cuboids[2 * (first + k)], sc.cuboids[2 * (first + k) + 1], r, ts, (int32_t)(first + k), cn);
     }
-    ts.cur = lk.hit;
+}
+// scalar convenience (host emulation, debug kernel): one visit = node + its leaf
+template <bool CNT>
+HD void trace_step(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    trace_node<CNT>(sc, r, ts, cn);
+    if (ts.leaf) trace_leaf<CNT>(sc, r, ts, cn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -185,7 +218,7 @@ HD V3f texel(const Scene &sc, const ImageRef &im, uint32_t x, uint32_t y) {
     uint32_t p = sc.texels[im.offset + yy * im.width + x];
     return v3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
 }
-HD float gamma_to_linear(float v) { return powf(v, 2.2f); }
+HD float gamma_to_linear(float v) { return HR_POWF(v, 2.2f); }
 HD V3f sample_bilinear(const Scene &sc, int32_t image, float u, float v) {
     const ImageRef im = sc.images[image];
     float x = u * (float)im.width, y = v * (float)im.height;
@@ -238,16 +271,18 @@ HD void tangent_basis(V3f n, V3f &t, V3f &b) {  // material.rs:202-211
 HD V3f sample_diffuse(float r0, float r1, V3f n) {  // material.rs:227-248
     V3f t, b;
     tangent_basis(n, t, b);
-    float phi = PI2_F * r0;
-    return (t * cosf(phi) + b * sinf(phi)) * sqrtf(r1) + n * sqrtf(1.0f - r1);
+    float sn, cs;
+    HR_SINCOS_2PI(r0, sn, cs);
+    return (t * cs + b * sn) * sqrtf(r1) + n * sqrtf(1.0f - r1);
 }
 HD V3f sample_ggx_half(float r0, float r1, V3f n, float alpha2) {  // material.rs:260-269
     V3f t, b;
     tangent_basis(n, t, b);
-    float phi = PI2_F * r0;
+    float sn, cs;
+    HR_SINCOS_2PI(r0, sn, cs);
     float cos_theta = sqrtf((1.0f - r1) / (1.0f + (alpha2 - 1.0f) * r1));
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-    return t * (sin_theta * cosf(phi)) + b * (sin_theta * sinf(phi)) + n * cos_theta;
+    return t * (sin_theta * cs) + b * (sin_theta * sn) + n * cos_theta;
 }
 HD float smith_lambda(float xn, float alpha2) { float a = 1.0f / (xn * xn) - 1.0f; return 0.5f * sqrtf(1.0f + alpha2 * a) - 0.5f; }
 HD float g_smith_joint(float ln, float vn, float alpha2) { return 1.0f / (1.0f + smith_lambda(ln, alpha2) + smith_lambda(vn, alpha2)); }
@@ -311,30 +346,33 @@ HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3
 // the path state machine
 struct Path {
     uint32_t q;           // path slot inside the tile batch, 0xffffffff = lane idle
-    uint32_t draw_base;   // index of draw 0 of this path in the draws buffer (stride 64 between draws)
+    uint32_t draw_base;   // index of raw draw 0 of this path in the tile's tail buffer (stride 64 between draws)
+    uint32_t lens_a;      // accepted lens attempt: the path's draws start at 2 * lens_a
     int32_t iter;         // 1..9 (renderer.rs:174)
     int32_t phase;        // 0 = main ray in flight, 1 = shadow ray in flight
     Ray ray;
     TraceState ts;
     V3f accum, refl;
-    // valid while a shadow ray is in flight
-    V3f next_o, next_d; float cur_refl;
-    V3f albedo, emission;
+    // valid while a shadow ray is in flight (the bounce ray waits in next_o / next_d)
+    V3f next_o, next_d;
+    V3f refl_next;        // reflectance after this iteration: refl * albedo * current_reflectance (renderer.rs:197)
+    V3f nee_scale;        // refl * albedo: what one emitter's  emission * bsdf * G / pdf  is multiplied by
     V3f view, n; int32_t surface; float param, roughness;
-    V3f nee_sum, nee_p, shadow_dir, shadow_vec;
+    float shadow_len;     // |sample point - shadow origin|
     int32_t emitter;
     float r0, r1;
 };
 static const uint32_t PATH_IDLE = 0xffffffffu;
 
-// camera.rs:83-96 with the lens sample already resolved by the seed kernel (draws 0,1 = 2u-1, 2v-1)
-HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const float *draws) {
+// camera.rs:83-96 with the lens rejection loop already resolved by the seed kernel (attempt p.lens_a)
+HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const u64 *draws) {
     float fx = (float)px, fy = (float)(rp.height - py);
     float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
     float m = (float)(rp.width < rp.height ? rp.width : rp.height);
     float ncx = ((fx + ox) * 2.0f - (float)rp.width) / m, ncy = ((fy + oy) * 2.0f - (float)rp.height) / m;
     const CameraF &c = sc.cam;
-    float lx = draws[p.draw_base] * c.lens_radius, ly = draws[p.draw_base + 64] * c.lens_radius;
+    float lx = draw_lens_f32(draws[p.draw_base + 64u * (2u * p.lens_a)]) * c.lens_radius;
+    float ly = draw_lens_f32(draws[p.draw_base + 64u * (2u * p.lens_a + 1u)]) * c.lens_radius;
     V3f lens_pos = v3(c.right) * lx + v3(c.up) * ly;
     V3f dir = normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward) - lens_pos);
     ray_set(p.ray, v3(c.eye) + lens_pos, dir);
@@ -343,87 +381,83 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
     trace_begin(p.ts, T_INF);
 }
 
-// scene.rs:92-101 + renderer.rs:276-279: set up the shadow ray toward emitter p.emitter
+// scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter p.emitter
 HD void nee_setup(const Scene &sc, Path &p) {
     const Emitter em = sc.emitters[p.emitter];
-    float theta = PI2_F * p.r0, unit_z = 1.0f - 2.0f * p.r1;
+    float unit_z = 1.0f - 2.0f * p.r1;
     float a = sqrtf(1.0f - unit_z * unit_z);
-    V3f sn = v3(a * cosf(theta), a * sinf(theta), unit_z);
-    p.nee_p = v3(em.c) + (em.r + OFFSET_F) * sn;
-    p.shadow_vec = p.nee_p - p.next_o;
-    p.shadow_dir = normalize(p.shadow_vec);
-    ray_set(p.ray, p.next_o, p.shadow_dir);
-    // closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4)
-    trace_begin(p.ts, sqrtf(dot(p.shadow_vec, p.shadow_vec)) + 0.03f);
+    float sn_, cs_;
+    HR_SINCOS_2PI(p.r0, sn_, cs_);
+    V3f sn = v3(a * cs_, a * sn_, unit_z);
+    V3f sp = v3(em.c) + (em.r + OFFSET_F) * sn;
+    V3f sv = sp - p.next_o;
+    p.shadow_len = sqrtf(dot(sv, sv));
+    ray_set(p.ray, p.next_o, sv * (1.0f / p.shadow_len));
+    // a closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4),
+    // so the search is limited to the sample distance + 0.03 (the reference does an unbounded closest-hit query)
+    trace_begin(p.ts, p.shadow_len + 0.03f);
     p.phase = 1;
-    // keep the sample normal's cosine for later: recomputed in nee_finish from nee_p - centre
+}
+
+HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
+    return (ts.type == 0) ? sc.tris[ts.prim].element : (ts.type == 1 ? sc.sphere_elem[ts.prim] : float_as_int(sc.cuboids[2 * ts.prim].w));
 }
 
 // returns true when the path is finished (accum final)
 template <bool CNT>
-HD bool path_advance(const Scene &sc, Path &p, const float *draws, LaneCounters *cn) {
+HD bool path_advance(const Scene &sc, Path &p, const u64 *draws, LaneCounters *cn) {
     if (CNT) cn->rays++;
-    bool hit = p.ts.prim >= 0;
+    const bool hit = p.ts.prim >= 0;
     if (p.phase == 0) {
-        p.r0 = draws[p.draw_base + 64u * (2u * (uint32_t)p.iter)];
-        p.r1 = draws[p.draw_base + 64u * (2u * (uint32_t)p.iter + 1u)];
-        if (hit) {
-            Surf s;
-            // element id is needed before we know whether uv matters; spheres: look it up first
-            int32_t elem = (p.ts.type == 0) ? sc.tris[p.ts.prim].element
-                                            : (p.ts.type == 1 ? sc.sphere_elem[p.ts.prim] : float_as_int(sc.cuboids[2 * p.ts.prim].w));
-            hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, elem), s);
-            PointMat m;
-            material_at(sc, s.elem, s.u, s.v, m);
-            p.view = -p.ray.d;
-            if (!bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, p.cur_refl)) return true;  // renderer.rs:190-193
-            p.albedo = m.albedo; p.emission = m.emission;
-            if (nee_available(m.surface) && sc.num_emitters > 0) {
-                p.n = s.n; p.surface = m.surface; p.param = m.param; p.roughness = m.roughness;
-                p.nee_sum = v3(0, 0, 0);
-                p.emitter = 0;
-                nee_setup(sc, p);
-                return false;
-            }
-        } else {
-            p.emission = sky_sample(sc, p.ray.d);  // scene.rs:398
-            p.albedo = v3(1, 1, 1);
-            p.cur_refl = 1.0f;
+        p.r0 = draw_f32(draws[p.draw_base + 64u * (2u * (p.lens_a + (uint32_t)p.iter))]);        // renderer.rs:175
+        p.r1 = draw_f32(draws[p.draw_base + 64u * (2u * (p.lens_a + (uint32_t)p.iter) + 1u)]);
+        if (!hit) {  // scene.rs:398 + renderer.rs:196,199
+            p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
+            return true;
+        }
+        Surf s;
+        hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, hit_element(sc, p.ts)), s);
+        PointMat m;
+        material_at(sc, s.elem, s.u, s.v, m);
+        p.view = -p.ray.d;
+        float cur_refl;
+        if (!bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, cur_refl)) return true;  // renderer.rs:190-193
+        p.accum = p.accum + p.refl * m.emission;          // renderer.rs:196
+        p.refl_next = p.refl * (m.albedo * cur_refl);     // renderer.rs:197
+        if (nee_available(m.surface) && sc.num_emitters > 0) {
+            p.nee_scale = p.refl * m.albedo;              // renderer.rs:183,295
+            p.n = s.n; p.surface = m.surface; p.param = m.param; p.roughness = m.roughness;
+            p.emitter = 0;
+            nee_setup(sc, p);
+            return false;
         }
     } else {
-        // renderer.rs:280-292
-        if (hit) {
-            V3f hp = p.ray.o + p.ray.d * p.ts.t;
-            V3f dp = hp - p.nee_p;
-            if (dot(dp, dp) < OFFSET_F * 4.0f) {
+        // renderer.rs:280-292.  Hit point and sample point lie on the same ray: |hit - sample| = |t - shadow_len|
+        float dt = p.ts.t - p.shadow_len;
+        if (hit && dt * dt < OFFSET_F * 4.0f) {
+            const Material mt = sc.materials[hit_element(sc, p.ts)];
+            V3f e = v3(mt.emission);
+            if (mt.emission_img >= 0) {
                 Surf s;
-                int32_t elem = (p.ts.type == 0) ? sc.tris[p.ts.prim].element
-                                                : (p.ts.type == 1 ? sc.sphere_elem[p.ts.prim] : float_as_int(sc.cuboids[2 * p.ts.prim].w));
-                const Material mt = sc.materials[elem];
-                V3f e = v3(mt.emission);
-                if (mt.emission_img >= 0) {
-                    hit_surface(sc, p.ray, p.ts, true, s);
-                    e = tex_sample(sc, mt.emission_img, e, s.u, s.v);
-                }
-                const Emitter em = sc.emitters[p.emitter];
-                V3f sn = (p.nee_p - v3(em.c)) * (1.0f / (em.r + OFFSET_F));
-                float dot_0 = fabsf(dot(p.n, p.shadow_dir)), dot_l = fabsf(dot(sn, p.shadow_dir));
-                float g = (dot_0 * dot_l) / dot(p.shadow_vec, p.shadow_vec);
-                float pdf = 1.0f / (4.0f * PI_F * em.r * em.r);
-                float w = bsdf_eval(p.surface, p.param, p.roughness, p.view, p.n, p.shadow_dir) * g / pdf;
-                p.nee_sum = p.nee_sum + e * w;
+                hit_surface(sc, p.ray, p.ts, true, s);
+                e = tex_sample(sc, mt.emission_img, e, s.u, s.v);
             }
+            const Emitter em = sc.emitters[p.emitter];
+            V3f sp = p.ray.o + p.ray.d * p.shadow_len;
+            V3f sn = (sp - v3(em.c)) * (1.0f / (em.r + OFFSET_F));
+            float dot_0 = fabsf(dot(p.n, p.ray.d)), dot_l = fabsf(dot(sn, p.ray.d));
+            float g = (dot_0 * dot_l) / (p.shadow_len * p.shadow_len);
+            float inv_pdf = 4.0f * PI_F * em.r * em.r;
+            float w = bsdf_eval(p.surface, p.param, p.roughness, p.view, p.n, p.ray.d) * g * inv_pdf;
+            p.accum = p.accum + p.nee_scale * (e * w);
         }
         p.emitter++;
         if ((uint32_t)p.emitter < sc.num_emitters) { nee_setup(sc, p); return false; }
-        p.accum = p.accum + p.refl * (p.nee_sum * p.albedo);  // renderer.rs:183-185, 295
-        hit = true;                                             // the main ray of this iteration did hit
         p.phase = 0;
     }
-    // renderer.rs:196-199
-    p.accum = p.accum + p.refl * p.emission;
-    p.refl = p.refl * (p.albedo * p.cur_refl);
-    if (!hit || is_zero(p.refl) || p.iter >= 9) return true;
+    // renderer.rs:197-199 (a miss returned above)
+    p.refl = p.refl_next;
+    if (is_zero(p.refl) || p.iter >= 9) return true;
     p.iter++;
     ray_set(p.ray, p.next_o, p.next_d);
     trace_begin(p.ts, T_INF);

@@ -22,21 +22,28 @@ using namespace hr;
 struct emu_scene { HostScene hs; Scene view; };
 
 struct ArrMem { u64 m[256]; u64 ld(int i) const { return m[i]; } void st(int i, u64 v) { m[i] = v; } };
-struct ArrTail { float t[ISAAC_TAIL]; float ld(int k) const { return t[k]; } void st(int k, float v) { t[k] = v; } };
+struct ArrStore { u64 t[ISAAC_TAIL]; u64 ld(int k) const { return t[k]; } void st(int k, u64 v) { t[k] = v; } };
 
-static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
+// what the seed kernel produces for one path: raw tail + accepted lens attempt
+static bool path_tail(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, ArrStore &st, uint32_t &lens_a) {
     static const IsaacWarm warm = isaac_warm();
     ArrMem mem;
-    ArrTail tm;
-    LensTail<ArrTail> lt(tm, lens_shape);
+    RawLensTail<ArrStore> lt(st, lens_shape);
     u64 s, t;
     path_seed_words(W, H, px, py, sub, s, t);
     isaac_seed_round(mem, warm, 8700304ULL, (u64)sampling, s, t, lt);
-    bool ok = lt.accepted >= 0 && 2 * lt.accepted + DRAWS_PER_PATH <= ISAAC_TAIL;
-    int first = ok ? 2 * lt.accepted + 2 : 0;
-    out20[0] = ok ? lt.sqx : 0.0f;
-    out20[1] = ok ? lt.sqy : 0.0f;
-    for (int d = 0; d < DRAWS_PER_PATH - 2; d++) out20[2 + d] = tm.ld(first + d);
+    lt.lens_slow();
+    bool ok = lt.in_window();
+    lens_a = ok ? (uint32_t)lt.accepted : 0u;
+    return ok;
+}
+static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
+    ArrStore st;
+    uint32_t a;
+    bool ok = path_tail(W, H, px, py, sub, sampling, lens_shape, st, a);
+    out20[0] = draw_lens_f32(st.t[2 * a]);
+    out20[1] = draw_lens_f32(st.t[2 * a + 1]);
+    for (int d = 2; d < DRAWS_PER_PATH; d++) out20[d] = draw_f32(st.t[2 * a + d]);
     return ok;
 }
 
@@ -55,7 +62,7 @@ void emu_scene_destroy(emu_scene *e) { delete e; }
 
 // stats: [0]=nodes [1]=leaves [2]=max depth [3]=tris [4]=spheres [5]=cuboids [6]=emitters
 void emu_scene_stats(const emu_scene *e, uint64_t *out) {
-    out[0] = e->hs.nodes.size(); out[1] = e->hs.bvh_leaves; out[2] = e->hs.bvh_max_depth;
+    out[0] = e->hs.num_nodes; out[1] = e->hs.bvh_leaves; out[2] = e->hs.bvh_max_depth;
     out[3] = e->hs.tris.size(); out[4] = e->hs.spheres.size(); out[5] = e->hs.cuboids.size() / 2; out[6] = e->hs.emitters.size();
 }
 
@@ -86,23 +93,23 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
     for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
         std::atomic<uint32_t> next{0};
         auto work = [&](int tid) {
-            float draws[DRAWS_PER_PATH * 64];
+            std::vector<u64> draws((size_t)ISAAC_TAIL * 64);
             for (;;) {
                 uint32_t y = next.fetch_add(1);
                 if (y >= H) break;
                 for (uint32_t x = 0; x < W; x++) {
                     float sum[3] = {0, 0, 0};
                     for (uint32_t sub = 0; sub < 4; sub++) {
-                        float d20[DRAWS_PER_PATH];
-                        path_draws(W, H, x, y, sub, sampling, sc.cam.lens_shape, d20);
-                        for (int d = 0; d < DRAWS_PER_PATH; d++) draws[d * 64] = d20[d];
+                        ArrStore st;
                         Path p;
                         p.q = 0; p.draw_base = 0;
-                        path_start(sc, rp, p, x, y, sub, draws);
+                        path_tail(W, H, x, y, sub, sampling, sc.cam.lens_shape, st, p.lens_a);
+                        for (int d = 0; d < ISAAC_TAIL; d++) draws[(size_t)d * 64] = st.t[d];
+                        path_start(sc, rp, p, x, y, sub, draws.data());
                         LaneCounters lc = {0, 0, 0, 0, 0};
                         for (;;) {
                             while (p.ts.cur != NODE_END) trace_step<true>(sc, p.ray, p.ts, &lc);
-                            if (path_advance<true>(sc, p, draws, &lc)) break;
+                            if (path_advance<true>(sc, p, draws.data(), &lc)) break;
                         }
                         sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
                         cn[tid][0]++; cn[tid][1] += lc.rays; cn[tid][2] += lc.node_tests; cn[tid][3] += lc.tri_tests;
