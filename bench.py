@@ -49,6 +49,7 @@ def main():
     import numpy as np
     import torch
     import hanamaru_amd as ha
+    from hanamaru_amd.sharding import step_range
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,8 +82,7 @@ def main():
 
     def run_step(i):
         # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; this rank takes (s-1) % world == rank
-        base = i * SPS * world + 1
-        r.render(base + rank, base + SPS * world, world)
+        r.render(*step_range(i, SPS, world, rank))
 
     def barrier():
         if dist is not None:

@@ -1,0 +1,64 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s_[a-z0-9_]+)\s*\(" % prefix, text)))
+
+
+def test_hip_library_exports_header(ha):
+    names = _declared("hanamaru_hip.h", "hr")
+    assert len(names) >= 18
+    lib = C.CDLL(ha.HIP_LIB)
+    for n in names:
+        assert hasattr(lib, n), "libhanamaru_hip.so lacks %s" % n
+    assert ha.hip_lib().hr_abi_version() == 1
+
+
+def test_host_library_exports_header(ha):
+    names = _declared("hanamaru_host.h", "hh")
+    assert len(names) >= 9
+    lib = C.CDLL(ha.HOST_LIB)
+    for n in names:
+        assert hasattr(lib, n), "libhanamaru_host.so lacks %s" % n
+
+
+def test_struct_layouts_match_header(ha):
+    # sizes the C compiler gives the POD structs (include/hanamaru_hip.h) vs the ctypes mirrors
+    assert C.sizeof(ha.Vec3) == 24 and C.sizeof(ha.Texture) == 32 and C.sizeof(ha.Material) == 16 + 3 * 32
+    assert C.sizeof(ha.Image) == 16 and C.sizeof(ha.Camera) == 6 * 24 + 24 and C.sizeof(ha.Skybox) == 48
+    assert C.sizeof(ha.Element) == 8 + 112 + 32 + 48 + 32
+    assert C.sizeof(ha.Stats) == 16 * 8
+
+
+def test_no_device_is_a_clean_error(ha):
+    """Without a GPU hr_create must fail with an error code and text — never crash, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ha.HipError) as e:
+        ha.Renderer(0)
+    assert e.value.code < 0 and str(e.value)
+
+
+def test_product_does_not_reference_oracle_or_emulation():
+    """The product tree must not import, link or name the checker (oracle/) or the host emulation (tests/emu)."""
+    pkg = os.path.join(ROOT, "hanamaru-renderer_amd")
+    offenders = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".cpp", ".h", ".hip", ".py", "Makefile")):
+                text = open(os.path.join(d, f), errors="ignore").read()
+                for line in text.splitlines():
+                    code = line.split("//")[0]
+                    if re.search(r"liboracle|oracle_py|libhr_emu|emu_py|#include\s+\"\.\./\.\./oracle", code):
+                        offenders.append((f, line.strip()))
+    assert not offenders, offenders

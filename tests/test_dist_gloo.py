@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two processes over gloo shard the sampling indices exactly as bench.py does on GPUs
+(hanamaru_amd.sharding), each renders its shard, one all-reduce sums the fp32 accumulators.  The renderer used
+here is the host emulation of the kernels (no GPU in this tier); what is under test is the sharding + collective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPS, STEPS = 40, 24, 2, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    for p in (os.path.join(ROOT, "hanamaru-renderer_amd", "python"), os.path.join(ROOT, "tests", "emu")):
+        sys.path.insert(0, p)
+    import emu_py
+    import hanamaru_amd as ha
+    from hanamaru_amd.sharding import step_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = ha.Scene("cornell_mini")
+    e = emu_py.EmuScene(sc.desc_ptr)
+    acc = np.zeros((H, W, 3), dtype=np.float32)
+    for step in range(STEPS):
+        b, en, st = step_range(step, SPS, world, rank)
+        e.render(W, H, b, en, st, threads=2, acc=acc)
+    t = torch.from_numpy(acc)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_covers_every_sampling_once():
+    from hanamaru_amd.sharding import samplings_of
+    for world in (1, 2, 4, 8):
+        for sps in (1, 3, 16):
+            seen = []
+            for step in range(3):
+                for rank in range(world):
+                    got = samplings_of(step, sps, world, rank)
+                    assert len(got) == sps and all((s - 1) % world == rank for s in got)
+                    seen += got
+            assert sorted(seen) == list(range(1, 3 * sps * world + 1))
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one(tmp_path, emu, ha):
+    world = 2
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    sc = ha.Scene("cornell_mini")
+    e = emu.EmuScene(sc.desc_ptr)
+    ref, _ = e.render(W, H, 1, STEPS * SPS * world + 1, threads=0)
+    # same samplings, different fp32 summation order (per-rank partial sums, then the all-reduce)
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert got.sum() > 0

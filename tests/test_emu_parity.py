@@ -1,0 +1,105 @@
+"""CPU-only tier: the kernels' per-lane code (csrc/*_core.h compiled for the host, tests/emu) against the f64
+oracle.  Same tolerances as tests/test_gpu_parity.py — the GPU tier repeats these through the C ABI."""
+import numpy as np
+import pytest
+
+ATOL_REL = 1e-2
+FRAC_OK = 0.995
+
+
+@pytest.fixture(scope="module")
+def emu_scenes(scenes, emu):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            sc, o = scenes(name)
+            cache[name] = (sc, o, emu.EmuScene(sc.desc_ptr))
+        return cache[name]
+    return get
+
+
+def test_device_bvh_shape(emu_scenes):
+    _, _, e = emu_scenes("rtcamp6_v3_1")
+    st = e.stats()
+    assert st["tris"] == 12294 and st["spheres"] == 1 and st["cuboids"] == 1 and st["emitters"] == 1
+    assert st["leaves"] * 2 - 1 == st["nodes"] and st["max_depth"] < 40
+    _, _, e2 = emu_scenes("spheres")
+    assert e2.stats()["spheres"] == 105 and e2.stats()["emitters"] == 5 and e2.stats()["tris"] == 0
+
+
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "cornell_mini", "spheres"])
+def test_closest_hit(emu_scenes, name):
+    sc, o, e = emu_scenes(name)
+    rng = np.random.default_rng(11)
+    n = 3000
+    eye = np.array(sc.desc.camera.eye.tuple())
+    org = eye + rng.normal(size=(n, 3)) * 0.3
+    tgt = rng.uniform(-2.5, 2.5, size=(n, 3)) * np.array([1.0, 0.6, 1.0]) + np.array([0, 0.8, 0])
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays32 = np.concatenate([org, d], axis=1).astype(np.float32)
+    got, gel = e.intersect(rays32)
+    ref, rel = o.intersect(rays32.astype(np.float64))
+    same = got[:, 0] == ref[:, 0]
+    assert same.mean() > 0.999
+    both = same & (ref[:, 0] == 1)
+    assert (gel[both] == rel[both]).mean() > 0.998
+    ok = both & (gel == rel)
+    terr = np.abs(got[ok, 1] - ref[ok, 1]) / np.maximum(1.0, ref[ok, 1])
+    assert np.quantile(terr, 0.99) < 2e-5 and terr.max() < 1e-3
+
+
+def test_axis_aligned_and_degenerate_rays(emu_scenes):
+    """Zero direction components give +-inf reciprocals and NaN slab terms (bvh.rs:20-39); results must match."""
+    sc, o, e = emu_scenes("cornell_mini")
+    rays = np.array([[0.0, 3.0, 2.5, 0, -1, 0], [0.6, 5, 0.4, 0, -1, 0], [-5, 0.25, 0.2, 1, 0, 0], [0.3, 0.2, 7, 0, 0, -1],
+                     [0, 0, 0, 0, 1, 0], [-3, 0.0, 0, 1, 0, 0], [10, 10, 10, 0, 1, 0]], dtype=np.float32)
+    got, gel = e.intersect(rays)
+    ref, rel = o.intersect(rays.astype(np.float64))
+    assert np.array_equal(got[:, 0], ref[:, 0].astype(np.float32))
+    hit = ref[:, 0] == 1
+    assert np.array_equal(gel[hit], rel[hit])
+    assert np.allclose(got[hit, 1], ref[hit, 1], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 96, 54, 2), ("cornell_mini", 64, 48, 3), ("spheres", 80, 45, 1), ("rtcamp6_dodeca", 50, 29, 1)])
+def test_radiance_accumulator(emu_scenes, name, w, h, s):
+    _, o, e = emu_scenes(name)
+    acc, cn = e.render(w, h, 1, s + 1, threads=0)
+    ref, rc = o.render(w, h, 1, s + 1, threads=0, counters=True)
+    rel = np.abs(acc.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    assert (rel <= ATOL_REL).mean() >= FRAC_OK
+    assert abs(acc.mean() - ref.mean()) <= 2e-3 * max(1.0, ref.mean())
+    # path structure: same number of rays within 0.1 % (an fp32 branch flip changes a path's length)
+    ref_rays = rc["rays_primary"] + rc["rays_bounce"] + rc["rays_shadow"]
+    assert cn["paths"] == rc["paths"] == w * h * 4 * s
+    assert abs(cn["rays"] - ref_rays) <= 1e-3 * ref_rays
+    # on the mesh scenes the device tree + culling must do less work than the reference-order walk it replaces
+    if name.startswith("rtcamp6"):
+        assert cn["node_tests"] * 2 < rc["mesh_node_tests"] + rc["top_node_tests"] and cn["tri_tests"] * 3 < rc["tri_tests"]
+
+
+def test_ragged_and_tiny_resolutions(emu_scenes):
+    _, o, e = emu_scenes("cornell_mini")
+    for w, h in [(1, 1), (5, 3), (4, 9), (17, 2)]:
+        acc, _ = e.render(w, h, 2, 4, threads=1)
+        ref, _ = o.render(w, h, 2, 4, threads=1)
+        rel = np.abs(acc - ref) / np.maximum(1.0, np.abs(ref))
+        assert (rel <= ATOL_REL).mean() >= 0.98, (w, h)
+
+
+def test_post_chain(emu_scenes, emu, orc):
+    _, o, _ = emu_scenes("cornell_mini")
+    for (w, h) in [(64, 40), (8, 5), (1, 1), (3, 1), (1, 4)]:
+        ref, _ = o.render(w, h, 1, 3, threads=0)
+        a32 = ref.astype(np.float32)
+        img = emu.resolve(a32, 2)
+        exp = orc.resolve(a32.astype(np.float64), 2)
+        diff = np.abs(img.astype(int) - exp.astype(int))
+        assert diff.max() <= 1
+        assert (diff == 0).mean() > 0.99 or w * h < 50
+    # saturation and zeros
+    acc = np.zeros((4, 4, 3), dtype=np.float32)
+    acc[1, 1] = 1e6
+    assert np.array_equal(emu.resolve(acc, 1), orc.resolve(acc.astype(np.float64), 1))

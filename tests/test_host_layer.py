@@ -1,0 +1,137 @@
+"""Host layer (loader.rs / camera.rs / matrix.rs / scene builders / image codecs restated in C++)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+def test_png_decode_is_exact(ha):
+    from PIL import Image
+    p = os.path.join(ASSETS, "textures/2d/magic-circle3.png")
+    assert np.array_equal(ha.decode_image(p), np.asarray(Image.open(p)))
+
+
+def test_png_write_round_trip(ha, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    path = str(tmp_path / "x.png")
+    ha.write_png(path, img)
+    assert np.array_equal(np.asarray(Image.open(path)), img)           # an independent decoder reads it back
+    assert np.array_equal(ha.decode_image(path)[:, :, :3], img)       # and so does ours
+    assert (ha.decode_image(path)[:, :, 3] == 255).all()
+
+
+@pytest.mark.parametrize("face", ["posx", "negx", "posy", "negy", "posz", "negz"])
+def test_jpeg_decode_close_to_libjpeg(ha, face):
+    """Baseline 4:2:0 JPEG.  The reference's decoder crate (jpeg-decoder 0.1.15) is not available; the decoder
+    is pinned against Pillow/libjpeg-turbo instead: different IDCT/upsampling roundings -> a few LSB."""
+    from PIL import Image
+    p = os.path.join(ASSETS, "textures/cube/Powerlines/%s.jpg" % face)
+    mine = ha.decode_image(p)
+    ref = np.asarray(Image.open(p).convert("RGB")).astype(int)
+    assert mine.shape == (1024, 1024, 4) and (mine[:, :, 3] == 255).all()
+    d = np.abs(mine[:, :, :3].astype(int) - ref)
+    assert d.max() <= 4 and d.mean() < 0.1 and (d > 2).mean() < 1e-4
+
+
+def test_decode_errors(ha, tmp_path):
+    with pytest.raises(ha.HostError):
+        ha.decode_image(str(tmp_path / "missing.png"))
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not an image at all")
+    with pytest.raises(ha.HostError):
+        ha.decode_image(str(bad))
+
+
+def _parse_obj(path):
+    v, f = [], []
+    for line in open(path):
+        t = line.rstrip("\r\n").split(" ")
+        if t[0] == "v":
+            v.append([float(t[1]), float(t[2]), float(t[3])])
+        elif t[0] == "f":
+            idx = [int(c.split("/")[0]) - 1 for c in t[1:]]
+            f.append(idx[:3])
+            if len(t) == 5:
+                f.append([idx[0], idx[2], idx[3]])
+    return np.array(v), np.array(f, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("rel,nv,nf", [("models/box.obj", 8, 12), ("models/picture_frame.obj", 56, 112), ("models/armadilo_1000.obj", 502, 1000),
+                                       ("models/bunny/bunny_wired_300.obj", 1910, 6170), ("models/fractal_dodecahedron.obj", 3200, 7200)])
+def test_obj_loader(ha, rel, nv, nf):
+    path = os.path.join(ASSETS, rel)
+    m = np.array([[2.0, 0, 0, 1.0], [0, 3.0, 0, -2.0], [0, 0, 0.5, 4.0], [0, 0, 0, 1]])
+    verts, faces = ha.load_obj(path, m)
+    rv, rf = _parse_obj(path)
+    assert verts.shape == (nv, 3) and faces.shape == (nf, 3)      # SURVEY.md Appendix C.3 counts
+    assert np.array_equal(faces, rf)
+    exp = np.stack([rv[:, 0] * 2.0 + rv[:, 1] * 0.0 + rv[:, 2] * 0.0 + 1.0, rv[:, 0] * 0.0 + rv[:, 1] * 3.0 + rv[:, 2] * 0.0 - 2.0,
+                    rv[:, 0] * 0.0 + rv[:, 1] * 0.0 + rv[:, 2] * 0.5 + 4.0], axis=1)
+    assert np.array_equal(verts, exp)                               # matrix.rs:180-189 operation order, bit-exact
+
+
+def test_obj_loader_errors(ha, tmp_path):
+    with pytest.raises(ha.HostError):
+        ha.load_obj(str(tmp_path / "nope.obj"))
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(ha.HostError):
+        ha.load_obj(str(bad))
+    empty = tmp_path / "empty.obj"
+    empty.write_text("# nothing\n")
+    v, f = ha.load_obj(str(empty))
+    assert v.shape == (0, 3) and f.shape == (0, 3)
+
+
+def test_rtcamp6_scene_structure(ha):
+    sc = ha.Scene("rtcamp6_v3_1")
+    d = sc.desc
+    assert d.num_elements == 11 and d.num_images == 7
+    kinds = [d.elements[i].kind for i in range(11)]
+    assert kinds == [ha.SPHERE, ha.MESH, ha.MESH, ha.MESH, ha.CUBOID] + [ha.MESH] * 6          # main.rs:1043-1150
+    assert [d.elements[i].num_faces for i in (1, 2, 3, 5)] == [6170, 12, 112, 1000]
+    light = d.elements[0]
+    assert light.center.tuple() == (-0.3, 0.7, 0.0) and light.radius == 0.2
+    assert light.material.emission.color.tuple() == (30.0, 20.0, 4.0) and light.material.surface == ha.DIFFUSE
+    surf = [d.elements[i].material.surface for i in range(11)]
+    assert surf == [ha.DIFFUSE, ha.GGX, ha.SPECULAR, ha.GGX, ha.DIFFUSE, ha.REFRACTION, ha.GGX, ha.REFRACTION, ha.GGX, ha.REFRACTION, ha.GGX]
+    assert d.elements[6].material.roughness.color.x == pytest.approx(0.05) and d.elements[10].material.roughness.color.x == pytest.approx(0.25)
+    assert d.elements[4].material.albedo.image >= 0 and d.elements[4].aabb_min.tuple() == (-9.0, -1.0, -9.0)
+    # camera.rs:45-64: tan of the FULL fov angle
+    cam = d.camera
+    theta = 2 * math.pi * 0.03
+    assert cam.eye.tuple() == pytest.approx((6.5 * math.sin(theta), 2.0, 6.5 * math.cos(theta)))
+    assert cam.lens_radius == 0.015 and cam.focus_distance == 5.0 and cam.lens_shape == 1
+    phu = np.array(cam.plane_half_up.tuple())
+    assert np.linalg.norm(phu) == pytest.approx(math.tan(math.radians(20.0)) * 5.0)
+    # hsv_to_rgb(0.45, 0.2, 1.0) of armadillo 0 (color.rs:50-61)
+    assert d.elements[5].material.albedo.color.tuple() == pytest.approx((0.8, 1.0, 0.94))
+    assert sc.image(d.elements[4].material.albedo.image).shape == (3000, 3000, 4)
+
+
+def test_spheres_scene(ha):
+    sc = ha.Scene("spheres")
+    d = sc.desc
+    assert d.num_elements == 105 and all(d.elements[i].kind == ha.SPHERE for i in range(105))
+    c = np.array([d.elements[i].center.tuple() for i in range(105)])
+    # scene.rs:366-376: accepted spheres have non-overlapping AABBs (r = 0.1)
+    for i in range(105):
+        dd = np.abs(c - c[i]).max(axis=1)
+        dd[i] = 1.0
+        assert (dd >= 0.2).all()
+    assert [d.elements[i].material.surface for i in range(4)] == [ha.DIFFUSE, ha.SPECULAR, ha.DIFFUSE, ha.SPECULAR]
+    em = [i for i in range(105) if d.elements[i].material.emission.color.tuple() != (0.0, 0.0, 0.0)]
+    assert em == list(range(100, 105))
+    assert (c[:100, 0] >= -0.5).all() and (c[:100, 0] < 2.0).all() and (np.abs(c[100:, 1]) < 1.0).all()
+
+
+def test_unknown_scene_and_missing_assets(ha, tmp_path):
+    with pytest.raises(ha.HostError):
+        ha.Scene("no_such_scene")
+    with pytest.raises(ha.HostError):
+        ha.Scene("rtcamp6_v3_1", str(tmp_path))

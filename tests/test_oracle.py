@@ -1,0 +1,181 @@
+"""The CPU oracle against every known answer available for this path.
+
+The reference has no tests and cannot be built here, so the pins are: the BVH shapes and the
+path statistics an independent restatement produced during the survey (Appendix C.3 / D.2 — two
+implementations agreeing), hand-derived values of the post chain, and the committed golden accumulators."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_bvh_shapes_match_survey(scenes):
+    _, o = scenes("rtcamp6_v3_1")
+    exp = {1: (4095, 2048, 11, {3: 2022, 4: 26}, (-1.332764, 0.003133, -0.540999, 1.062427, 2.494685, 1.340048)),
+           2: (7, 4, 2, {3: 4}, (-0.680204, 0.0, -3.730405, 2.680204, 2.7, -2.269595)),
+           3: (63, 32, 5, {3: 16, 4: 16}, (-0.871415, 0.0, -3.822478, 2.871415, 3.0, -2.177522)),
+           5: (511, 256, 8, {3: 24, 4: 232}, (-0.423932, 0.0, 1.810497, 0.425070, 1.0, 2.585678))}
+    for el, (nodes, leaves, depth, hist, aabb) in exp.items():
+        st = o.bvh_stats(el)
+        assert (st["nodes"], st["leaves"], st["max_depth"]) == (nodes, leaves, depth)
+        assert {k: v for k, v in enumerate(st["leaf_hist"]) if v} == hist
+        assert np.allclose(st["aabb"], aabb, atol=1e-6)
+    for el in range(6, 11):
+        st = o.bvh_stats(el)
+        assert (st["nodes"], st["leaves"], st["max_depth"]) == (511, 256, 8)
+    assert o.bvh_stats(0) is None and o.bvh_stats(4) is None
+    top = o.bvh_stats(-1)
+    assert (top["nodes"], top["leaves"], top["max_depth"]) == (5, 3, 2)
+    assert o.top_leaves() == [[2, 3, 8, 7, 9], [0, 4, 1], [6, 10, 5]]
+    assert o.num_emissions() == 1
+
+
+def test_dodecahedron_bvh(scenes):
+    _, o = scenes("rtcamp6_dodeca")
+    st = o.bvh_stats(11)
+    assert (st["nodes"], st["leaves"], st["max_depth"]) == (4095, 2048, 11)
+    assert {k: v for k, v in enumerate(st["leaf_hist"]) if v} == {3: 992, 4: 1056}
+
+
+def test_path_statistics_match_survey_c1(scenes):
+    """BASELINE config 1 (480x270, -s 1): every aggregate of SURVEY.md Appendix D.2, exactly."""
+    _, o = scenes("rtcamp6_v3_1")
+    _, c = o.render(480, 270, 1, 2, threads=0, counters=True)
+    assert c["paths"] == 518400
+    assert (c["rays_primary"], c["rays_bounce"], c["rays_shadow"]) == (518400, 576504, 486762)
+    assert c["surface_hits"] == 622558 and c["draws"] == 3510822
+    assert c["tex_samples"] == 269796 and c["sky_lookups"] == 473863
+    assert c["top_node_tests"] == 7888444 and c["mesh_roots"] == 7473052
+    assert c["mesh_node_tests"] == 161042086
+    assert (c["tri_tests"], c["tri_accepted"]) == (77005150, 1515082)
+    assert c["sphere_tests"] == 1571724 and c["cuboid_tests"] == 1571724
+    assert c["rays_per_path_hist"][1:19] == [177987, 49532, 192395, 15726, 30107, 7296, 13377, 4016, 7842, 2974, 4283, 1342, 2657, 840, 1898,
+                                             1129, 1904, 3095]
+    dh = c["draws_per_path_hist"]
+    assert [dh[k] for k in range(4, 34, 2)] == [157850, 207019, 74426, 32908, 16354, 9241, 5693, 3998, 8564, 1870, 371, 83, 16, 4, 3]
+    # algorithmic bytes of the reference-order traversal: 15,897 B/path
+    alg = 32 * (c["top_node_tests"] + c["mesh_node_tests"]) + 36 * c["tri_tests"] + 16 * c["sphere_tests"] + 24 * c["cuboid_tests"]
+    assert round(alg / c["paths"]) == 15897
+
+
+@pytest.mark.parametrize("name,w,h,s,fn", [("rtcamp6_v3_1", 64, 36, 2, "rtcamp6_64x36_s2.npz"), ("cornell_mini", 48, 32, 2, "cornell_mini_48x32_s2.npz"),
+                                           ("spheres", 48, 27, 1, "spheres_48x27_s1.npz")])
+def test_golden_accumulators(scenes, orc, name, w, h, s, fn):
+    g = np.load(os.path.join(GOLD, fn))
+    _, o = scenes(name)
+    acc, c = o.render(w, h, 1, s + 1, threads=0, counters=True)
+    assert np.array_equal(acc.astype(np.float32), g["acc"])            # the oracle is deterministic
+    assert np.array_equal(orc.resolve(acc, s), g["rgb8"])
+    assert [c[k] for k in orc.COUNTER_FIELDS] == g["counters"].tolist()
+
+
+def test_render_is_additive_and_thread_independent(scenes):
+    _, o = scenes("cornell_mini")
+    a, _ = o.render(40, 30, 1, 4, threads=1)
+    b, _ = o.render(40, 30, 1, 4, threads=5)
+    assert np.array_equal(a, b)
+    parts = np.zeros_like(a)
+    for r in range(3):
+        o.render(40, 30, 1 + r, 4, stride=3, threads=2, acc=parts)
+    assert np.allclose(parts, a, rtol=0, atol=1e-12)
+    px = o.calc_pixel(40, 30, 7, 9, 1, 0, 2) + 0
+    assert np.isfinite(px).all()
+
+
+def test_reinhard_gamma_known_values(orc):
+    # tonemap.rs:22-27 by hand: c = 1.5*hdr, L = .22r + .707g + .071b, out = sat(c (L/900 + 1)/(L + 1)), then ^(1/2.2)
+    def ref(hdr):
+        c = 1.5 * np.asarray(hdr, dtype=np.float64)
+        lum = 0.22 * c[0] + 0.707 * c[1] + 0.071 * c[2]
+        return np.clip(c * (lum / 900.0 + 1.0) / (lum + 1.0), 0, 1) ** (1 / 2.2)
+    acc = np.array([[[4.0, 4.0, 4.0], [0.0, 0.0, 0.0], [400.0, 0.4, 0.04]]])      # one sampling: scale 1/4
+    _, stage = orc.resolve(acc, 1, want_stage=True)
+    for i, hdr in enumerate([(1, 1, 1), (0, 0, 0), (100, 0.1, 0.01)]):
+        assert np.allclose(stage[0, i], ref(hdr), rtol=1e-14, atol=0)
+    lum = 1.5 * (0.22 + 0.707 + 0.071)
+    assert stage[0, 0, 0] == pytest.approx((1.5 * (lum / 900 + 1) / (lum + 1)) ** (1 / 2.2), rel=1e-14)
+
+
+def _bilateral_numpy(img):
+    """filter.rs:32-58 with the wrapping-u32 edge rules spelled out."""
+    h, w, _ = img.shape
+    out = np.zeros_like(img)
+
+    def gauss(x, s):
+        return math.exp(-(x * x) / (2 * s * s)) / (2 * math.pi * s * s)
+    for y in range(h):
+        for x in range(w):
+            cs = img[y, x].sum()
+            acc, wp = np.zeros(3), 0.0
+            for i in range(3):
+                for j in range(3):
+                    nx = (x - ((1 - i) & 0xffffffff)) & 0xffffffff
+                    ny = (y - ((1 - j) & 0xffffffff)) & 0xffffffff
+                    nx, ny = min(nx, w - 1), min(ny, h - 1)
+                    dx, dy = (x - nx) & 0xffffffff, (y - ny) & 0xffffffff
+                    dist = math.sqrt((dx * dx + dy * dy) & 0xffffffff)
+                    wgt = gauss((img[ny, nx].sum() - cs) / 3.0, 1.0) * gauss(dist, 16.0)
+                    acc += img[ny, nx] * wgt
+                    wp += wgt
+            out[y, x] = acc / wp
+    return out
+
+
+@pytest.mark.parametrize("w,h", [(9, 6), (1, 1), (2, 7), (5, 1)])
+def test_bilateral_edge_rules(orc, w, h):
+    rng = np.random.default_rng(w * 31 + h)
+    acc = rng.uniform(0, 3, size=(h, w, 3)) * 4
+    img, stage = orc.resolve(acc, 1, want_stage=True)
+    exp = _bilateral_numpy(stage)
+    exp8 = (255.0 * np.clip(exp, 0, 1)).astype(np.uint8)        # color.rs:10-16 truncation
+    assert np.array_equal(img, exp8)
+
+
+def test_texture_bilinear_and_edges(scenes, ha):
+    sc, o = scenes("cornell_mini")
+    im = sc.image(0).astype(np.float64) / 255.0
+    hh, ww = im.shape[:2]
+
+    def texel(x, y):                       # texture.rs:59-63 incl. the u32 wrap of (H - y - 1)
+        x = min(x, ww - 1)
+        yy = (hh - y - 1) & 0xffffffff
+        return im[min(yy, hh - 1), x, :3]
+
+    def ref(u, v):                         # texture.rs:29-49
+        x, y = u * ww, v * hh
+        x1, y1 = math.floor(x), math.floor(y)
+        x2, y2 = x1 + 1.0, y1 + 1.0
+        ix1, ix2, iy1, iy2 = max(int(x1), 0), max(int(x2), 0), max(int(y1), 0), max(int(y2), 0)
+        g = (texel(ix1, iy1) * (x2 - x) * (y2 - y) + texel(ix2, iy1) * (x - x1) * (y2 - y) + texel(ix1, iy2) * (x2 - x) * (y - y1) +
+             texel(ix2, iy2) * (x - x1) * (y - y1))
+        return g ** 2.2
+    for u, v in [(0.3, 0.7), (0.0, 0.0), (0.999, 0.999), (1.0, 1.0), (0.5, 1.0), (0.013, 0.51)]:
+        assert np.allclose(o.image_bilinear(0, u, v), ref(u, v), rtol=1e-13, atol=1e-15)
+
+
+def test_skybox_face_selection(scenes):
+    sc, o = scenes("cornell_mini")
+    # face images of cornell_mini are distinguishable by their blue channel: 200 - 20 f (scenes.cpp)
+    inten = np.array(sc.desc.skybox.intensity.tuple())
+    for f, d in enumerate([(1, .1, .2), (-1, .1, .2), (.1, 1, .2), (.1, -1, .2), (.1, .2, 1), (.1, .2, -1)]):
+        rgb = o.skybox(np.array(d, dtype=np.float64))
+        assert rgb[2] == pytest.approx(inten[2] * ((200 - 20 * f) / 255.0) ** 2.2, rel=1e-12)
+    # ties fall through to the Z faces (strict '>' comparisons, scene.rs:300-318)
+    assert o.skybox(np.array([1.0, 1.0, 0.5]))[2] == pytest.approx(inten[2] * ((200 - 80) / 255.0) ** 2.2, rel=1e-12)
+
+
+def test_closest_hit_basics(scenes):
+    sc, o = scenes("cornell_mini")       # element 5 = emissive sphere, centre (0.6, 1.9, 0.4), r 0.25 (scenes.cpp)
+    rays = np.array([[0.6, 5, 0.4, 0, -1, 0],      # straight down onto it
+                     [0.6, 5, 0.4, 0, 1, 0],       # up: miss
+                     [0.6, 1.9, 0.4, 0, 1, 0],     # from INSIDE: spheres are never hit from inside (scene.rs:61-63)
+                     [0.0, 3.0, 2.5, 0, -1, 0]],   # onto the floor cuboid (top face y = 0)
+                    dtype=np.float64)
+    out, el = o.intersect(rays)
+    assert out[0, 0] == 1 and el[0] == 5 and out[0, 1] == pytest.approx(5 - 2.15) and np.allclose(out[0, 5:8], (0, 1, 0))
+    assert out[1, 0] == 0 and el[1] == -1 and out[1, 1] == 1e100          # Intersection::empty distance (config.rs:9)
+    assert out[2, 0] == 0 and el[2] == -1
+    assert out[3, 0] == 1 and el[3] == 0 and out[3, 1] == pytest.approx(3.0) and np.allclose(out[3, 5:8], (0, 1, 0))
