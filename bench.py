@@ -151,6 +151,12 @@ def main():
                          "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
                          "rays_per_path": round(counters["rays"] / max(1, counters["paths"]), 3)})
             out["rays_per_s_M"] = round(value * counters["rays"] / max(1, counters["paths"]), 1)
+        # HBM traffic is a PMC measurement (separate rocprofv3 --pmc pass, see profiles/); scaled per launch
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile) and (W, H, args.scene) == (1920, 1080, "rtcamp6_v3_1"):
+            tj = json.load(open(tfile))
+            roof["traffic"] = int(tj["hbm_bytes_per_path"] * paths_per_launch)
+            roof["traffic_source"] = tj["source"]
         out["roofline"] = roof
 
         if world == 1 and not args.no_cpu_baseline:
