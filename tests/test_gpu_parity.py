@@ -191,3 +191,29 @@ def test_error_paths(ha):
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
     r.close()
+
+
+def test_cli_drop_in(tmp_path, scenes, orc):
+    """The host driver with the reference's flag surface (main.rs:1230-1256): -w -h -s -t -i; writes result.png,
+    NNN.png and result.txt with the reference's log lines; the image matches the oracle's post chain."""
+    import os
+    import subprocess
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "hanamaru-renderer_amd", "hanamaru-hip")
+    assert os.path.exists(exe), "hanamaru-hip not built (run __graft_entry__.build())"
+    r = subprocess.run([exe, "-w", "96", "-h", "54", "-s", "6", "-t", "1000", "-i", "1000", "--assets", os.path.join(root, "assets")],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    for line in ["resolution: 96x54.", "max sampling: 6x4 spp.", "time limit: 1000.00 sec.", "reached max sampling", "output final image: 000.png",
+                 "sampled: 6x4 spp."]:
+        assert line in r.stdout, (line, r.stdout)
+    txt = open(tmp_path / "result.txt").read()
+    assert "init scene:" in txt and "sampled: 6x4 spp." in txt and txt.splitlines()[-1].startswith("total ")
+    img = np.asarray(Image.open(tmp_path / "result.png"))
+    assert img.shape == (54, 96, 3) and np.array_equal(img, np.asarray(Image.open(tmp_path / "000.png")))
+    _, o = scenes("rtcamp6_v3_1")
+    ref, _ = o.render(96, 54, 1, 7, threads=0)
+    exp = orc.resolve(ref, 6)
+    d = np.abs(img.astype(int) - exp.astype(int))
+    assert (d <= 2).mean() > 0.99 and abs(img.mean() - exp.mean()) < 0.5
