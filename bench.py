@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--scene", default="rtcamp6_v3_1")
     ap.add_argument("--adv-den", type=int, default=0, help="trace kernel early-exit denominator (0 = library default)")
     ap.add_argument("--leaf-den", type=int, default=0)
+    ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -76,6 +77,8 @@ def main():
         r.set_option("adv_den", args.adv_den)
     if args.leaf_den:
         r.set_option("leaf_den", args.leaf_den)
+    if args.min_waves:
+        r.set_option("min_waves", args.min_waves)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
     paths_per_step_gpu = W * H * 4 * SPS

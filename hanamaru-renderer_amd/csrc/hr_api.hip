@@ -48,19 +48,23 @@ static int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------------------------------ kernels
 
+// One generator per LDS bank column: mem[i][col], SEED_COLS columns per workgroup.
+static const int SEED_COLS = 80;               // 80 x 2 KiB = 160 KiB = the whole LDS of a CU
+static const int SEED_WAVES = 2, SEED_LANES = SEED_COLS / SEED_WAVES;   // 2 waves x 40 active lanes
 struct LdsMem {
-    u64 *col;  // &mem[0][lane]
-    __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
-    __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
+    u64 *col;  // &mem[0][col]
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_COLS]; }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_COLS] = v; }
 };
 // global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
 struct GlobalTail {
     u64 *col;  // &tail[item][0][lane]
+    bool on;   // false for the padding lanes of the last pass
     __device__ __forceinline__ u64 ld(int k) const { return col[k * 64]; }
-    __device__ __forceinline__ void st(int k, u64 v) { col[k * 64] = v; }
+    __device__ __forceinline__ void st(int k, u64 v) { if (on) col[k * 64] = v; }
 };
 
-static const size_t SEED_LDS_BYTES = 256 * 64 * 8;  // 128 KiB: mem[256][64 lanes] u64
+static const size_t SEED_LDS_BYTES = (size_t)256 * SEED_COLS * 8;  // 160 KiB: mem[256][80 columns] u64
 
 __device__ __forceinline__ void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint32_t &px, uint32_t &py, uint32_t &sub) {
     uint32_t tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
@@ -70,30 +74,39 @@ __device__ __forceinline__ void tile_lane_pixel(const RenderParams &rp, uint32_t
     py = ty * 4u + (pix >> 2);
 }
 
-// tails layout: [tile][k_sampling][ISAAC_TAIL][64 lanes] u64;  lens layout: [tile][k_sampling][64 lanes] u32
-__global__ __launch_bounds__(64) void seed_isaac64_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ tails, uint32_t *__restrict__ lens,
-                                                          Counters *cnt) {
+// tails layout: [item = tile * num_k + k][ISAAC_TAIL][64 lanes] u64;  lens layout: [item][64 lanes] u32.
+// The LDS holds 80 generators, so a workgroup walks the flat path index (item * 64 + j) in strides of 80:
+// its two waves (40 active lanes each) run concurrently on two SIMDs — the time of one seeding pass does not
+// depend on the lane count (one wave issues at most one instruction every ~4-5 cycles), only on how many
+// generator states fit in the CU's LDS.
+__global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ tails,
+                                                                      uint32_t *__restrict__ lens, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64 *mem = reinterpret_cast<u64 *>(smem);
-    const uint32_t lane = threadIdx.x;
-    // one latency-bound wave per CU next to the trace kernel's waves: always win issue arbitration
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane >= (uint32_t)SEED_LANES) return;
+    const uint32_t col = wave * SEED_LANES + lane;
+    // latency-bound waves next to the trace kernel's waves: always win issue arbitration
     __builtin_amdgcn_s_setprio(3);
     const IsaacWarm warm = isaac_warm();
-    const uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    for (uint64_t base = (uint64_t)blockIdx.x * SEED_COLS; base < paths; base += (uint64_t)gridDim.x * SEED_COLS) {
+        const uint64_t pid = base + col;
+        const bool in_range = pid < paths;
+        const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
         uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
         uint32_t px, py, sub;
-        tile_lane_pixel(rp, tile, lane, px, py, sub);
-        bool valid = px < rp.width && py < rp.height;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        bool valid = in_range && px < rp.width && py < rp.height;
         u64 s, t;
         path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
-        LdsMem m{mem + lane};
-        GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + lane};
+        LdsMem m{mem + col};
+        GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
         RawLensTail<GlobalTail> lt(gt, lens_shape);
         isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
         lt.lens_slow();
         bool ok = lt.in_window();
-        lens[(size_t)item * 64 + lane] = ok ? (uint32_t)lt.accepted : 0u;
+        if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
         if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
     }
 }
@@ -102,6 +115,11 @@ __global__ __launch_bounds__(64) void seed_isaac64_kernel(RenderParams rp, int l
 struct RawTail {
     u64 *out; int window;
     __device__ __forceinline__ void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; }
+};
+struct LdsMem64 {
+    u64 *col;
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
 };
 __global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
                                                         int window, u64 *__restrict__ out) {
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, 
     uint32_t pix = p >> 2, sub = p & 3u;
     u64 s, t;
     path_seed_words(W, H, pix % W, pix / W, sub, s, t);
-    LdsMem m{mem + lane};
+    LdsMem64 m{mem + lane};
     u64 dummy[ISAAC_TAIL];
     RawTail rt{valid ? out + (size_t)idx * window : dummy, window};
     isaac_seed_round(m, warm, 8700304ULL, (u64)sampling, s, t, rt);
@@ -129,12 +147,10 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // No barriers: every wave owns its 48 floats of LDS and runs on its own.
 static const int TRACE_WAVES = 4;
 
-template <bool CNT>
-__global__ __launch_bounds__(64 * TRACE_WAVES) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails, const uint32_t *__restrict__ lens,
+template <bool CNT, int MINW>
+__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails, const uint32_t *__restrict__ lens,
                                                                  float *__restrict__ accum, Counters *cnt) {
-    __shared__ float tile_sum_all[TRACE_WAVES][48];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float *tile_sum = tile_sum_all[wave];
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     // Workgroup b runs on XCD b % 8 (observed dispatch order).  Tiles differ in cost by an order of magnitude
     // (sky vs. the wire-frame bunny), so neighbouring tile groups are dealt round-robin to the XCDs: every
@@ -144,7 +160,6 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void trace_kernel(Scene sc, Rende
     const uint32_t group = blockIdx.x;
     const uint32_t tile = group * TRACE_WAVES + wave;
     if (group >= groups || tile >= tiles) return;
-    if (lane < 48) tile_sum[lane] = 0.0f;
 
     LaneCounters lc = {0, 0, 0, 0, 0};
     uint32_t npaths = 0;
@@ -162,10 +177,16 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void trace_kernel(Scene sc, Rende
         // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
             if (path_advance<CNT>(sc, p, tile_tails, &lc)) {
+                // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
+                // path adds its radiance straight into the accumulator.  A tile belongs to exactly one wave of
+                // one launch, so only lanes of this wave ever touch these addresses: workgroup-scope atomics
+                // (executed in the XCD's L2) are sufficient.
                 uint32_t pix = (p.q & 63u) >> 2;
-                atomicAdd(&tile_sum[pix * 3 + 0], p.accum.x);
-                atomicAdd(&tile_sum[pix * 3 + 1], p.accum.y);
-                atomicAdd(&tile_sum[pix * 3 + 2], p.accum.z);
+                uint32_t px = (tile % rp.tiles_x) * 4u + (pix & 3u), py = (tile / rp.tiles_x) * 4u + (pix >> 2);
+                float *dst = accum + ((size_t)py * rp.width + px) * 3;
+                __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 2, p.accum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 p.q = PATH_IDLE;
             }
         }
@@ -208,11 +229,6 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void trace_kernel(Scene sc, Rende
             }
             if (trav && p.ts.leaf != 0) trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
         }
-    }
-    if (lane < 48) {
-        uint32_t pix = lane / 3, c = lane - pix * 3;
-        uint32_t px = (tile % rp.tiles_x) * 4u + (pix & 3u), py = (tile / rp.tiles_x) * 4u + (pix >> 2);
-        if (px < rp.width && py < rp.height) accum[((size_t)py * rp.width + px) * 3 + c] += tile_sum[lane];
     }
     if (CNT) {
         // wave reduction, one atomic per counter per wave
@@ -288,6 +304,7 @@ struct hr_ctx {
     bool counters = false;
     uint32_t batch = 4;
     uint32_t adv_den = 4, leaf_den = 2;
+    int min_waves = 5;
     int num_cus = 256;
     std::vector<EventPair> seed_events, trace_events, post_events;
     double seed_ms = 0, trace_ms = 0, post_ms = 0;
@@ -487,13 +504,13 @@ static int ensure_draws(hr_ctx *c, size_t items) {
 }
 
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
-    uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
-    uint32_t grid = std::min<uint32_t>(items, (uint32_t)c->num_cus);
+    uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
     EventPair ev;
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
-    hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot], c->lens[slot],
+    hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot], c->lens[slot],
                        c->d_counters);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, st));
@@ -536,12 +553,16 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(ev.a, c->stream));
         uint32_t groups = (tiles + TRACE_WAVES - 1) / TRACE_WAVES;
         uint32_t grid = groups;
-        if (c->counters)
-            hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64 * TRACE_WAVES), 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot],
-                               c->accum, c->d_counters);
-        else
-            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64 * TRACE_WAVES), 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot],
-                               c->accum, c->d_counters);
+        {
+            dim3 g(grid), b(64 * TRACE_WAVES);
+#define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot], c->accum, c->d_counters)
+            if (c->counters) HR_LAUNCH_TRACE(true, 3);
+            else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4);
+            else if (c->min_waves == 5) HR_LAUNCH_TRACE(false, 5);
+            else if (c->min_waves == 6) HR_LAUNCH_TRACE(false, 6);
+            else HR_LAUNCH_TRACE(false, 3);
+#undef HR_LAUNCH_TRACE
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, c->stream));
         c->trace_events.push_back(ev);
@@ -635,6 +656,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "adv_den") {
         if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "adv_den must be in [1,64]");
         c->adv_den = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "min_waves") {
+        if (value < 3 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [3,6]");
+        c->min_waves = (int)value;
         return HR_OK;
     }
     if (k == "leaf_den") {
