@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--adv-den", type=int, default=0, help="trace kernel early-exit denominator (0 = library default)")
     ap.add_argument("--leaf-den", type=int, default=0)
     ap.add_argument("--min-waves", type=int, default=0)
+    ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -70,6 +71,8 @@ def main():
     W, H, SPS = args.width, args.height, args.spp_per_step
     scene = ha.Scene(args.scene)
     r = ha.Renderer(local_rank)
+    if args.max_leaf:
+        r.set_option("max_leaf", args.max_leaf)
     r.upload_scene(scene)
     r.set_resolution(W, H)
     r.set_option("batch", args.batch)

@@ -31,7 +31,7 @@ Scene HostScene::view() const {
     return d;
 }
 
-int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err) {
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf) {
     if (!sd) return ferr(err, HR_ERR_INVALID, "null scene");
     if (!sd->elements || sd->num_elements == 0) return ferr(err, HR_ERR_INVALID, "scene has no elements");
     struct TriD { double v0[3], v1[3], v2[3]; int32_t elem; };
@@ -107,7 +107,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err) {
         return ferr(err, HR_ERR_UNSUPPORTED, "more than 2^20 primitives of one type");
 
     BuiltBvh bvh;
-    build_bvh(prims, 4, bvh);
+    build_bvh(prims, max_leaf, bvh);
     out.nodes = bvh.nodes; out.num_nodes = bvh.num_nodes;
     out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves;
 

@@ -31,6 +31,6 @@ struct HostScene {
 };
 
 // returns HR_OK or a negative hr_status; `err` receives the message
-int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err);
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf = 4);
 
 }  // namespace hr

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     p.ts.cur = NODE_END; p.ts.leaf = 0;
     const u64 *tile_tails = tails + (size_t)tile * rp.num_k * ISAAC_TAIL * 64;
     const uint32_t *tile_lens = lens + (size_t)tile * rp.num_k * 64;
-    const uint32_t adv_den = rp.adv_den ? rp.adv_den : 4u;
+    const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
 
     for (;;) {
@@ -303,8 +303,9 @@ struct hr_ctx {
     uint8_t *d_rgb8 = nullptr;
     bool counters = false;
     uint32_t batch = 4;
-    uint32_t adv_den = 4, leaf_den = 2;
+    uint32_t adv_den = 2, leaf_den = 2;
     int min_waves = 5;
+    int max_leaf = 4;
     int num_cus = 256;
     std::vector<EventPair> seed_events, trace_events, post_events;
     double seed_ms = 0, trace_ms = 0, post_ms = 0;
@@ -420,7 +421,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
 
     HostScene hs;
     std::string ferr;
-    rc = flatten_scene(sd, hs, ferr);
+    rc = flatten_scene(sd, hs, ferr, c->max_leaf);
     if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());
     Scene &d = c->dsc;
     d = hs.view();
@@ -661,6 +662,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "min_waves") {
         if (value < 3 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [3,6]");
         c->min_waves = (int)value;
+        return HR_OK;
+    }
+    if (k == "max_leaf") {  // takes effect at the next hr_upload_scene
+        if (value < 1 || value > 15) return fail(HR_ERR_INVALID, "max_leaf must be in [1,15]");
+        c->max_leaf = (int)value;
         return HR_OK;
     }
     if (k == "leaf_den") {

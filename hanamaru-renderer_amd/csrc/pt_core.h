@@ -15,6 +15,25 @@
 
 namespace hr {
 
+// Transcendentals.  On the device the hardware forms are used: v_exp_f32(y * v_log_f32(x)) for x^y and
+// v_sin_f32 / v_cos_f32, which take their argument in REVOLUTIONS — exactly the 2*pi*r0 the samplers need,
+// so no range reduction is involved.  The host emulation uses libm.
+// Reciprocal / square root use the raw 1-ulp hardware instructions (the compiler's default expansions add
+// 4-5 range-scaling instructions each for denormal inputs, which do not occur here).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_POWF(x, y) __builtin_amdgcn_exp2f((y) * __builtin_amdgcn_logf(x))
+#define HR_SINCOS_2PI(r, s, c) do { (s) = __builtin_amdgcn_sinf(r); (c) = __builtin_amdgcn_cosf(r); } while (0)
+#define HR_RCP(x) __builtin_amdgcn_rcpf(x)
+#define HR_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define HR_RSQ(x) __builtin_amdgcn_rsqf(x)
+#else
+#define HR_POWF(x, y) powf((x), (y))
+#define HR_SINCOS_2PI(r, s, c) do { float ph_ = 6.28318530717958647692f * (r); (s) = sinf(ph_); (c) = cosf(ph_); } while (0)
+#define HR_RCP(x) (1.0f / (x))
+#define HR_SQRT(x) sqrtf(x)
+#define HR_RSQ(x) (1.0f / sqrtf(x))
+#endif
+
 struct V3f { float x, y, z; };
 HD V3f v3(float x, float y, float z) { V3f r; r.x = x; r.y = y; r.z = z; return r; }
 HD V3f v3(const float *p) { return v3(p[0], p[1], p[2]); }
@@ -26,22 +45,11 @@ HD V3f operator*(float s, V3f a) { return v3(a.x * s, a.y * s, a.z * s); }
 HD V3f operator-(V3f a) { return v3(-a.x, -a.y, -a.z); }
 HD float dot(V3f a, V3f b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 HD V3f cross(V3f a, V3f b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-HD V3f normalize(V3f a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+HD V3f normalize(V3f a) { return a * HR_RSQ(dot(a, a)); }
 HD V3f reflect(V3f v, V3f n) { return v - (2.0f * dot(v, n)) * n; }  // vector.rs:60-62
 HD bool is_zero(V3f a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 HD float saturatef(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 HD bool sign_neg(float v) { return signbit(v); }
-
-// Transcendentals.  On the device the hardware forms are used: v_exp_f32(y * v_log_f32(x)) for x^y and
-// v_sin_f32 / v_cos_f32, which take their argument in REVOLUTIONS — exactly the 2*pi*r0 the samplers need,
-// so no range reduction is involved.  The host emulation uses libm.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define HR_POWF(x, y) __builtin_amdgcn_exp2f((y) * __builtin_amdgcn_logf(x))
-#define HR_SINCOS_2PI(r, s, c) do { (s) = __builtin_amdgcn_sinf(r); (c) = __builtin_amdgcn_cosf(r); } while (0)
-#else
-#define HR_POWF(x, y) powf((x), (y))
-#define HR_SINCOS_2PI(r, s, c) do { float ph_ = 6.28318530717958647692f * (r); (s) = sinf(ph_); (c) = cosf(ph_); } while (0)
-#endif
 
 static const float PI_F = 3.14159265358979323846f;
 static const float PI2_F = 6.28318530717958647692f;
@@ -55,7 +63,7 @@ struct Ray {
 };
 HD void ray_set(Ray &r, V3f o, V3f d) {
     r.o = o; r.d = d;
-    r.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // bvh.rs:21-25 (±inf for zero components)
+    r.inv = v3(HR_RCP(d.x), HR_RCP(d.y), HR_RCP(d.z));  // bvh.rs:21-25 (±inf for zero components)
     r.oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
 }
 
@@ -81,15 +89,15 @@ HD void tri_test(const Tri &tr, const Ray &r, TraceState &ts, int32_t index, Lan
     V3f c12 = cross(e1, e2);                 // det(e1,e2,c) = (e1 x e2) . c
     float den = dot(c12, ri);
     if (den == 0.0f) return;
-    float inv = 1.0f / den;
+    float inv = HR_RCP(den);
     V3f dd = r.o - v3(tr.v0);
     V3f q = cross(dd, ri);                   // helpers: det(d,e2,ri) = -(d x ri).e2 ... written out below
     float u = -dot(q, e2) * inv;             // det(d, e2, ri)  = d . (e2 x ri) = -(d x ri) . e2
-    if (u < 0.0f || u > 1.0f) return;
+    if (!(u >= 0.0f && u <= 1.0f)) return;   // bvh.rs:277 (written so that a NaN from a degenerate triangle rejects)
     float v = dot(q, e1) * inv;              // det(e1, d, ri)  = e1 . (d x ri)
-    if (v < 0.0f || u + v > 1.0f) return;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return;
     float t = dot(c12, dd) * inv;            // det(e1, e2, d)
-    if (t < 0.0f || t > ts.t) return;
+    if (!(t >= 0.0f && t <= ts.t)) return;
     ts.t = t; ts.prim = index; ts.type = 0; ts.u = u; ts.v = v;
 }
 // scene.rs:58-78 (outer root only).  Same roots as the reference's b^2 - c form, but the discriminant is
@@ -103,7 +111,7 @@ HD void sphere_test(const f4 &s, const Ray &r, TraceState &ts, int32_t index, La
     V3f perp = a - b * r.d;
     float d = s.w * s.w - dot(perp, perp);
     if (!(d > 0.0f)) return;
-    float t = -b - sqrtf(d);
+    float t = -b - HR_SQRT(d);
     if (t > 0.0f && t < ts.t) { ts.t = t; ts.prim = index; ts.type = 1; }
 }
 // bvh.rs:20-39: returns hit flag and the reference's `distance` (tmin if sign-positive else tmax)
@@ -185,14 +193,14 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         s.n = normalize(s.pos - v3(sp.x, sp.y, sp.z));
         s.elem = sc.sphere_elem[ts.prim];
         if (want_uv) {  // scene.rs:67-71
-            s.v = 1.0f - acosf(s.n.y) / PI_F;
+            s.v = 1.0f - acosf(s.n.y) * (1.0f / PI_F);
             float sg = signbit(s.n.z) ? -1.0f : 1.0f;
-            s.u = 0.5f - sg * acosf(s.n.x / sqrtf(s.n.x * s.n.x + s.n.z * s.n.z)) / PI2_F;
+            s.u = 0.5f - sg * acosf(s.n.x * HR_RSQ(s.n.x * s.n.x + s.n.z * s.n.z)) * (1.0f / PI2_F);
         }
     } else {
         const f4 mn = sc.cuboids[2 * ts.prim], mx = sc.cuboids[2 * ts.prim + 1];
         s.elem = float_as_int(mn.w);
-        V3f uvw = v3((s.pos.x - mn.x) / (mx.x - mn.x), (s.pos.y - mn.y) / (mx.y - mn.y), (s.pos.z - mn.z) / (mx.z - mn.z));
+        V3f uvw = v3((s.pos.x - mn.x) * HR_RCP(mx.x - mn.x), (s.pos.y - mn.y) * HR_RCP(mx.y - mn.y), (s.pos.z - mn.z) * HR_RCP(mx.z - mn.z));
         // scene.rs:160-182 face cascade Y+, Y-, X-, X+, Z-, Z+
         s.n = v3(0.f, 0.f, 0.f);
         if (fabsf(s.pos.y - mx.y) < EPS_F) { s.n = v3(0, 1, 0); s.u = uvw.x; s.v = 1.0f - uvw.z; }
@@ -216,7 +224,8 @@ HD V3f texel(const Scene &sc, const ImageRef &im, uint32_t x, uint32_t y) {
     uint32_t yy = im.height - y - 1u;  // wrapping
     yy = yy > im.height - 1 ? im.height - 1 : yy;
     uint32_t p = sc.texels[im.offset + yy * im.width + x];
-    return v3((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f);
+    const float k = 1.0f / 255.0f;
+    return v3((float)(p & 255u) * k, (float)((p >> 8) & 255u) * k, (float)((p >> 16) & 255u) * k);
 }
 HD float gamma_to_linear(float v) { return HR_POWF(v, 2.2f); }
 HD V3f sample_bilinear(const Scene &sc, int32_t image, float u, float v) {
@@ -237,11 +246,14 @@ HD V3f sky_sample(const Scene &sc, V3f d) {  // scene.rs:295-319
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     int face; float u, v;
     if (ax > ay && ax > az) {
-        if (!signbit(d.x)) { face = 0; u = -d.z / d.x; v = d.y / d.x; } else { face = 1; u = -d.z / d.x; v = -d.y / d.x; }
+        float i = HR_RCP(d.x);
+        if (!signbit(d.x)) { face = 0; u = -d.z * i; v = d.y * i; } else { face = 1; u = -d.z * i; v = -d.y * i; }
     } else if (ay > ax && ay > az) {
-        if (!signbit(d.y)) { face = 2; u = d.x / d.y; v = -d.z / d.y; } else { face = 3; u = -d.x / d.y; v = -d.z / d.y; }
+        float i = HR_RCP(d.y);
+        if (!signbit(d.y)) { face = 2; u = d.x * i; v = -d.z * i; } else { face = 3; u = -d.x * i; v = -d.z * i; }
     } else {
-        if (!signbit(d.z)) { face = 4; u = d.x / d.z; v = d.y / d.z; } else { face = 5; u = d.x / d.z; v = -d.y / d.z; }
+        float i = HR_RCP(d.z);
+        if (!signbit(d.z)) { face = 4; u = d.x * i; v = d.y * i; } else { face = 5; u = d.x * i; v = -d.y * i; }
     }
     return v3(sc.sky_intensity) * sample_bilinear(sc, sc.sky_image[face], 0.5f * (u + 1.0f), 0.5f * (v + 1.0f));
 }
@@ -273,19 +285,19 @@ HD V3f sample_diffuse(float r0, float r1, V3f n) {  // material.rs:227-248
     tangent_basis(n, t, b);
     float sn, cs;
     HR_SINCOS_2PI(r0, sn, cs);
-    return (t * cs + b * sn) * sqrtf(r1) + n * sqrtf(1.0f - r1);
+    return (t * cs + b * sn) * HR_SQRT(r1) + n * HR_SQRT(1.0f - r1);
 }
 HD V3f sample_ggx_half(float r0, float r1, V3f n, float alpha2) {  // material.rs:260-269
     V3f t, b;
     tangent_basis(n, t, b);
     float sn, cs;
     HR_SINCOS_2PI(r0, sn, cs);
-    float cos_theta = sqrtf((1.0f - r1) / (1.0f + (alpha2 - 1.0f) * r1));
-    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float cos_theta = HR_SQRT((1.0f - r1) * HR_RCP(1.0f + (alpha2 - 1.0f) * r1));
+    float sin_theta = HR_SQRT(1.0f - cos_theta * cos_theta);
     return t * (sin_theta * cs) + b * (sin_theta * sn) + n * cos_theta;
 }
-HD float smith_lambda(float xn, float alpha2) { float a = 1.0f / (xn * xn) - 1.0f; return 0.5f * sqrtf(1.0f + alpha2 * a) - 0.5f; }
-HD float g_smith_joint(float ln, float vn, float alpha2) { return 1.0f / (1.0f + smith_lambda(ln, alpha2) + smith_lambda(vn, alpha2)); }
+HD float smith_lambda(float xn, float alpha2) { float a = HR_RCP(xn * xn) - 1.0f; return 0.5f * HR_SQRT(1.0f + alpha2 * a) - 0.5f; }
+HD float g_smith_joint(float ln, float vn, float alpha2) { return HR_RCP(1.0f + smith_lambda(ln, alpha2) + smith_lambda(vn, alpha2)); }
 HD float f_schlick(float vh, float f0) { float x = 1.0f - vh, x2 = x * x; return f0 + (1.0f - f0) * (x * (x2 * x2)); }
 
 HD float bsdf_eval(int32_t surface, float param, float roughness, V3f view, V3f n, V3f light) {  // material.rs:53-89
@@ -296,23 +308,23 @@ HD float bsdf_eval(int32_t surface, float param, float roughness, V3f view, V3f 
     if (signbit(ln)) return 0.0f;
     float vn = dot(view, n), vh = dot(view, h), hn = dot(h, n);
     float tmp = 1.0f - (1.0f - alpha2) * hn * hn;
-    float d = alpha2 / (PI_F * tmp * tmp);
-    return d * g_smith_joint(ln, vn, alpha2) * f_schlick(vh, param) / (4.0f * ln * vn);
+    float d = alpha2 * HR_RCP(PI_F * tmp * tmp);
+    return d * g_smith_joint(ln, vn, alpha2) * f_schlick(vh, param) * HR_RCP(4.0f * ln * vn);
 }
 // material.rs:154-199
 HD void sample_refraction(float r0, V3f pos, V3f view, V3f n, float ior, V3f &no, V3f &nd, float &refl) {
     bool incoming = signbit(dot(view, n));
     V3f on = incoming ? n : -n;
-    float nnt = incoming ? 1.0f / ior : ior;
+    float nnt = incoming ? HR_RCP(ior) : ior;
     V3f rdir = reflect(view, on);
     float vn = dot(view, on);
     float k = 1.0f - nnt * nnt * (1.0f - vn * vn);  // vector.rs:64-71
     if (k < 0.0f) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; return; }
-    V3f tdir = nnt * view - (nnt * vn + sqrtf(k)) * on;
+    V3f tdir = nnt * view - (nnt * vn + HR_SQRT(k)) * on;
     if (is_zero(tdir)) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; return; }
     float cos_i = dot(view, -on), cos_t = dot(tdir, -on);
     float a = nnt * cos_i - cos_t, b = nnt * cos_i + cos_t, c = nnt * cos_t - cos_i, d = nnt * cos_t + cos_i;
-    float fr = 0.5f * (a * a / (b * b) + c * c / (d * d));
+    float fr = 0.5f * (a * a * HR_RCP(b * b) + c * c * HR_RCP(d * d));
     if (r0 <= fr) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; }
     else { no = pos - OFFSET_F * on; nd = tdir; refl = nnt * nnt; }
 }
@@ -330,7 +342,7 @@ HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3
             float ln = dot(l, n);
             if (signbit(ln)) return false;
             float vn = dot(view, n), vh = dot(view, h), hn = dot(h, n);
-            refl = f_schlick(vh, m.param) * saturatef(g_smith_joint(ln, vn, alpha2) * vh / (hn * vn));
+            refl = f_schlick(vh, m.param) * saturatef(g_smith_joint(ln, vn, alpha2) * vh * HR_RCP(hn * vn));
             no = pos + n * OFFSET_F; nd = l;
             return true;
         }
@@ -369,7 +381,7 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
     float fx = (float)px, fy = (float)(rp.height - py);
     float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
     float m = (float)(rp.width < rp.height ? rp.width : rp.height);
-    float ncx = ((fx + ox) * 2.0f - (float)rp.width) / m, ncy = ((fy + oy) * 2.0f - (float)rp.height) / m;
+    float ncx = ((fx + ox) * 2.0f - (float)rp.width) * HR_RCP(m), ncy = ((fy + oy) * 2.0f - (float)rp.height) * HR_RCP(m);
     const CameraF &c = sc.cam;
     float lx = draw_lens_f32(draws[p.draw_base + 64u * (2u * p.lens_a)]) * c.lens_radius;
     float ly = draw_lens_f32(draws[p.draw_base + 64u * (2u * p.lens_a + 1u)]) * c.lens_radius;
@@ -385,14 +397,15 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
 HD void nee_setup(const Scene &sc, Path &p) {
     const Emitter em = sc.emitters[p.emitter];
     float unit_z = 1.0f - 2.0f * p.r1;
-    float a = sqrtf(1.0f - unit_z * unit_z);
+    float a = HR_SQRT(1.0f - unit_z * unit_z);
     float sn_, cs_;
     HR_SINCOS_2PI(p.r0, sn_, cs_);
     V3f sn = v3(a * cs_, a * sn_, unit_z);
     V3f sp = v3(em.c) + (em.r + OFFSET_F) * sn;
     V3f sv = sp - p.next_o;
-    p.shadow_len = sqrtf(dot(sv, sv));
-    ray_set(p.ray, p.next_o, sv * (1.0f / p.shadow_len));
+    float sl2 = dot(sv, sv), isl = HR_RSQ(sl2);
+    p.shadow_len = sl2 * isl;
+    ray_set(p.ray, p.next_o, sv * isl);
     // a closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4),
     // so the search is limited to the sample distance + 0.03 (the reference does an unbounded closest-hit query)
     trace_begin(p.ts, p.shadow_len + 0.03f);
@@ -444,9 +457,9 @@ HD bool path_advance(const Scene &sc, Path &p, const u64 *draws, LaneCounters *c
             }
             const Emitter em = sc.emitters[p.emitter];
             V3f sp = p.ray.o + p.ray.d * p.shadow_len;
-            V3f sn = (sp - v3(em.c)) * (1.0f / (em.r + OFFSET_F));
+            V3f sn = (sp - v3(em.c)) * HR_RCP(em.r + OFFSET_F);
             float dot_0 = fabsf(dot(p.n, p.ray.d)), dot_l = fabsf(dot(sn, p.ray.d));
-            float g = (dot_0 * dot_l) / (p.shadow_len * p.shadow_len);
+            float g = (dot_0 * dot_l) * HR_RCP(p.shadow_len * p.shadow_len);
             float inv_pdf = 4.0f * PI_F * em.r * em.r;
             float w = bsdf_eval(p.surface, p.param, p.roughness, p.view, p.n, p.ray.d) * g * inv_pdf;
             p.accum = p.accum + p.nee_scale * (e * w);
