@@ -146,6 +146,7 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // One workgroup = 4 waves = 4 independent tiles (a single-wave workgroup caps residency at ~8 waves per CU).
 // No barriers: every wave owns its 48 floats of LDS and runs on its own.
 static const int TRACE_WAVES = 4;
+static const int NODE_UNROLL = 2;   // box tests per pass of the box-phase loop (amortises the ballot / branch overhead)
 
 template <bool CNT, int MINW>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails, const uint32_t *__restrict__ lens,
@@ -220,12 +221,17 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             const bool trav = active && !trace_done(p.ts);
             const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
             if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
+            // lanes allowed to be still walking when the leaf phase starts
+            const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
+            const uint32_t walk_max = n_trav - park;
             for (;;) {
                 const bool go = trav && p.ts.leaf == 0 && p.ts.cur != NODE_END;
                 const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
-                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
-                if (!n_go || n_leaf * leaf_den >= n_trav) break;
-                if (go) trace_node<CNT>(sc, p.ray, p.ts, &lc);
+                if (n_go <= walk_max) break;
+                if (go) {
+                    trace_node<CNT>(sc, p.ray, p.ts, &lc);
+                    if (NODE_UNROLL > 1 && p.ts.leaf == 0 && p.ts.cur != NODE_END) trace_node<CNT>(sc, p.ray, p.ts, &lc);
+                }
             }
             if (trav && p.ts.leaf != 0) trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
         }
