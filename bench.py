@@ -139,13 +139,14 @@ def main():
             "vs_baseline": None, "dtype": "f32",
             "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
             "config": {"workload": "%s %dx%d, %d samplings (x4 sub-samples) per step per GPU; K=64 steps = 1024 samplings" % (args.scene, W, H, SPS),
-                       "samplings_per_step_per_gpu": SPS, "samplings_per_launch": args.batch, "paths_per_step": paths_per_step_gpu * world,
+                       "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": paths_per_step_gpu * world,
                        "parallelism": "spp-sharded x%d, one all-reduce" % world},
             "rays_per_s_M": None,
         }
         launches = max(1, st["trace_launches"])
         avg_ms = st["trace_kernel_ms"] / launches
-        paths_per_launch = W * H * 4 * min(args.batch, SPS)
+        # the library may cap the samplings per launch (hand-off buffer size): use what was actually launched
+        paths_per_launch = st["paths"] / launches if st["paths"] else W * H * 4 * min(args.batch, SPS)
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4)}

@@ -312,6 +312,7 @@ struct hr_ctx {
     uint32_t adv_den = 2, leaf_den = 2;
     int min_waves = 5;
     int max_leaf = 4;
+    uint64_t max_tail_bytes = 20ull << 30;  // per buffer (two buffers)
     int num_cus = 256;
     std::vector<EventPair> seed_events, trace_events, post_events;
     double seed_ms = 0, trace_ms = 0, post_ms = 0;
@@ -540,7 +541,13 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    // the raw-draw hand-off costs 32 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
     uint32_t batch = std::max<uint32_t>(1, c->batch);
+    {
+        uint64_t per_sampling = (uint64_t)tiles * ISAAC_TAIL * 64 * sizeof(u64);
+        uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
+        batch = (uint32_t)std::min<uint64_t>(batch, fit);
+    }
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
     for (uint32_t done = 0; done < total_k; done += batch) {
@@ -668,6 +675,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "min_waves") {
         if (value < 3 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [3,6]");
         c->min_waves = (int)value;
+        return HR_OK;
+    }
+    if (k == "max_tail_gib") {
+        if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
+        c->max_tail_bytes = (uint64_t)value << 30;
         return HR_OK;
     }
     if (k == "max_leaf") {  // takes effect at the next hr_upload_scene

@@ -154,7 +154,9 @@ int hr_write_accumulator(hr_ctx *ctx, const float *host_rgb); /* resume / post-c
 int hr_resolve(hr_ctx *ctx, uint32_t samplings_done, uint8_t *host_rgb8);
 
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
-/* keys: "counters" (0/1), "rng_window" (8..256), "batch" (samplings per launch) */
+/* keys: "counters" (0/1), "batch" (samplings per launch, default 4), "adv_den" / "leaf_den" (trace-kernel phase
+ * thresholds), "min_waves" (3..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
+ * "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
 
 /* ---- unit-level entry points used by the parity tests (same kernels' device functions) ---- */
