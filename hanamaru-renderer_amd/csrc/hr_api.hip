@@ -274,6 +274,17 @@ __global__ void intersect_debug_kernel(Scene sc, uint32_t n, const float *__rest
     out_elem[i] = elem;
 }
 
+// DebugRenderer (renderer.rs:101-146): one thread per pixel, 2x2 sub-samples, pinhole rays
+__global__ void debug_render_kernel(Scene sc, RenderParams rp, int mode, float *__restrict__ accum) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= rp.width || y >= rp.height) return;
+    LaneCounters lc;
+    V3f sum = v3(0, 0, 0);
+    for (uint32_t sub = 0; sub < 4; sub++) sum = sum + debug_pixel<false>(sc, rp, x, y, sub, mode, &lc);
+    float *o = accum + ((size_t)y * rp.width + x) * 3;
+    o[0] += sum.x; o[1] += sum.y; o[2] += sum.z;
+}
+
 __global__ void tonemap_gamma_kernel(const float *__restrict__ acc, float *__restrict__ out, uint32_t n, float scale) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -588,6 +599,18 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
             if ((rc = sync_all(c))) return rc;
         }
     }
+    return HR_OK;
+}
+
+int hr_render_debug(hr_ctx *c, int mode) {
+    if (!c || mode < 0 || mode > 3) return fail(HR_ERR_INVALID, "hr_render_debug: mode must be 0..3");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_render_debug: no scene uploaded");
+    if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_render_debug: hr_set_resolution not called");
+    HIP_TRY(hipSetDevice(c->device));
+    RenderParams rp{};
+    rp.width = c->W; rp.height = c->H;
+    hipLaunchKernelGGL(debug_render_kernel, dim3((c->W + 15) / 16, (c->H + 15) / 16), dim3(16, 16), 0, c->stream, c->dsc, rp, mode, c->accum);
+    HIP_TRY(hipGetLastError());
     return HR_OK;
 }
 

@@ -477,4 +477,40 @@ HD bool path_advance(const Scene &sc, Path &p, const u64 *draws, LaneCounters *c
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// DebugRenderer::calc_pixel (renderer.rs:116-139): pinhole ray (camera.rs:98-107), no RNG.
+// mode 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane.  Also serves as a traversal-only workload.
+template <bool CNT>
+HD V3f debug_pixel(const Scene &sc, const RenderParams &rp, uint32_t px, uint32_t py, uint32_t sub, int mode, LaneCounters *cn) {
+    float fx = (float)px, fy = (float)(rp.height - py);
+    float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
+    float m = (float)(rp.width < rp.height ? rp.width : rp.height);
+    float ncx = ((fx + ox) * 2.0f - (float)rp.width) * HR_RCP(m), ncy = ((fy + oy) * 2.0f - (float)rp.height) * HR_RCP(m);
+    const CameraF &c = sc.cam;
+    Ray ray;
+    ray_set(ray, v3(c.eye), normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward)));
+    TraceState ts;
+    trace_begin(ts, T_INF);
+    while (ts.cur != NODE_END) trace_step<CNT>(sc, ray, ts, cn);
+    if (CNT) cn->rays++;
+    if (ts.prim < 0) return sky_sample(sc, ray.d);
+    Surf s;
+    hit_surface(sc, ray, ts, material_needs_uv(sc, hit_element(sc, ts)), s);
+    if (mode == 1) return s.n;
+    if (mode == 2) { float v = 0.5f * ts.t * HR_RCP(c.focus_distance); return v3(v, v, v); }
+    if (mode == 3) { float v = fabsf(ts.t - c.focus_distance); return v3(v, v, v); }
+    PointMat pm;
+    material_at(sc, s.elem, s.u, s.v, pm);
+    const V3f light = normalize(v3(1.0f, 2.0f, -1.0f));
+    Ray sh;
+    ray_set(sh, s.pos + s.n * OFFSET_F, light);
+    TraceState st;
+    trace_begin(st, T_INF);
+    while (st.cur != NODE_END) trace_step<CNT>(sc, sh, st, cn);
+    if (CNT) cn->rays++;
+    float shadow = st.prim >= 0 ? 0.5f : 1.0f;
+    float diffuse = fmaxf(dot(s.n, light), 0.0f);
+    return pm.emission + pm.albedo * (diffuse * shadow);
+}
+
 }  // namespace hr

@@ -1,7 +1,10 @@
 // hanamaru-hip — host driver with the reference binary's flag surface and outputs (main.rs:1226-1295,
 // renderer.rs:205-251): `hanamaru-hip -w W -h H -s S -t SEC -i SEC`.  Stand-in for the Rust host (no Rust
 // toolchain here): scene authoring + PNG writing stay on the host, the render loop calls the C ABI.
-// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N.
+// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N,
+// --checkpoint FILE (write the fp32 accumulator + sampling count when the render stops) and --resume FILE
+// (continue from such a file: samplings are independent and seeded by index, so a resumed render adds exactly
+// the samplings that are missing — SURVEY.md §8f rank 3; the reference has no resumable state).
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -36,7 +39,7 @@ static double now_sec() {
 static void usage(const char *prog) {
     printf("Usage: %s [options]\n\nOptions:\n"
            "        --help          print this help menu\n"
-           "    -d, --debug         use debug mode (not supported by the HIP back end)\n"
+           "    -d, --debug         use debug mode\n"
            "    -w, --width WIDTH   output resolution width\n"
            "    -h, --height HEIGHT output resolution height\n"
            "    -s, --sampling SAMPLING\n                        sampling limit\n"
@@ -44,14 +47,16 @@ static void usage(const char *prog) {
            "    -i, --interval INTERVAL\n                        report interval sec\n"
            "        --scene NAME    rtcamp6_v3_1 (default) | spheres | rtcamp6_dodeca | cornell_mini\n"
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
-           "        --batch N       samplings per kernel launch (default 4)\n",
+           "        --batch N       samplings per kernel launch (default 4)\n"
+           "        --checkpoint F  write accumulator + sampling count to F when the render stops\n"
+           "        --resume F      continue from a checkpoint file\n",
            prog);
 }
 
 int main(int argc, char **argv) {
     uint32_t width = 1920, height = 1080, sampling = 1000;  // main.rs:1249-1251
     double time_limit = 123.0, interval = 15.0;              // main.rs:1255-1256
-    std::string scene_name = "rtcamp6_v3_1", assets;
+    std::string scene_name = "rtcamp6_v3_1", assets, ckpt_out, ckpt_in;
     int batch = 4;
     bool debug = false;
     for (int i = 1; i < argc; i++) {
@@ -70,9 +75,10 @@ int main(int argc, char **argv) {
         else if (a == "--scene") scene_name = val("scene");
         else if (a == "--assets") assets = val("assets");
         else if (a == "--batch") batch = atoi(val("batch"));
+        else if (a == "--checkpoint") ckpt_out = val("checkpoint");
+        else if (a == "--resume") ckpt_in = val("resume");
         else { fprintf(stderr, "Unrecognized option: '%s'.\n", a.c_str()); return 1; }
     }
-    if (debug) { fprintf(stderr, "debug renderer (renderer.rs:101-146) is out of scope for the HIP back end\n"); return 1; }
     if (assets.empty()) {
         FILE *probe = fopen("assets/models/box.obj", "rb");
         if (probe) { fclose(probe); assets = "assets"; } else assets = ".";
@@ -107,7 +113,28 @@ int main(int argc, char **argv) {
         printf("update_imgbuf: %.3f sec\n", now_sec() - t0);
         return hh_write_png_rgb8(path, rgb.data(), width, height);
     };
-    for (uint32_t s = 1; s <= sampling;) {
+    uint32_t first = 1;
+    if (!ckpt_in.empty()) {
+        FILE *f = fopen(ckpt_in.c_str(), "rb");
+        uint32_t hdr[4] = {0, 0, 0, 0};
+        std::vector<float> acc((size_t)width * height * 3);
+        bool ok = f && fread(hdr, 4, 4, f) == 4 && hdr[0] == 0x43415248u /* "HRAC" */ && hdr[1] == width && hdr[2] == height &&
+                  fread(acc.data(), sizeof(float), acc.size(), f) == acc.size();
+        if (f) fclose(f);
+        if (!ok) { fprintf(stderr, "cannot resume from %s (missing, wrong magic or resolution)\n", ckpt_in.c_str()); return 1; }
+        CHECK_HR(hr_write_accumulator(ctx, acc.data()));
+        first = hdr[3] + 1;
+        sampled = hdr[3];
+        printf("resumed at %ux4 sampled\n", hdr[3]);
+    }
+    if (debug) {  // main.rs:1279-1281: DebugRenderer { mode: FocalPlane }, max_sampling 1, report_progress = update_imgbuf + stop
+        CHECK_HR(hr_render_debug(ctx, 3));
+        CHECK_HR(hr_synchronize(ctx));
+        CHECK_HR(hr_resolve(ctx, 1, rgb.data()));
+        sampled = 1;
+        sampling = 0;
+    }
+    for (uint32_t s = first; s <= sampling;) {
         uint32_t e = s + (uint32_t)batch;
         if (e > sampling + 1) e = sampling + 1;
         CHECK_HR(hr_render(ctx, s, e, 1));
@@ -133,6 +160,15 @@ int main(int argc, char **argv) {
         }
         last_progress = now;
         s = e;
+    }
+    if (!ckpt_out.empty()) {
+        std::vector<float> acc((size_t)width * height * 3);
+        CHECK_HR(hr_read_accumulator(ctx, acc.data()));
+        uint32_t hdr[4] = {0x43415248u, width, height, sampled};
+        FILE *f = fopen(ckpt_out.c_str(), "wb");
+        bool ok = f && fwrite(hdr, 4, 4, f) == 4 && fwrite(acc.data(), sizeof(float), acc.size(), f) == acc.size();
+        if (f) fclose(f);
+        if (!ok) { fprintf(stderr, "cannot write checkpoint %s\n", ckpt_out.c_str()); return 1; }
     }
     if (hh_write_png_rgb8("result.png", rgb.data(), width, height) != 0) { fprintf(stderr, "png: %s\n", hh_last_error()); return 1; }
     tee("sampled: %ux%u spp.", sampled, 4u);

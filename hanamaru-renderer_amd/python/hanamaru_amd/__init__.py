@@ -127,6 +127,7 @@ def hip_lib():
         L.hr_clear.argtypes = [C.c_void_p]
         L.hr_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.hr_synchronize.argtypes = [C.c_void_p]
+        L.hr_render_debug.argtypes = [C.c_void_p, C.c_int]
         L.hr_read_accumulator.argtypes = [C.c_void_p, C.c_void_p]
         L.hr_write_accumulator.argtypes = [C.c_void_p, C.c_void_p]
         L.hr_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -259,6 +260,9 @@ class Renderer:
 
     def render(self, begin, end, stride=1):
         self._check(self.L.hr_render(self._h, begin, end, stride))
+
+    def render_debug(self, mode):
+        self._check(self.L.hr_render_debug(self._h, mode))
 
     def synchronize(self):
         self._check(self.L.hr_synchronize(self._h))

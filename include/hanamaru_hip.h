@@ -147,6 +147,11 @@ int hr_clear(hr_ctx *ctx);                 /* zero accumulator + stats */
 int hr_render(hr_ctx *ctx, uint32_t sampling_begin, uint32_t sampling_end, uint32_t stride);
 int hr_synchronize(hr_ctx *ctx);
 
+/* DebugRenderer (renderer.rs:101-146, max_sampling = 1): adds ONE sampling of the chosen visualiser to the
+ * accumulator — pinhole rays, no RNG.  mode: 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane (renderer.rs:102-107;
+ * the reference's -d flag selects FocalPlane, main.rs:1280).  Resolve with samplings_done = 1. */
+int hr_render_debug(hr_ctx *ctx, int mode);
+
 int hr_read_accumulator(hr_ctx *ctx, float *host_rgb);        /* W*H*3, row-major, top row first */
 int hr_write_accumulator(hr_ctx *ctx, const float *host_rgb); /* resume / post-chain tests */
 

@@ -18,7 +18,7 @@
  *     published known-answer vectors.  The u64->f64 conversion (B.3) is
  *     recalled, not pinned; flip ORC_F64_FROM_TOP53 to switch to the other known variant.
  *   - structural known-answers (BVH shapes, Appendix C.3; path statistics, Appendix D.2) are checked in
- *     tests/test_oracle_scene.py.
+ *     tests/test_oracle.py.
  */
 #include <atomic>
 #include <algorithm>
@@ -875,6 +875,48 @@ ORC_API int orc_render(const orc_scene *os, uint32_t W, uint32_t H, uint32_t s_b
         for (auto &c : cns) add_counters(total, c);
         memcpy(counters_out, &total, sizeof total);
     }
+    return 0;
+}
+
+// DebugRenderer::calc_pixel (renderer.rs:116-139) + Renderer::render's 2x2 supersampling, one sampling.
+// mode: 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane (renderer.rs:102-107)
+ORC_API int orc_render_debug(const orc_scene *os, uint32_t W, uint32_t H, int mode, double *acc) {
+    if (!os || !acc || mode < 0 || mode > 3) return -1;
+    const Scene &s = os->s;
+    const hr_camera &c = s.camera;
+    V3 light_direction = normalize(V3(1.0, 2.0, -1.0));
+    for (uint32_t y = 0; y < H; y++)
+        for (uint32_t x = 0; x < W; x++) {
+            V3 sum;
+            for (uint32_t sy = 0; sy < SUPERSAMPLING; sy++)
+                for (uint32_t sx = 0; sx < SUPERSAMPLING; sx++) {
+                    double ncx, ncy;
+                    normalized_coord(W, H, x, y, sx, sy, ncx, ncy);
+                    Ray ray;  // camera.rs:98-107 (pinhole)
+                    ray.origin = V3(c.eye);
+                    ray.direction = normalize(ncx * V3(c.plane_half_right) + ncy * V3(c.plane_half_up) + c.focus_distance * V3(c.forward));
+                    Intersection isect;
+                    bool hit = scene_intersect(s, ray, isect, nullptr, nullptr);
+                    V3 col;
+                    if (hit) {
+                        if (mode == 0) {
+                            Ray shadow_ray{isect.position + isect.normal * OFFSET, light_direction};
+                            Intersection si;
+                            bool shadow_hit = scene_intersect(s, shadow_ray, si, nullptr, nullptr);
+                            double shadow = shadow_hit ? 0.5 : 1.0;
+                            double diffuse = std::fmax(dot(isect.normal, light_direction), 0.0);
+                            col = isect.material.emission + isect.material.albedo * diffuse * shadow;
+                        } else if (mode == 1) col = isect.normal;
+                        else if (mode == 2) { double v = 0.5 * isect.distance / c.focus_distance; col = V3(v, v, v); }
+                        else { double v = std::fabs(isect.distance - c.focus_distance); col = V3(v, v, v); }
+                    } else {
+                        col = isect.material.emission;
+                    }
+                    sum = sum + col;
+                }
+            double *p = &acc[((size_t)y * W + x) * 3];
+            p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
+        }
     return 0;
 }
 

@@ -28,6 +28,7 @@ def lib():
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_counters_size.restype = C.c_size_t
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_calc_pixel.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
         L.orc_path_draws.argtypes = [C.c_uint32] * 7 + [C.c_void_p, C.c_int]
         L.orc_isaac64.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
@@ -82,6 +83,12 @@ class OracleScene:
             cd["rays_per_path_hist"] = vals[len(COUNTER_FIELDS):len(COUNTER_FIELDS) + 24]
             cd["draws_per_path_hist"] = vals[len(COUNTER_FIELDS) + 24:len(COUNTER_FIELDS) + 64]
         return acc, cd
+
+    def render_debug(self, w, h, mode):
+        acc = np.zeros((h, w, 3), dtype=np.float64)
+        rc = lib().orc_render_debug(self._h, w, h, mode, acc.ctypes.data)
+        assert rc == 0
+        return acc
 
     def calc_pixel(self, w, h, x, y, sx, sy, sampling):
         out = np.zeros(3, dtype=np.float64)

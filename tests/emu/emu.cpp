@@ -129,6 +129,20 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
     return 0;
 }
 
+int emu_render_debug(const emu_scene *e, uint32_t W, uint32_t H, int mode, float *acc) {
+    RenderParams rp{};
+    rp.width = W; rp.height = H;
+    LaneCounters lc;
+    for (uint32_t y = 0; y < H; y++)
+        for (uint32_t x = 0; x < W; x++) {
+            V3f sum = v3(0, 0, 0);
+            for (uint32_t sub = 0; sub < 4; sub++) sum = sum + debug_pixel<false>(e->view, rp, x, y, sub, mode, &lc);
+            float *o = &acc[((size_t)y * W + x) * 3];
+            o[0] += sum.x; o[1] += sum.y; o[2] += sum.z;
+        }
+    return 0;
+}
+
 int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out, int32_t *out_elem) {
     const Scene &sc = e->view;
     for (uint32_t i = 0; i < n; i++) {

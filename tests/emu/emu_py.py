@@ -19,6 +19,7 @@ def lib():
         L.emu_path_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
@@ -52,6 +53,11 @@ class EmuScene:
         cn = (C.c_uint64 * 6)()
         lib().emu_render(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data, cn)
         return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests"], list(cn)))
+
+    def render_debug(self, w, h, mode):
+        acc = np.zeros((h, w, 3), dtype=np.float32)
+        lib().emu_render_debug(self._h, w, h, mode, acc.ctypes.data)
+        return acc
 
     def intersect(self, rays):
         r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

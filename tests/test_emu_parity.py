@@ -103,3 +103,16 @@ def test_post_chain(emu_scenes, emu, orc):
     acc = np.zeros((4, 4, 3), dtype=np.float32)
     acc[1, 1] = 1e6
     assert np.array_equal(emu.resolve(acc, 1), orc.resolve(acc.astype(np.float64), 1))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_debug_renderer(emu_scenes, mode):
+    """DebugRenderer modes (renderer.rs:101-146): Shading / Normal / Depth / FocalPlane, pinhole rays, no RNG."""
+    _, o, e = emu_scenes("rtcamp6_v3_1")
+    w, h = 64, 36
+    got = e.render_debug(w, h, mode).astype(np.float64)
+    ref = o.render_debug(w, h, mode)
+    d = np.abs(got - ref)
+    tol = 2e-3 * np.maximum(1.0, np.abs(ref))
+    assert (d <= tol).mean() > 0.99        # silhouette pixels may resolve to a different primitive in fp32
+    assert abs(got.mean() - ref.mean()) < 2e-3 * max(1.0, abs(ref.mean()))
