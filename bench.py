@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--leaf-den", type=int, default=0)
     ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--max-leaf", type=int, default=0)
+    ap.add_argument("--split-ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -73,6 +74,8 @@ def main():
     r = ha.Renderer(local_rank)
     if args.max_leaf:
         r.set_option("max_leaf", args.max_leaf)
+    if args.split_ratio:
+        r.set_option("split_ratio", args.split_ratio)
     r.upload_scene(scene)
     r.set_resolution(W, H)
     r.set_option("batch", args.batch)

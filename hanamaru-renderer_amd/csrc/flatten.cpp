@@ -7,6 +7,63 @@
 
 namespace hr {
 
+// ---- early split clipping (Ernst & Greiner 2007): a long thin triangle that runs diagonally through space has
+// an AABB hundreds of times larger than itself (the wire-frame bunny is made of such triangles).  Before the
+// BVH is built its reference is split along the longest axis of its box, clipping the triangle to each half, until
+// the box is no longer much larger than the piece of triangle inside it.  Leaves then hold several references to
+// the same triangle; closest-hit results are unchanged (the same triangle tested twice gives the same t).
+struct P3 { double x[3]; };
+static void poly_box(const std::vector<P3> &poly, double *mn, double *mx) {
+    for (int a = 0; a < 3; a++) { mn[a] = 1e300; mx[a] = -1e300; }
+    for (const P3 &p : poly) for (int a = 0; a < 3; a++) { mn[a] = std::fmin(mn[a], p.x[a]); mx[a] = std::fmax(mx[a], p.x[a]); }
+}
+static double poly_area(const std::vector<P3> &poly) {
+    double ax = 0, ay = 0, az = 0;
+    for (size_t i = 1; i + 1 < poly.size(); i++) {
+        double e1[3], e2[3];
+        for (int a = 0; a < 3; a++) { e1[a] = poly[i].x[a] - poly[0].x[a]; e2[a] = poly[i + 1].x[a] - poly[0].x[a]; }
+        ax += e1[1] * e2[2] - e1[2] * e2[1]; ay += e1[2] * e2[0] - e1[0] * e2[2]; az += e1[0] * e2[1] - e1[1] * e2[0];
+    }
+    return 0.5 * std::sqrt(ax * ax + ay * ay + az * az);
+}
+static void clip_poly(const std::vector<P3> &in, int axis, double pos, bool keep_low, std::vector<P3> &out) {
+    out.clear();
+    size_t n = in.size();
+    for (size_t i = 0; i < n; i++) {
+        const P3 &a = in[i], &b = in[(i + 1) % n];
+        bool ia = keep_low ? a.x[axis] <= pos : a.x[axis] >= pos, ib = keep_low ? b.x[axis] <= pos : b.x[axis] >= pos;
+        if (ia) out.push_back(a);
+        if (ia != ib) {
+            double t = (pos - a.x[axis]) / (b.x[axis] - a.x[axis]);
+            P3 c;
+            for (int k = 0; k < 3; k++) c.x[k] = a.x[k] + t * (b.x[k] - a.x[k]);
+            c.x[axis] = pos;
+            out.push_back(c);
+        }
+    }
+}
+static void split_refs(const std::vector<P3> &poly, uint32_t tri_index, int depth, double ratio_max, std::vector<BuildPrim> &out) {
+    double mn[3], mx[3];
+    poly_box(poly, mn, mx);
+    double d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    double sa = 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    double area = poly_area(poly);
+    int axis = d[0] > d[1] ? (d[0] > d[2] ? 0 : 2) : (d[1] > d[2] ? 1 : 2);
+    if (depth <= 0 || poly.size() < 3 || !(sa > ratio_max * 4.0 * area) || !(d[axis] > 1e-6)) {
+        BuildPrim p{};
+        p.type = 0; p.index = tri_index;
+        for (int a = 0; a < 3; a++) { p.bmin[a] = mn[a]; p.bmax[a] = mx[a]; }
+        out.push_back(p);
+        return;
+    }
+    double pos = 0.5 * (mn[axis] + mx[axis]);
+    std::vector<P3> lo, hi;
+    clip_poly(poly, axis, pos, true, lo);
+    clip_poly(poly, axis, pos, false, hi);
+    if (lo.size() >= 3) split_refs(lo, tri_index, depth - 1, ratio_max, out);
+    if (hi.size() >= 3) split_refs(hi, tri_index, depth - 1, ratio_max, out);
+}
+
 static int ferr(std::string &err, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -31,7 +88,7 @@ Scene HostScene::view() const {
     return d;
 }
 
-int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf) {
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf, double split_ratio) {
     if (!sd) return ferr(err, HR_ERR_INVALID, "null scene");
     if (!sd->elements || sd->num_elements == 0) return ferr(err, HR_ERR_INVALID, "scene has no elements");
     struct TriD { double v0[3], v1[3], v2[3]; int32_t elem; };
@@ -90,20 +147,26 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
                 const hr_vec3 &a = e.vertexes[i0], &b = e.vertexes[i1], &cc = e.vertexes[i2];
                 t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z;
                 t.v2[0] = cc.x; t.v2[1] = cc.y; t.v2[2] = cc.z; t.elem = (int32_t)ei;
-                BuildPrim p{};
-                p.type = 0; p.index = (uint32_t)tris.size();
-                for (int k = 0; k < 3; k++) {
-                    p.bmin[k] = std::fmin(std::fmin(t.v0[k], t.v1[k]), t.v2[k]);
-                    p.bmax[k] = std::fmax(std::fmax(t.v0[k], t.v1[k]), t.v2[k]);
+                if (split_ratio > 0.0) {
+                    std::vector<P3> poly(3);
+                    for (int k = 0; k < 3; k++) { poly[0].x[k] = t.v0[k]; poly[1].x[k] = t.v1[k]; poly[2].x[k] = t.v2[k]; }
+                    split_refs(poly, (uint32_t)tris.size(), 6, split_ratio, prims);
+                } else {
+                    BuildPrim p{};
+                    p.type = 0; p.index = (uint32_t)tris.size();
+                    for (int k = 0; k < 3; k++) {
+                        p.bmin[k] = std::fmin(std::fmin(t.v0[k], t.v1[k]), t.v2[k]);
+                        p.bmax[k] = std::fmax(std::fmax(t.v0[k], t.v1[k]), t.v2[k]);
+                    }
+                    prims.push_back(p);
                 }
-                prims.push_back(p);
                 tris.push_back(t);
             }
         } else {
             return ferr(err, HR_ERR_INVALID, "element %u: unknown kind %d", ei, e.kind);
         }
     }
-    if (tris.size() >= (1u << 20) || spheres.size() >= (1u << 20) || cuboids.size() / 2 >= (1u << 20))
+    if (prims.size() >= (1u << 20) || tris.size() >= (1u << 20) || spheres.size() >= (1u << 20) || cuboids.size() / 2 >= (1u << 20))
         return ferr(err, HR_ERR_UNSUPPORTED, "more than 2^20 primitives of one type");
 
     BuiltBvh bvh;
@@ -111,8 +174,8 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     out.nodes = bvh.nodes; out.num_nodes = bvh.num_nodes;
     out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves;
 
-    out.tris.assign(tris.size(), Tri{});
-    for (size_t i = 0; i < tris.size(); i++) {
+    out.tris.assign(bvh.order[0].size(), Tri{});   // one record per reference (split triangles appear more than once)
+    for (size_t i = 0; i < bvh.order[0].size(); i++) {
         const TriD &s = tris[bvh.order[0][i]];
         Tri &d = out.tris[i];
         memset(&d, 0, sizeof d);

@@ -31,6 +31,8 @@ struct HostScene {
 };
 
 // returns HR_OK or a negative hr_status; `err` receives the message
-int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf = 4);
+// split_ratio > 0 enables early split clipping of triangle references whose box surface area exceeds
+// split_ratio x 4 x (triangle area inside the box)
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf = 4, double split_ratio = 0.0);
 
 }  // namespace hr

@@ -323,6 +323,7 @@ struct hr_ctx {
     uint32_t adv_den = 2, leaf_den = 2;
     int min_waves = 5;
     int max_leaf = 4;
+    double split_ratio = 0.0;
     uint64_t max_tail_bytes = 20ull << 30;  // per buffer (two buffers)
     int num_cus = 256;
     std::vector<EventPair> seed_events, trace_events, post_events;
@@ -439,7 +440,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
 
     HostScene hs;
     std::string ferr;
-    rc = flatten_scene(sd, hs, ferr, c->max_leaf);
+    rc = flatten_scene(sd, hs, ferr, c->max_leaf, c->split_ratio);
     if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());
     Scene &d = c->dsc;
     d = hs.view();
@@ -703,6 +704,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "max_tail_gib") {
         if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
         c->max_tail_bytes = (uint64_t)value << 30;
+        return HR_OK;
+    }
+    if (k == "split_ratio") {  // early split clipping of triangle references (0 = off), next hr_upload_scene
+        if (value < 0 || value > 1000) return fail(HR_ERR_INVALID, "split_ratio must be in [0,1000]");
+        c->split_ratio = value;
         return HR_OK;
     }
     if (k == "max_leaf") {  // takes effect at the next hr_upload_scene

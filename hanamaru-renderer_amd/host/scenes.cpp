@@ -199,6 +199,20 @@ static void build_rtcamp6_v3_1(Builder &b, bool with_dodecahedron) {
     }
 }
 
+// main.rs:928-1017 (not live in main()): two NEE emitters, one of them a 1 mm "camera light",
+// strong depth of field, white diffuse floor
+static void build_rtcamp6_v3(Builder &b) {
+    hh_camera_new(V3(0.0, 2.0, 6.0).c(), V3(0.0, 1.0, 0.0).c(), normalize(V3(0, 1, 0)).c(), 20.0, 1, 0.2, 4.9, &b.sc->desc.camera);
+    const hr_camera &cam = b.sc->desc.camera;
+    double radius = 0.2;
+    b.add_sphere(V3(-0.3, 0.5 + radius, 0.0), radius, mat(HR_DIFFUSE, 0, tex_one(0), tex_one(10.0), tex_one(0)));
+    b.add_sphere(V3(cam.eye) - V3(cam.forward), 0.001, mat(HR_DIFFUSE, 0, tex_one(0), tex_one(1000.0), tex_one(0)));
+    b.add_mesh("models/bunny/bunny_wired_300.obj", M44::scale_linear(1.5) * M44::translate(0, 0, 0) * M44::rotate_y(0.3),
+               mat(HR_GGX, 0.8, tex_color(V3(1.0, 0.01, 0.01)), tex_one(0), tex_one(0.05)));
+    b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_DIFFUSE, 0, tex_one(1), tex_one(0), tex_one(1)));
+    b.skybox("textures/cube/Powerlines", V3(1, 1, 1));
+}
+
 // BASELINE config 2 (build-defined): sphere generator of main.rs:862-905
 static void build_spheres(Builder &b) {
     const uint64_t seed[4] = {870, 2000, 304, 2};  // main.rs:805
@@ -320,6 +334,7 @@ int hh_scene_create(const char *name, const char *asset_root, hh_scene **out) {
     for (int i = 0; i < 6; i++) sc->desc.skybox.face_image[i] = -1;
     if (n == "rtcamp6_v3_1") build_rtcamp6_v3_1(b, false);
     else if (n == "rtcamp6_dodeca") build_rtcamp6_v3_1(b, true);
+    else if (n == "rtcamp6_v3") build_rtcamp6_v3(b);
     else if (n == "spheres") build_spheres(b);
     else if (n == "cornell_mini") build_cornell_mini(b);
     else { set_error("unknown scene '%s'", name); return HR_ERR_INVALID; }

@@ -49,10 +49,14 @@ static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_
 
 extern "C" {
 
+static int g_max_leaf = 4;
+static double g_split_ratio = 0.0;
+void emu_set_build_options(int max_leaf, double split_ratio) { g_max_leaf = max_leaf; g_split_ratio = split_ratio; }
+
 int emu_scene_create(const hr_scene_desc *sd, emu_scene **out) {
     emu_scene *e = new emu_scene;
     std::string err;
-    int rc = flatten_scene(sd, e->hs, err);
+    int rc = flatten_scene(sd, e->hs, err, g_max_leaf, g_split_ratio);
     if (rc) { fprintf(stderr, "emu: %s\n", err.c_str()); delete e; return rc; }
     e->view = e->hs.view();
     *out = e;

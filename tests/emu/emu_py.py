@@ -15,6 +15,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.emu_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.emu_scene_destroy.argtypes = [C.c_void_p]
+        L.emu_set_build_options.argtypes = [C.c_int, C.c_double]
         L.emu_scene_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_path_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
@@ -65,6 +66,10 @@ class EmuScene:
         el = np.empty((r.shape[0],), dtype=np.int32)
         lib().emu_intersect(self._h, r.shape[0], r.ctypes.data, out.ctypes.data, el.ctypes.data)
         return out, el
+
+
+def set_build_options(max_leaf=4, split_ratio=0.0):
+    lib().emu_set_build_options(max_leaf, split_ratio)
 
 
 def path_draws(w, h, x, y, sub, sampling, lens_shape=1):
