@@ -159,7 +159,11 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_path * paths_per_launch),
                          "node_tests_per_ray": round(counters["node_tests"] / max(1, counters["rays"]), 2),
                          "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
-                         "rays_per_path": round(counters["rays"] / max(1, counters["paths"]), 3)})
+                         "rays_per_path": round(counters["rays"] / max(1, counters["paths"]), 3),
+                         "lanes_per_shade_call": round(counters["shade_lanes"] / max(1, counters["shade_calls"]), 1),
+                         "lanes_per_box_pass": round(counters["box_lanes"] / max(1, counters["box_passes"]), 1),
+                         "lanes_per_leaf_call": round(counters["leaf_lanes"] / max(1, counters["leaf_calls"]), 1),
+                         "wave_passes_per_path": {k: round(counters[k] / max(1, counters["paths"]), 3) for k in ("shade_calls", "box_passes", "leaf_calls")}})
             out["rays_per_s_M"] = round(value * counters["rays"] / max(1, counters["paths"]), 1)
         # HBM traffic is a PMC measurement (separate rocprofv3 --pmc pass, see profiles/); scaled per launch
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")

@@ -91,6 +91,8 @@ static const int DRAWS_PER_PATH = 20; // what a path can consume at most (debug 
 
 struct Counters {
     unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, pad;
+    // wave-level phase statistics of the trace kernel (counters build): invocations and lanes served
+    unsigned long long shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters, pad2;
 };
 
 }  // namespace hr

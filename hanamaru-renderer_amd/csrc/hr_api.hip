@@ -143,47 +143,50 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// One workgroup = 4 waves = 4 independent tiles (a single-wave workgroup caps residency at ~8 waves per CU).
-// No barriers: every wave owns its 48 floats of LDS and runs on its own.
+// Persistent waves: a workgroup is 4 independent waves (single-wave workgroups cap residency at ~8 waves per CU);
+// every wave pulls 4x4-pixel tiles from a global counter until none are left.  A tile = 64 paths per sampling of
+// the batch; finished lanes are refilled from the tile's path queue, and when that runs dry the wave pulls the
+// next tile while its slow lanes are still working, so lanes only starve at the very end of a launch
+// (measured before: with one tile per wave the mean box-phase pass had 19.6 of 64 lanes active).
+// No barriers, no LDS.
 static const int TRACE_WAVES = 4;
 static const int NODE_UNROLL = 2;   // box tests per pass of the box-phase loop (amortises the ballot / branch overhead)
 
 template <bool CNT, int MINW>
-__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails, const uint32_t *__restrict__ lens,
-                                                                 float *__restrict__ accum, Counters *cnt) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails,
+                                                                       const uint32_t *__restrict__ lens, float *__restrict__ accum,
+                                                                       Counters *cnt, uint32_t *tile_counter) {
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
-    // Workgroup b runs on XCD b % 8 (observed dispatch order).  Tiles differ in cost by an order of magnitude
-    // (sky vs. the wire-frame bunny), so neighbouring tile groups are dealt round-robin to the XCDs: every
-    // XCD sees the same mix of cheap and expensive image regions.  (A contiguous band per XCD was measured
-    // ~40 % slower: the XCDs holding the bunny finish last.)  The scene (~4 MB) is resident in every XCD's L2.
-    const uint32_t groups = (tiles + TRACE_WAVES - 1) / TRACE_WAVES;
-    const uint32_t group = blockIdx.x;
-    const uint32_t tile = group * TRACE_WAVES + wave;
-    if (group >= groups || tile >= tiles) return;
-
     LaneCounters lc = {0, 0, 0, 0, 0};
     uint32_t npaths = 0;
-    const uint32_t total = 64u * rp.num_k;
-    uint32_t next = 0;  // wave-uniform queue head: slot q = k * 64 + j
+    uint32_t ph[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform phase statistics (counters build only)
+    const uint32_t total = 64u * rp.num_k;   // paths per tile in this launch: slot q = k * 64 + j
+    const size_t tile_stride = (size_t)rp.num_k * ISAAC_TAIL * 64;
+    uint32_t cur_tile = 0, next = total;      // wave-uniform: the tile being handed out and its queue head
+    bool exhausted = false;
     Path p;
     p.q = PATH_IDLE;
+    p.tile = 0;
     p.ts.cur = NODE_END; p.ts.leaf = 0;
-    const u64 *tile_tails = tails + (size_t)tile * rp.num_k * ISAAC_TAIL * 64;
-    const uint32_t *tile_lens = lens + (size_t)tile * rp.num_k * 64;
     const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
 
     for (;;) {
         // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
+        if (CNT) {
+            uint32_t n = (uint32_t)__popcll(__ballot(p.q != PATH_IDLE && trace_done(p.ts)));
+            ph[6]++;
+            if (n) { ph[0]++; ph[1] += n; }
+        }
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
-            if (path_advance<CNT>(sc, p, tile_tails, &lc)) {
+            if (path_advance<CNT>(sc, p, tails + (size_t)p.tile * tile_stride, &lc)) {
                 // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
                 // path adds its radiance straight into the accumulator.  A tile belongs to exactly one wave of
                 // one launch, so only lanes of this wave ever touch these addresses: workgroup-scope atomics
                 // (executed in the XCD's L2) are sufficient.
                 uint32_t pix = (p.q & 63u) >> 2;
-                uint32_t px = (tile % rp.tiles_x) * 4u + (pix & 3u), py = (tile / rp.tiles_x) * 4u + (pix >> 2);
+                uint32_t px = (p.tile % rp.tiles_x) * 4u + (pix & 3u), py = (p.tile / rp.tiles_x) * 4u + (pix >> 2);
                 float *dst = accum + ((size_t)py * rp.width + px) * 3;
                 __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -191,27 +194,37 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 p.q = PATH_IDLE;
             }
         }
-        // ---- B: refill idle lanes from the tile's path queue (ballot + prefix rank = live-lane compaction)
+        // ---- B: refill idle lanes (ballot + prefix rank = live-lane compaction); pull a new tile when the queue is dry
         unsigned long long idle = __ballot(p.q == PATH_IDLE);
-        if (idle && next < total) {
-            uint32_t q = next + lane_rank(idle);
-            if (p.q == PATH_IDLE && q < total) {
-                uint32_t k = q >> 6, j = q & 63u, px, py, sub;
-                tile_lane_pixel(rp, tile, j, px, py, sub);
-                if (px < rp.width && py < rp.height) {
-                    p.q = q;
-                    p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
-                    p.lens_a = tile_lens[k * 64 + j];
-                    path_start(sc, rp, p, px, py, sub, tile_tails);
-                    npaths++;
-                }
+        if (idle) {
+            if (next >= total && !exhausted) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(tile_counter, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= tiles) exhausted = true;
+                else { cur_tile = t; next = 0; }
             }
-            next += (uint32_t)__popcll(idle);
+            if (next < total) {
+                uint32_t q = next + lane_rank(idle);
+                if (p.q == PATH_IDLE && q < total) {
+                    uint32_t k = q >> 6, j = q & 63u, px, py, sub;
+                    tile_lane_pixel(rp, cur_tile, j, px, py, sub);
+                    if (px < rp.width && py < rp.height) {
+                        p.q = q;
+                        p.tile = cur_tile;
+                        p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
+                        p.lens_a = lens[((size_t)cur_tile * rp.num_k + k) * 64 + j];
+                        path_start(sc, rp, p, px, py, sub, tails + (size_t)cur_tile * tile_stride);
+                        npaths++;
+                    }
+                }
+                next += (uint32_t)__popcll(idle);
+            }
         }
         const bool active = p.q != PATH_IDLE;
         const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
         if (!n_active) {
-            if (next >= total) break;
+            if (exhausted) break;
             continue;
         }
         // ---- C: traversal as two well-filled phases.  Box phase: lanes walk nodes until 1/leaf_den of the
@@ -228,10 +241,15 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 const bool go = trav && p.ts.leaf == 0 && p.ts.cur != NODE_END;
                 const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
                 if (n_go <= walk_max) break;
+                if (CNT) { ph[2]++; ph[3] += n_go; }
                 if (go) {
                     trace_node<CNT>(sc, p.ray, p.ts, &lc);
                     if (NODE_UNROLL > 1 && p.ts.leaf == 0 && p.ts.cur != NODE_END) trace_node<CNT>(sc, p.ray, p.ts, &lc);
                 }
+            }
+            if (CNT) {
+                uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
+                if (n) { ph[4]++; ph[5] += n; }
             }
             if (trav && p.ts.leaf != 0) trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
         }
@@ -247,6 +265,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         if (lane == 0) {
             atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
             atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
+            atomicAdd(&cnt->shade_calls, (unsigned long long)ph[0]); atomicAdd(&cnt->shade_lanes, (unsigned long long)ph[1]);
+            atomicAdd(&cnt->box_passes, (unsigned long long)ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ph[3]);
+            atomicAdd(&cnt->leaf_calls, (unsigned long long)ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ph[5]);
+            atomicAdd(&cnt->outer_iters, (unsigned long long)ph[6]);
         }
     }
 }
@@ -316,6 +338,7 @@ struct hr_ctx {
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
     bool trace_pending[2] = {false, false};
     Counters *d_counters = nullptr;
+    uint32_t *d_tile_counter = nullptr;  // [2]: next tile of the trace launch in each slot
     float *post_tmp = nullptr;
     uint8_t *d_rgb8 = nullptr;
     bool counters = false;
@@ -401,6 +424,7 @@ int hr_create(int device_id, hr_ctx **out) {
     }
     HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(Counters)));
     HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
+    HIP_TRY(hipMalloc((void **)&c->d_tile_counter, 2 * sizeof(uint32_t)));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_isaac64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
     *out = c;
@@ -422,6 +446,7 @@ int hr_destroy(hr_ctx *c) {
         if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
     }
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->post_tmp) (void)hipFree(c->post_tmp);
     if (c->d_rgb8) (void)hipFree(c->d_rgb8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -577,11 +602,13 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventCreate(&ev.a));
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, c->stream));
-        uint32_t groups = (tiles + TRACE_WAVES - 1) / TRACE_WAVES;
-        uint32_t grid = groups;
+        // persistent waves: enough workgroups to fill every CU (6 per CU covers every occupancy variant), never more
+        // waves than tiles
+        uint32_t grid = std::min<uint32_t>((uint32_t)c->num_cus * 6u, (tiles + TRACE_WAVES - 1) / TRACE_WAVES);
+        HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
-#define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot], c->accum, c->d_counters)
+#define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
             if (c->counters) HR_LAUNCH_TRACE(true, 3);
             else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4);
             else if (c->min_waves == 5) HR_LAUNCH_TRACE(false, 5);
@@ -676,6 +703,8 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow;
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
+    out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
+    out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
     out->bvh_nodes = c->st_nodes; out->triangles = c->st_tris; out->spheres = c->st_spheres; out->cuboids = c->st_cuboids;
     return HR_OK;
 }

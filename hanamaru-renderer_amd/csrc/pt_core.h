@@ -358,6 +358,7 @@ HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3
 // the path state machine
 struct Path {
     uint32_t q;           // path slot inside the tile batch, 0xffffffff = lane idle
+    uint32_t tile;        // the 4x4-pixel tile the path belongs to (a wave works on several tiles over its life)
     uint32_t draw_base;   // index of raw draw 0 of this path in the tile's tail buffer (stride 64 between draws)
     uint32_t lens_a;      // accepted lens attempt: the path's draws start at 2 * lens_a
     int32_t iter;         // 1..9 (renderer.rs:174)

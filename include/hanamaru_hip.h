@@ -117,6 +117,8 @@ typedef struct hr_stats {
     double post_kernel_ms;
     uint64_t seed_launches, trace_launches;
     uint64_t bvh_nodes, triangles, spheres, cuboids;
+    /* counters build only: wave-level phase statistics of the trace kernel (invocations, lanes served) */
+    uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;
