@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--split-ratio", type=float, default=0.0)
+    ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -85,6 +86,8 @@ def main():
         r.set_option("leaf_den", args.leaf_den)
     if args.min_waves:
         r.set_option("min_waves", args.min_waves)
+    if args.seed_mode >= 0:
+        r.set_option("seed_mode", args.seed_mode)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
     paths_per_step_gpu = W * H * 4 * SPS
@@ -152,7 +155,8 @@ def main():
         paths_per_launch = st["paths"] / launches if st["paths"] else W * H * 4 * min(args.batch, SPS)
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
-                "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4)}
+                "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
+                "init_kernel_avg_ms": round(st["init_kernel_ms"] / max(1, st["init_launches"]), 4) if st["init_launches"] else None}
         if bytes_per_path is not None and avg_ms > 0:
             gbs = bytes_per_path * paths_per_launch / (avg_ms * 1e-3) / 1e9
             roof.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_path": round(bytes_per_path, 1),

@@ -111,6 +111,78 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
     }
 }
 
+// ---- split seeding (option seed_mode = 1) -------------------------------------------------------------------
+// seed_init_kernel: the two ISAAC-64 init passes, scratch-free (isaac_init_final), one lane per path at full
+// occupancy, result (2 KiB per path) streamed to `minit` as [item][i][64 lanes] u64.
+// seed_round_kernel: the LDS-bound part only — load 80 states into the LDS columns, one round, lens loop, tails.
+// The LDS holds a generator for ~half as long as in the fused kernel, at the price of 4 KiB of HBM traffic per path.
+// `minit` layout = the LDS image of the round kernel: [group of SEED_COLS paths][i = 0..255][column] u64, 160 KiB per
+// group, so the round kernel fills its LDS with a straight linear copy (global_load_lds, no VGPR round trip).
+struct GlobalState {
+    u64 *col;  // &minit[group][0][column]
+    __device__ __forceinline__ void st(int i, u64 v) { __builtin_nontemporal_store(v, col + i * SEED_COLS); }
+};
+__global__ __launch_bounds__(256) void seed_init_kernel(RenderParams rp, u64 *__restrict__ minit) {
+    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t pid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (pid >= paths) return;
+    const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
+    uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+    uint32_t px, py, sub;
+    tile_lane_pixel(rp, tile, j, px, py, sub);
+    if (px >= rp.width || py >= rp.height) return;
+    u64 s, t;
+    path_seed_words(rp.width, rp.height, px, py, sub, s, t);
+    const IsaacWarm warm = isaac_warm();
+    const uint64_t group = pid / SEED_COLS;
+    const uint32_t column = (uint32_t)(pid - group * SEED_COLS);
+    GlobalState out{minit + (size_t)group * 256 * SEED_COLS + column};
+    isaac_init_final(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+}
+
+__global__ __launch_bounds__(64 * SEED_WAVES) void seed_round_kernel(RenderParams rp, int lens_shape, const u64 *__restrict__ minit,
+                                                                    u64 *__restrict__ tails, uint32_t *__restrict__ lens, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64 *mem = reinterpret_cast<u64 *>(smem);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool worker = lane < (uint32_t)SEED_LANES;       // 40 lanes per wave own a generator column
+    const uint32_t col = wave * SEED_LANES + (worker ? lane : 0u);
+    __builtin_amdgcn_s_setprio(3);
+    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t groups = (paths + SEED_COLS - 1) / SEED_COLS;
+    constexpr int CHUNKS = (int)(SEED_LDS_BYTES / 1024) / SEED_WAVES;   // 1 KiB per wave-instruction, 80 per wave
+    for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        __syncthreads();   // both waves are done with the previous group's columns
+        // ---- linear copy of the group's 160 KiB state image into the LDS, all 64 lanes of both waves, asynchronous
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(minit + (size_t)g * 256 * SEED_COLS);
+#pragma unroll 8
+        for (int q = 0; q < CHUNKS; q++) {
+            const uint32_t off = (uint32_t)((wave * CHUNKS + q) * 1024);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + off + lane * 16u),
+                                             (void __attribute__((address_space(3))) *)(smem + off), 16, 0, 2 /* nt */);
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the wave's own pieces have landed
+        __syncthreads();
+        if (worker) {
+            const uint64_t pid = g * SEED_COLS + col;
+            const bool in_range = pid < paths;
+            const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
+            uint32_t tile = item / rp.num_k;
+            uint32_t px, py, sub;
+            tile_lane_pixel(rp, tile, j, px, py, sub);
+            bool valid = in_range && px < rp.width && py < rp.height;
+            LdsMem m{mem + col};
+            GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
+            RawLensTail<GlobalTail> lt(gt, lens_shape);
+            isaac_round(m, lt);
+            lt.lens_slow();
+            bool ok = lt.in_window();
+            if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
+            if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+        }
+    }
+}
+
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
 struct RawTail {
     u64 *out; int window;
@@ -333,6 +405,16 @@ struct hr_ctx {
     uint32_t W = 0, H = 0;
     float *accum_own = nullptr, *accum = nullptr;
     u64 *tails[2] = {nullptr, nullptr};
+    u64 *minit[2] = {nullptr, nullptr};   // split seeding: initialised generator states, 2 KiB per path
+    size_t minit_cap = 0;                 // items per buffer
+    hipStream_t init_stream = nullptr;
+    hipEvent_t init_done[2] = {nullptr, nullptr};
+    bool seed_pending[2] = {false, false};
+    int seed_mode = 0;                    // 0 = fused seed kernel, 1 = init kernel + round kernel
+    uint64_t max_state_bytes = 40ull << 30;  // per minit buffer
+    std::vector<EventPair> init_events;
+    double init_ms = 0;
+    uint64_t init_launches = 0;
     uint32_t *lens[2] = {nullptr, nullptr};
     size_t draws_cap = 0;  // items (tile x sampling) per buffer
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
@@ -388,12 +470,15 @@ static int drain_events(hr_ctx *c) {
     HIP_TRY(sum(c->seed_events, c->seed_ms));
     HIP_TRY(sum(c->trace_events, c->trace_ms));
     HIP_TRY(sum(c->post_events, c->post_ms));
+    HIP_TRY(sum(c->init_events, c->init_ms));
     return HR_OK;
 }
 static int sync_all(hr_ctx *c) {
+    HIP_TRY(hipStreamSynchronize(c->init_stream));
     HIP_TRY(hipStreamSynchronize(c->seed_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->trace_pending[0] = c->trace_pending[1] = false;
+    c->seed_pending[0] = c->seed_pending[1] = false;
     return drain_events(c);
 }
 
@@ -417,15 +502,18 @@ int hr_create(int device_id, hr_ctx **out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->seed_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->init_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipEventCreateWithFlags(&c->seed_done[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->trace_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->init_done[i], hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(Counters)));
     HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
     HIP_TRY(hipMalloc((void **)&c->d_tile_counter, 2 * sizeof(uint32_t)));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_isaac64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
     *out = c;
     return HR_OK;
@@ -436,12 +524,14 @@ int hr_destroy(hr_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     free_scene(c);
-    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events})
+    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events, &c->init_events})
         for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (int i = 0; i < 2; i++) {
         if (c->tails[i]) (void)hipFree(c->tails[i]);
         if (c->lens[i]) (void)hipFree(c->lens[i]);
+        if (c->minit[i]) (void)hipFree(c->minit[i]);
+        if (c->init_done[i]) (void)hipEventDestroy(c->init_done[i]);
         if (c->seed_done[i]) (void)hipEventDestroy(c->seed_done[i]);
         if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
     }
@@ -451,6 +541,7 @@ int hr_destroy(hr_ctx *c) {
     if (c->d_rgb8) (void)hipFree(c->d_rgb8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->seed_stream) (void)hipStreamDestroy(c->seed_stream);
+    if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c;
     return HR_OK;
 }
@@ -530,8 +621,8 @@ int hr_clear(hr_ctx *c) {
     HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->seed_ms = c->trace_ms = c->post_ms = 0;
-    c->seed_launches = c->trace_launches = 0;
+    c->seed_ms = c->trace_ms = c->post_ms = c->init_ms = 0;
+    c->seed_launches = c->trace_launches = c->init_launches = 0;
     c->paths_rendered = 0;
     return HR_OK;
 }
@@ -548,6 +639,17 @@ static int ensure_draws(hr_ctx *c, size_t items) {
     return HR_OK;
 }
 
+static int ensure_states(hr_ctx *c, size_t items) {
+    if (items <= c->minit_cap) return HR_OK;
+    for (int i = 0; i < 2; i++) {
+        if (c->minit[i]) { HIP_TRY(hipFree(c->minit[i])); c->minit[i] = nullptr; }
+        // items * 64 paths, rounded up to whole groups of SEED_COLS, 2 KiB each
+        HIP_TRY(hipMalloc((void **)&c->minit[i], ((items * 64 + SEED_COLS - 1) / SEED_COLS) * SEED_COLS * 256 * sizeof(u64)));
+    }
+    c->minit_cap = items;
+    return HR_OK;
+}
+
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
@@ -555,8 +657,12 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
-    hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot], c->lens[slot],
-                       c->d_counters);
+    if (c->seed_mode == 1)
+        hipLaunchKernelGGL(seed_round_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->minit[slot],
+                           c->tails[slot], c->lens[slot], c->d_counters);
+    else
+        hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot],
+                           c->lens[slot], c->d_counters);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, st));
     c->seed_events.push_back(ev);
@@ -584,9 +690,14 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         uint64_t per_sampling = (uint64_t)tiles * ISAAC_TAIL * 64 * sizeof(u64);
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
         batch = (uint32_t)std::min<uint64_t>(batch, fit);
+        if (c->seed_mode == 1) {
+            uint64_t fit2 = std::max<uint64_t>(1, c->max_state_bytes / std::max<uint64_t>(1, per_sampling * 4));  // 128 KiB per item
+            batch = (uint32_t)std::min<uint64_t>(batch, fit2);
+        }
     }
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
+    if (c->seed_mode == 1 && (rc = ensure_states(c, (size_t)tiles * batch))) return rc;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
         rp.sampling_begin = s_begin + done * stride;
@@ -594,9 +705,26 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         int slot = (int)(c->batch_counter & 1);
         c->batch_counter++;
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
+        if (c->seed_mode == 1) {
+            // init kernel of this batch: its state buffer was last read by the round kernel two batches ago
+            if (c->seed_pending[slot]) HIP_TRY(hipStreamWaitEvent(c->init_stream, c->seed_done[slot], 0));
+            uint64_t paths = (uint64_t)tiles * nk * 64u;
+            EventPair iev;
+            HIP_TRY(hipEventCreate(&iev.a));
+            HIP_TRY(hipEventCreate(&iev.b));
+            HIP_TRY(hipEventRecord(iev.a, c->init_stream));
+            hipLaunchKernelGGL(seed_init_kernel, dim3((uint32_t)((paths + 255) / 256)), dim3(256), 0, c->init_stream, rp, c->minit[slot]);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(iev.b, c->init_stream));
+            c->init_events.push_back(iev);
+            c->init_launches++;
+            HIP_TRY(hipEventRecord(c->init_done[slot], c->init_stream));
+            HIP_TRY(hipStreamWaitEvent(c->seed_stream, c->init_done[slot], 0));
+        }
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(c->seed_stream, c->trace_done[slot], 0));
         if ((rc = launch_seed(c, rp, slot, c->seed_stream))) return rc;
         HIP_TRY(hipEventRecord(c->seed_done[slot], c->seed_stream));
+        c->seed_pending[slot] = true;
         HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
         EventPair ev;
         HIP_TRY(hipEventCreate(&ev.a));
@@ -703,6 +831,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow;
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
+    out->init_kernel_ms = c->init_ms; out->init_launches = c->init_launches;
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
     out->bvh_nodes = c->st_nodes; out->triangles = c->st_tris; out->spheres = c->st_spheres; out->cuboids = c->st_cuboids;
@@ -733,6 +862,13 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "max_tail_gib") {
         if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
         c->max_tail_bytes = (uint64_t)value << 30;
+        return HR_OK;
+    }
+    if (k == "seed_mode") {
+        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "seed_mode must be 0 (fused) or 1 (init + round kernels)");
+        int rc = sync_all(c);
+        if (rc) return rc;
+        c->seed_mode = (int)value;
         return HR_OK;
     }
     if (k == "split_ratio") {  // early split clipping of triangle references (0 = off), next hr_upload_scene

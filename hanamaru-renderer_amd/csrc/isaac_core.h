@@ -47,7 +47,31 @@ HD double isaac_to_f64(u64 v) {
     return cv.d - 1.0;
 }
 
+// The two init passes of `Isaac64Rng::init(true)` WITHOUT a 2 KiB scratch array: pass 2 needs the end state of
+// pass 1 before it can start, so pass 1 is run once "dry" (registers only) and then regenerated block by block
+// next to pass 2.  96 mixes instead of 64, but no LDS: this is what lets the init run at full occupancy in its own
+// kernel while the LDS-bound round kernel only has to load the result.  Out: void st(int i, u64 v), i = 0..255.
+template <class Out>
+HD void isaac_init_final(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3) {
+    u64 a = w.r[0] + s0, b = w.r[1] + s1, c = w.r[2] + s2, d = w.r[3] + s3, e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
+    HR_NOUNROLL
+    for (int i = 0; i < 32; i++) { HR_ISAAC_MIX(a, b, c, d, e, f, g, h) }
+    u64 A = a, B = b, C = c, D = d, E = e, F = f, G = g, H = h;   // pass 2 continues from here
+    a = w.r[0] + s0; b = w.r[1] + s1; c = w.r[2] + s2; d = w.r[3] + s3; e = w.r[4]; f = w.r[5]; g = w.r[6]; h = w.r[7];
+    HR_NOUNROLL
+    for (int i = 0; i < 256; i += 8) {
+        HR_ISAAC_MIX(a, b, c, d, e, f, g, h)                       // pass-1 block: what rsl-pass stored in mem[i..i+8)
+        A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
+        HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
+        out.st(i, A); out.st(i + 1, B); out.st(i + 2, C); out.st(i + 3, D);
+        out.st(i + 4, E); out.st(i + 5, F); out.st(i + 6, G); out.st(i + 7, H);
+    }
+}
+
 // Mem: u64 ld(int i) / void st(int i, u64 v).  Tail: void put(int step, u64 value) for step >= 256 - ISAAC_TAIL.
+template <class Mem, class Tail>
+HD void isaac_round(Mem &mem, Tail &tail);
+
 template <class Mem, class Tail>
 HD void isaac_seed_round(Mem &mem, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3, Tail &tail) {
     u64 a = w.r[0], b = w.r[1], c = w.r[2], d = w.r[3], e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
@@ -68,6 +92,11 @@ HD void isaac_seed_round(Mem &mem, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u
         mem.st(i, a); mem.st(i + 1, b); mem.st(i + 2, c); mem.st(i + 3, d);
         mem.st(i + 4, e); mem.st(i + 5, f); mem.st(i + 6, g); mem.st(i + 7, h);
     }
+    isaac_round(mem, tail);
+}
+
+template <class Mem, class Tail>
+HD void isaac_round(Mem &mem, Tail &tail) {
     // one isaac64() round: a = b = 0, c = 1  ->  aa = 0, bb = 1.
     // Step n (0..255) reads x = mem[n] and mem[(n+128)&255], gathers mem[(x>>3)&255], stores y to mem[n],
     // gathers mem[(y>>11)&255].  The only serial chain is bb -> y -> second gather -> bb; everything else

@@ -77,7 +77,8 @@ class Stats(C.Structure):
                 ("seed_launches", C.c_uint64), ("trace_launches", C.c_uint64),
                 ("bvh_nodes", C.c_uint64), ("triangles", C.c_uint64), ("spheres", C.c_uint64), ("cuboids", C.c_uint64),
                 ("shade_calls", C.c_uint64), ("shade_lanes", C.c_uint64), ("box_passes", C.c_uint64), ("box_lanes", C.c_uint64),
-                ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64)]
+                ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64),
+                ("init_kernel_ms", C.c_double), ("init_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -119,6 +119,8 @@ typedef struct hr_stats {
     uint64_t bvh_nodes, triangles, spheres, cuboids;
     /* counters build only: wave-level phase statistics of the trace kernel (invocations, lanes served) */
     uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
+    double init_kernel_ms;     /* split seeding (option seed_mode = 1): the init kernel */
+    uint64_t init_launches;
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;

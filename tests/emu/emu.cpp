@@ -86,6 +86,19 @@ int emu_raw_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub
     return 0;
 }
 
+// same as emu_raw_draws, through the split path (isaac_init_final into a staging array, then isaac_round)
+int emu_raw_draws_split(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int window, uint64_t *out) {
+    static const IsaacWarm warm = isaac_warm();
+    ArrMem stage, mem;
+    u64 s, t;
+    path_seed_words(W, H, px, py, sub, s, t);
+    isaac_init_final(stage, warm, 8700304ULL, (u64)sampling, s, t);
+    for (int i = 0; i < 256; i++) mem.st(i, stage.ld(i));
+    RawTail rt{out, window};
+    isaac_round(mem, rt);
+    return 0;
+}
+
 // counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests
 int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc,
                uint64_t *counters) {

@@ -282,3 +282,21 @@ def test_cli_checkpoint_resume_and_debug(tmp_path):
     assert "sampled: 1x4 spp." in out
     img = np.asarray(Image.open(dd / "result.png"))
     assert img.shape == (36, 64, 3) and img.std() > 5
+
+
+def test_split_seeding_is_bit_identical(gpu, scenes):
+    """seed_mode 1 (scratch-free init kernel + LDS round kernel) must hand the trace kernel exactly the draws of
+    seed_mode 0 (fused kernel): same raw tails -> the accumulators agree up to the atomics' fp32 summation order."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(130, 71)        # ragged: tiles hang over the right and bottom edges
+    import ctypes as C
+    outs = []
+    for mode in (0, 1):
+        gpu.set_option("seed_mode", mode)
+        gpu.clear()
+        gpu.render(1, 6)
+        outs.append(gpu.read_accumulator().astype(np.float64))
+    gpu.set_option("seed_mode", 0)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max())
+    assert outs[0].sum() > 0

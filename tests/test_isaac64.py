@@ -63,7 +63,10 @@ def test_kernel_generator_core_matches_oracle(emu, orc):
     for w, h in [(480, 270), (1920, 1080), (7, 5)]:
         for _ in range(12):
             x, y, sub, s = int(rng.integers(w)), int(rng.integers(h)), int(rng.integers(4)), int(rng.integers(1, 5000))
-            assert np.array_equal(emu.raw_draws(w, h, x, y, sub, s, 64), orc.path_draws(w, h, x, y, sub & 1, sub >> 1, s, 64))
+            ref = orc.path_draws(w, h, x, y, sub & 1, sub >> 1, s, 64)
+            assert np.array_equal(emu.raw_draws(w, h, x, y, sub, s, 64), ref)
+            # split form: scratch-free init (pass 1 regenerated next to pass 2) + round on the loaded state
+            assert np.array_equal(emu.raw_draws_split(w, h, x, y, sub, s, 64), ref)
 
 
 def test_kernel_lens_rejection_matches_oracle(emu, orc):
