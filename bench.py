@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--split-ratio", type=float, default=0.0)
     ap.add_argument("--seed-mode", type=int, default=-1)
+    ap.add_argument("--init-wgs", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -62,13 +63,26 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # HR_BENCH_ONE_DEVICE=1 is a debugging aid for boxes with a single GPU: every rank uses cuda:0 and the
+    # collective runs over gloo on a host copy (RCCL refuses two ranks on one device).  Never set by the driver.
+    one_device = os.environ.get("HR_BENCH_ONE_DEVICE") == "1"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if one_device else "nccl", rank=rank, world_size=world)
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    def all_reduce_(t, op):
+        if one_device:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     W, H, SPS = args.width, args.height, args.spp_per_step
     scene = ha.Scene(args.scene)
@@ -88,6 +102,8 @@ def main():
         r.set_option("min_waves", args.min_waves)
     if args.seed_mode >= 0:
         r.set_option("seed_mode", args.seed_mode)
+    if args.init_wgs:
+        r.set_option("init_wgs_per_cu", args.init_wgs)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
     paths_per_step_gpu = W * H * 4 * SPS
@@ -125,16 +141,18 @@ def main():
         run_step(i)
     r.synchronize()
     if dist is not None:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        all_reduce_(acc, dist.ReduceOp.SUM)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = r.stats()
 
+    if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0:
+        sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % float(acc.mean().item()))
     if rank == 0:
         total_paths = paths_per_step_gpu * world * args.steps
         value = total_paths / elapsed / 1e6

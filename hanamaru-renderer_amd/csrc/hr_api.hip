@@ -123,21 +123,23 @@ struct GlobalState {
     __device__ __forceinline__ void st(int i, u64 v) { __builtin_nontemporal_store(v, col + i * SEED_COLS); }
 };
 __global__ __launch_bounds__(256) void seed_init_kernel(RenderParams rp, u64 *__restrict__ minit) {
+    // persistent, grid-stride: the launch decides how many waves trickle the states out (it only has to keep ahead
+    // of the round kernel; flooding the chip with init waves takes issue slots from the trace kernel)
     const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
-    const uint64_t pid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (pid >= paths) return;
-    const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
-    uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
-    uint32_t px, py, sub;
-    tile_lane_pixel(rp, tile, j, px, py, sub);
-    if (px >= rp.width || py >= rp.height) return;
-    u64 s, t;
-    path_seed_words(rp.width, rp.height, px, py, sub, s, t);
     const IsaacWarm warm = isaac_warm();
-    const uint64_t group = pid / SEED_COLS;
-    const uint32_t column = (uint32_t)(pid - group * SEED_COLS);
-    GlobalState out{minit + (size_t)group * 256 * SEED_COLS + column};
-    isaac_init_final(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+    for (uint64_t pid = (uint64_t)blockIdx.x * 256u + threadIdx.x; pid < paths; pid += (uint64_t)gridDim.x * 256u) {
+        const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
+        uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        if (px >= rp.width || py >= rp.height) continue;
+        u64 s, t;
+        path_seed_words(rp.width, rp.height, px, py, sub, s, t);
+        const uint64_t group = pid / SEED_COLS;
+        const uint32_t column = (uint32_t)(pid - group * SEED_COLS);
+        GlobalState out{minit + (size_t)group * 256 * SEED_COLS + column};
+        isaac_init_final(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+    }
 }
 
 __global__ __launch_bounds__(64 * SEED_WAVES) void seed_round_kernel(RenderParams rp, int lens_shape, const u64 *__restrict__ minit,
@@ -411,6 +413,7 @@ struct hr_ctx {
     hipEvent_t init_done[2] = {nullptr, nullptr};
     bool seed_pending[2] = {false, false};
     int seed_mode = 0;                    // 0 = fused seed kernel, 1 = init kernel + round kernel
+    uint32_t init_wgs_per_cu = 1;         // split seeding: resident 256-thread workgroups of the init kernel per CU
     uint64_t max_state_bytes = 40ull << 30;  // per minit buffer
     std::vector<EventPair> init_events;
     double init_ms = 0;
@@ -713,7 +716,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
             HIP_TRY(hipEventCreate(&iev.a));
             HIP_TRY(hipEventCreate(&iev.b));
             HIP_TRY(hipEventRecord(iev.a, c->init_stream));
-            hipLaunchKernelGGL(seed_init_kernel, dim3((uint32_t)((paths + 255) / 256)), dim3(256), 0, c->init_stream, rp, c->minit[slot]);
+            uint32_t igrid = (uint32_t)std::min<uint64_t>((paths + 255) / 256, (uint64_t)c->num_cus * c->init_wgs_per_cu);
+            hipLaunchKernelGGL(seed_init_kernel, dim3(igrid), dim3(256), 0, c->init_stream, rp, c->minit[slot]);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(iev.b, c->init_stream));
             c->init_events.push_back(iev);
@@ -862,6 +866,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "max_tail_gib") {
         if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
         c->max_tail_bytes = (uint64_t)value << 30;
+        return HR_OK;
+    }
+    if (k == "init_wgs_per_cu") {
+        if (value < 1 || value > 8) return fail(HR_ERR_INVALID, "init_wgs_per_cu must be in [1,8]");
+        c->init_wgs_per_cu = (uint32_t)value;
         return HR_OK;
     }
     if (k == "seed_mode") {

@@ -300,3 +300,30 @@ def test_split_seeding_is_bit_identical(gpu, scenes):
     gpu.set_option("seed_mode", 0)
     assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max())
     assert outs[0].sum() > 0
+
+
+def test_bench_multirank_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path (sharding by sampling index, accumulate into a torch tensor, one all-reduce) run as two
+    ranks on ONE GPU (HR_BENCH_ONE_DEVICE: gloo on a host copy, RCCL refuses two ranks per device): the summed accumulator
+    must equal a single-rank run over the same sampling indices."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--warmup", "0", "--spp-per-step", "2", "--width", "160", "--height", "90", "--no-cpu-baseline", "--no-counters"]
+    env = dict(os.environ, HR_BENCH_CHECKSUM="1")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4"] + common, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env2 = dict(env, HR_BENCH_ONE_DEVICE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"] + common, env=env2,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    m1 = float(re.search(r"accumulator mean after all-reduce: ([0-9.eE+-]+)", one.stderr).group(1))
+    m2 = float(re.search(r"accumulator mean after all-reduce: ([0-9.eE+-]+)", two.stderr).group(1))
+    assert abs(m1 - m2) <= 1e-6 * m1
+    j = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "roofline" in j
