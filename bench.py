@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload): the reference's live scene `rtcamp6_v3_1` at 1920x1080.  One STEP = one
-hr_render() batch of `--spp-per-step` samplings (default 16) of the whole image on every GPU = 16 x 1920 x 1080
-x 4 camera paths per GPU.  The default K = 64 steps is exactly BASELINE's 1920x1080 x 1024 samplings on one GPU.
+hr_render() call of `--spp-per-step` samplings (default 16, launched 4 at a time) of the whole image on every GPU
+= 16 x 1920 x 1080 x 4 camera paths per GPU.  The default K = 64 steps is exactly BASELINE's 1920x1080 x 1024 samplings on one GPU.
 With N GPUs the sampling indices are sharded round-robin ((s-1) mod N == rank, one process per GPU), every
 GPU still renders `spp-per-step` samplings per step (weak scaling), and the fp32 radiance accumulators are
 summed with ONE all-reduce (RCCL) inside the timed region.  Inputs (scene, textures) are resident in HBM

@@ -33,7 +33,6 @@ struct alignas(16) Node {
 HD bool node_word_is_leaf(uint32_t a) { return (a >> 28) != 0u && a != 0xffffffffu; }
 static const uint32_t NODE_END = 0xffffffffu;
 
-struct alignas(8) Link { uint32_t hit, miss; };
 
 struct alignas(16) Tri {
     float v0[3]; float e1x;

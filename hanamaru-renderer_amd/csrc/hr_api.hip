@@ -1,13 +1,15 @@
 // hr_api.hip — HIP kernels (gfx950) and the C ABI of include/hanamaru_hip.h.
 //
 // Kernels
-//   seed_isaac64_kernel   one lane = one path's ISAAC-64 generator, state in an LDS bank column
-//                         (64 lanes x 2 KiB = 128 KiB + 16 KiB fp32 tail per workgroup, 1 workgroup / CU),
-//                         resolves the lens rejection loop in f64 and emits 20 fp32 draws per path.
-//   trace_kernel          the path-tracing megakernel: one wave per 4x4-pixel tile, one lane per path,
-//                         stackless threaded-BVH traversal, finished lanes are refilled from the tile's
-//                         path queue with ballot / mbcnt prefix ranks; LDS-free except 192 B of tile sums,
-//                         so it co-resides with the LDS-hungry seed kernel of the NEXT batch.
+//   seed_isaac64_kernel   one lane = one path's ISAAC-64 generator, state in an LDS column: 80 columns x 2 KiB =
+//                         all 160 KiB of a CU's LDS, one workgroup (2 waves x 40 lanes) per CU; decides the lens
+//                         rejection loop in f64 and stores the last 64 raw outputs of every path (`tails`).
+//   trace_kernel          the path-tracing megakernel: persistent waves pull 4x4-pixel tiles from a global counter,
+//                         one lane per path, stackless threaded-BVH traversal in box / leaf phases, finished lanes
+//                         are refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed
+//                         kernel of the NEXT batch (own stream).
+//   seed_init_kernel + seed_round_kernel   optional split form of the seeding (seed_mode = 1), see DESIGN.md.
+//   debug_render_kernel   DebugRenderer modes (renderer.rs:101-146).
 //   tonemap_gamma_kernel, bilateral_quantise_kernel   the post chain.
 #include <hip/hip_runtime.h>
 

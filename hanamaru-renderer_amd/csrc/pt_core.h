@@ -49,7 +49,6 @@ HD V3f normalize(V3f a) { return a * HR_RSQ(dot(a, a)); }
 HD V3f reflect(V3f v, V3f n) { return v - (2.0f * dot(v, n)) * n; }  // vector.rs:60-62
 HD bool is_zero(V3f a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 HD float saturatef(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
-HD bool sign_neg(float v) { return signbit(v); }
 
 static const float PI_F = 3.14159265358979323846f;
 static const float PI2_F = 6.28318530717958647692f;

@@ -190,6 +190,13 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
+    for key, bad in [("batch", 0), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("rng_window", 32)]:
+        with pytest.raises(ha.HipError):
+            r.set_option(key, bad)
+    with pytest.raises(ha.HipError):
+        r.render_debug(7)
+    with pytest.raises(ha.HipError):
+        r.debug_draws(1, 0, 4, 65)       # window larger than the stored tail
     r.close()
 
 
