@@ -334,3 +334,35 @@ def test_bench_multirank_path_on_one_gpu(tmp_path):
     assert abs(m1 - m2) <= 1e-6 * m1
     j = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "roofline" in j
+
+
+def test_4k_and_sphere_scene_properties(gpu, scenes):
+    """BASELINE configs 5 and 2 at their full sizes, size-independent properties only (the oracle needs minutes there):
+    exact path counts, no RNG-window overflow, finite non-negative radiance, the hand-off buffer cap shrinking the batch
+    at 4K, and image means that agree with a low-resolution oracle render of the same scene."""
+    sc, o = scenes("rtcamp6_dodeca")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(3840, 2160)
+    gpu.set_option("counters", 1)
+    gpu.set_option("batch", 4)
+    gpu.clear()
+    gpu.render(1, 3)
+    acc = gpu.read_accumulator()
+    st = gpu.stats()
+    assert st["paths"] == 3840 * 2160 * 4 * 2 and st["rng_overflow"] == 0
+    assert st["trace_launches"] == 2                     # 4K: one sampling per launch (20 GiB cap on the raw-draw buffers)
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    ref, _ = o.render(192, 108, 1, 3, threads=0)
+    assert abs(acc.mean() - ref.mean()) < 0.05 * ref.mean()
+    sc2, o2 = scenes("spheres")
+    gpu.upload_scene(sc2)
+    gpu.set_resolution(1920, 1080)
+    gpu.clear()
+    gpu.render(1, 5)
+    acc = gpu.read_accumulator()
+    st = gpu.stats()
+    gpu.set_option("counters", 0)
+    assert st["paths"] == 1920 * 1080 * 4 * 4 and st["rng_overflow"] == 0 and st["tri_tests"] == 0 and st["sphere_tests"] > 0
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    ref2, _ = o2.render(240, 135, 1, 5, threads=0)
+    assert abs(acc.mean() - ref2.mean()) < 0.05 * ref2.mean()
