@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--split-ratio", type=float, default=0.0)
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--init-wgs", type=int, default=0)
+    ap.add_argument("--seed-prio", type=int, default=-1)
+    ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -104,6 +106,8 @@ def main():
         r.set_option("seed_mode", args.seed_mode)
     if args.init_wgs:
         r.set_option("init_wgs_per_cu", args.init_wgs)
+    if args.seed_prio >= 0:
+        r.set_option("seed_prio", args.seed_prio)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
     paths_per_step_gpu = W * H * 4 * SPS
@@ -135,6 +139,8 @@ def main():
         run_step(i)
     r.synchronize()
     r.clear()
+    if args.debug_skip:
+        r.set_option("debug_skip", args.debug_skip)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

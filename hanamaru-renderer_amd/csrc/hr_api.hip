@@ -88,8 +88,13 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane >= (uint32_t)SEED_LANES) return;
     const uint32_t col = wave * SEED_LANES + lane;
-    // latency-bound waves next to the trace kernel's waves: always win issue arbitration
-    __builtin_amdgcn_s_setprio(3);
+    // latency-bound waves next to the trace kernel's waves: win issue arbitration (priority is a launch parameter)
+    switch (rp.pad[0]) {
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
     const IsaacWarm warm = isaac_warm();
     const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     for (uint64_t base = (uint64_t)blockIdx.x * SEED_COLS; base < paths; base += (uint64_t)gridDim.x * SEED_COLS) {
@@ -122,7 +127,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
 // group, so the round kernel fills its LDS with a straight linear copy (global_load_lds, no VGPR round trip).
 struct GlobalState {
     u64 *col;  // &minit[group][0][column]
-    __device__ __forceinline__ void st(int i, u64 v) { __builtin_nontemporal_store(v, col + i * SEED_COLS); }
+    // agent-scope relaxed store = `global_store_dwordx2 ... sc1`: written through, the line is not kept in the XCD's L2
+    // (MI355X_MICROARCH.md), so the 2 KiB-per-path stream does not evict the BVH the trace kernel lives on
+    __device__ __forceinline__ void st(int i, u64 v) { __hip_atomic_store(col + i * SEED_COLS, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
 __global__ __launch_bounds__(256) void seed_init_kernel(RenderParams rp, u64 *__restrict__ minit) {
     // persistent, grid-stride: the launch decides how many waves trickle the states out (it only has to keep ahead
@@ -151,7 +158,12 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_round_kernel(RenderParam
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool worker = lane < (uint32_t)SEED_LANES;       // 40 lanes per wave own a generator column
     const uint32_t col = wave * SEED_LANES + (worker ? lane : 0u);
-    __builtin_amdgcn_s_setprio(3);
+    switch (rp.pad[0]) {  // s_setprio takes an immediate
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
     const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     const uint64_t groups = (paths + SEED_COLS - 1) / SEED_COLS;
     constexpr int CHUNKS = (int)(SEED_LDS_BYTES / 1024) / SEED_WAVES;   // 1 KiB per wave-instruction, 80 per wave
@@ -415,7 +427,9 @@ struct hr_ctx {
     hipEvent_t init_done[2] = {nullptr, nullptr};
     bool seed_pending[2] = {false, false};
     int seed_mode = 0;                    // 0 = fused seed kernel, 1 = init kernel + round kernel
-    uint32_t init_wgs_per_cu = 1;         // split seeding: resident 256-thread workgroups of the init kernel per CU
+    uint32_t init_wgs_per_cu = 1;
+    uint32_t seed_prio = 3;               // s_setprio of the seed / round kernel's waves
+    int debug_skip = 0;                   // timing experiments only: 1 = skip the init kernel, 2 = skip the seed/round kernel (garbage image)         // split seeding: resident 256-thread workgroups of the init kernel per CU
     uint64_t max_state_bytes = 40ull << 30;  // per minit buffer
     std::vector<EventPair> init_events;
     double init_ms = 0;
@@ -662,7 +676,8 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
-    if (c->seed_mode == 1)
+    if (c->debug_skip & 2) {
+    } else if (c->seed_mode == 1)
         hipLaunchKernelGGL(seed_round_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->minit[slot],
                            c->tails[slot], c->lens[slot], c->d_counters);
     else
@@ -688,6 +703,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.stride = stride;
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
+    rp.pad[0] = c->seed_prio;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     // the raw-draw hand-off costs 32 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
     uint32_t batch = std::max<uint32_t>(1, c->batch);
@@ -709,6 +725,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         rp.num_k = nk;
         int slot = (int)(c->batch_counter & 1);
         c->batch_counter++;
+        hipStream_t sstream = c->seed_stream;  // (alternating two seed streams to overlap kernel tails was measured: no gain)
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
         if (c->seed_mode == 1) {
             // init kernel of this batch: its state buffer was last read by the round kernel two batches ago
@@ -719,17 +736,17 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
             HIP_TRY(hipEventCreate(&iev.b));
             HIP_TRY(hipEventRecord(iev.a, c->init_stream));
             uint32_t igrid = (uint32_t)std::min<uint64_t>((paths + 255) / 256, (uint64_t)c->num_cus * c->init_wgs_per_cu);
-            hipLaunchKernelGGL(seed_init_kernel, dim3(igrid), dim3(256), 0, c->init_stream, rp, c->minit[slot]);
+            if (!(c->debug_skip & 1)) hipLaunchKernelGGL(seed_init_kernel, dim3(igrid), dim3(256), 0, c->init_stream, rp, c->minit[slot]);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(iev.b, c->init_stream));
             c->init_events.push_back(iev);
             c->init_launches++;
             HIP_TRY(hipEventRecord(c->init_done[slot], c->init_stream));
-            HIP_TRY(hipStreamWaitEvent(c->seed_stream, c->init_done[slot], 0));
+            HIP_TRY(hipStreamWaitEvent(sstream, c->init_done[slot], 0));
         }
-        if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(c->seed_stream, c->trace_done[slot], 0));
-        if ((rc = launch_seed(c, rp, slot, c->seed_stream))) return rc;
-        HIP_TRY(hipEventRecord(c->seed_done[slot], c->seed_stream));
+        if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(sstream, c->trace_done[slot], 0));
+        if ((rc = launch_seed(c, rp, slot, sstream))) return rc;
+        HIP_TRY(hipEventRecord(c->seed_done[slot], sstream));
         c->seed_pending[slot] = true;
         HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
         EventPair ev;
@@ -870,6 +887,12 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->max_tail_bytes = (uint64_t)value << 30;
         return HR_OK;
     }
+    if (k == "seed_prio") {
+        if (value < 0 || value > 3) return fail(HR_ERR_INVALID, "seed_prio must be in [0,3]");
+        c->seed_prio = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
     if (k == "init_wgs_per_cu") {
         if (value < 1 || value > 8) return fail(HR_ERR_INVALID, "init_wgs_per_cu must be in [1,8]");
         c->init_wgs_per_cu = (uint32_t)value;
