@@ -192,9 +192,9 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         s.n = normalize(s.pos - v3(sp.x, sp.y, sp.z));
         s.elem = sc.sphere_elem[ts.prim];
         if (want_uv) {  // scene.rs:67-71
-            s.v = 1.0f - acosf(s.n.y) * (1.0f / PI_F);
+            s.v = 1.0f - acosf(fminf(fmaxf(s.n.y, -1.0f), 1.0f)) * (1.0f / PI_F);
             float sg = signbit(s.n.z) ? -1.0f : 1.0f;
-            s.u = 0.5f - sg * acosf(s.n.x * HR_RSQ(s.n.x * s.n.x + s.n.z * s.n.z)) * (1.0f / PI2_F);
+            s.u = 0.5f - sg * acosf(fminf(fmaxf(s.n.x * HR_RSQ(s.n.x * s.n.x + s.n.z * s.n.z), -1.0f), 1.0f)) * (1.0f / PI2_F);
         }
     } else {
         const f4 mn = sc.cuboids[2 * ts.prim], mx = sc.cuboids[2 * ts.prim + 1];
@@ -284,7 +284,7 @@ HD V3f sample_diffuse(float r0, float r1, V3f n) {  // material.rs:227-248
     tangent_basis(n, t, b);
     float sn, cs;
     HR_SINCOS_2PI(r0, sn, cs);
-    return (t * cs + b * sn) * HR_SQRT(r1) + n * HR_SQRT(1.0f - r1);
+    return (t * cs + b * sn) * HR_SQRT(r1) + n * HR_SQRT(fmaxf(1.0f - r1, 0.0f));
 }
 HD V3f sample_ggx_half(float r0, float r1, V3f n, float alpha2) {  // material.rs:260-269
     V3f t, b;
@@ -292,7 +292,7 @@ HD V3f sample_ggx_half(float r0, float r1, V3f n, float alpha2) {  // material.r
     float sn, cs;
     HR_SINCOS_2PI(r0, sn, cs);
     float cos_theta = HR_SQRT((1.0f - r1) * HR_RCP(1.0f + (alpha2 - 1.0f) * r1));
-    float sin_theta = HR_SQRT(1.0f - cos_theta * cos_theta);
+    float sin_theta = HR_SQRT(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));   // 1-ulp rcp/sqrt can push cos_theta past 1
     return t * (sin_theta * cs) + b * (sin_theta * sn) + n * cos_theta;
 }
 HD float smith_lambda(float xn, float alpha2) { float a = HR_RCP(xn * xn) - 1.0f; return 0.5f * HR_SQRT(1.0f + alpha2 * a) - 0.5f; }
@@ -397,7 +397,7 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
 HD void nee_setup(const Scene &sc, Path &p) {
     const Emitter em = sc.emitters[p.emitter];
     float unit_z = 1.0f - 2.0f * p.r1;
-    float a = HR_SQRT(1.0f - unit_z * unit_z);
+    float a = HR_SQRT(fmaxf(1.0f - unit_z * unit_z, 0.0f));
     float sn_, cs_;
     HR_SINCOS_2PI(p.r0, sn_, cs_);
     V3f sn = v3(a * cs_, a * sn_, unit_z);

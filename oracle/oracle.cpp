@@ -9,16 +9,16 @@
  * cannot be compiled into oracle/_ref.  This is a restatement of its algorithm, function by function,
  * each citing the reference file:line it follows (paths relative to /root/reference/src).
  *
- * PINNING STATUS (see DESIGN.md §Oracle):
- *   - the reference has NO tests, golden vectors or fixtures for this path, so there is
- *     nothing of the reference's own to pin against, and the reference binary cannot be run here:
- *     "parity unpinned" with respect to the Rust binary.
+ * PINNING STATUS (see DESIGN.md §6):
+ *   - the reference has no unit tests or fixtures for this path and cannot be built here, BUT its
+ *     repository commits one output of the real binary: rtcamp6_1000x4spp.png (default scene, 1920x1080, -s 1000,
+ *     README.md:19).  tests/test_oracle.py renders crops of exactly that configuration with this oracle and gets the
+ *     same 8-bit pixels (interior of every tested crop: identical).  That pins — against the Rust program itself —
+ *     the per-path seeding, the ISAAC-64 u64->f64 conversion, the scene, the texture decoders, the estimator and
+ *     the post chain.  PINNED.
  *   - the third-party RNG (rand 0.4.3 StdRng = ISAAC-64, a Cargo.lock dependency not vendored under
- *     /root/reference) IS pinned: tests/test_isaac64.py checks this restatement against rand's
- *     published known-answer vectors.  The u64->f64 conversion (B.3) is
- *     recalled, not pinned; flip ORC_F64_FROM_TOP53 to switch to the other known variant.
- *   - structural known-answers (BVH shapes, Appendix C.3; path statistics, Appendix D.2) are checked in
- *     tests/test_oracle.py.
+ *     /root/reference) is additionally pinned by rand's published known-answer vectors (tests/test_isaac64.py).
+ *   - structural known answers (BVH shapes; path statistics, Appendix D.2): tests/test_oracle.py.
  */
 #include <atomic>
 #include <algorithm>
@@ -875,6 +875,34 @@ ORC_API int orc_render(const orc_scene *os, uint32_t W, uint32_t H, uint32_t s_b
         for (auto &c : cns) add_counters(total, c);
         memcpy(counters_out, &total, sizeof total);
     }
+    return 0;
+}
+
+// Same as orc_render but only for the pixel rectangle [x0, x0+rw) x [y0, y0+rh) of a W x H image (seeds depend on the
+// full-image coordinates).  acc: rw*rh*3 doubles.  Lets the CPU tier compare a crop against the reference binary's
+// committed 1920x1080 x 1000-sampling render.
+ORC_API int orc_render_region(const orc_scene *os, uint32_t W, uint32_t H, uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh, uint32_t s_begin,
+                              uint32_t s_end, uint32_t stride, int nthreads, double *acc) {
+    if (!os || !acc || !W || !H || !stride || x0 + rw > W || y0 + rh > H) return -1;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    const Scene &s = os->s;
+    std::atomic<uint32_t> next{0};
+    const uint32_t total = rw * rh;
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= total) break;
+            uint32_t x = x0 + i % rw, y = y0 + i / rw;
+            V3 sum;
+            for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) sum = sum + supersampling(s, W, H, x, y, sampling, nullptr);
+            double *p = &acc[(size_t)i * 3];
+            p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto &t : th) t.join();
     return 0;
 }
 

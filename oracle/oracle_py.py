@@ -28,6 +28,7 @@ def lib():
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_counters_size.restype = C.c_size_t
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_render_region.argtypes = [C.c_void_p] + [C.c_uint32] * 9 + [C.c_int, C.c_void_p]
         L.orc_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_calc_pixel.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
         L.orc_path_draws.argtypes = [C.c_uint32] * 7 + [C.c_void_p, C.c_int]
@@ -83,6 +84,13 @@ class OracleScene:
             cd["rays_per_path_hist"] = vals[len(COUNTER_FIELDS):len(COUNTER_FIELDS) + 24]
             cd["draws_per_path_hist"] = vals[len(COUNTER_FIELDS) + 24:len(COUNTER_FIELDS) + 64]
         return acc, cd
+
+    def render_region(self, w, h, x0, y0, rw, rh, s_begin, s_end, stride=1, threads=0):
+        acc = np.zeros((rh, rw, 3), dtype=np.float64)
+        rc = lib().orc_render_region(self._h, w, h, x0, y0, rw, rh, s_begin, s_end, stride, threads, acc.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_render_region failed: %d" % rc)
+        return acc
 
     def render_debug(self, w, h, mode):
         acc = np.zeros((h, w, 3), dtype=np.float64)

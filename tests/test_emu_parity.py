@@ -68,6 +68,7 @@ def test_radiance_accumulator(emu_scenes, name, w, h, s):
     _, o, e = emu_scenes(name)
     acc, cn = e.render(w, h, 1, s + 1, threads=0)
     ref, rc = o.render(w, h, 1, s + 1, threads=0, counters=True)
+    assert np.isfinite(acc).all()
     rel = np.abs(acc.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
     assert (rel <= ATOL_REL).mean() >= FRAC_OK
     assert abs(acc.mean() - ref.mean()) <= 2e-3 * max(1.0, ref.mean())

@@ -179,3 +179,20 @@ def test_closest_hit_basics(scenes):
     assert out[1, 0] == 0 and el[1] == -1 and out[1, 1] == 1e100          # Intersection::empty distance (config.rs:9)
     assert out[2, 0] == 0 and el[2] == -1
     assert out[3, 0] == 1 and el[3] == 0 and out[3, 1] == pytest.approx(3.0) and np.allclose(out[3, 5:8], (0, 1, 0))
+
+
+@pytest.mark.parametrize("x0,y0", [(200, 100), (300, 930), (936, 562), (1300, 420)])
+def test_oracle_reproduces_the_reference_binarys_committed_render(scenes, orc, x0, y0):
+    """tests/golden/reference_rtcamp6_1000x4spp.png is the output of the REAL reference binary (committed in its repository,
+    README.md:19: default scene, 1920x1080, -s 1000).  The oracle renders small crops of that exact configuration (seeds
+    depend on full-image coordinates) and must reproduce the 8-bit image: this pins, against the Rust program itself, the
+    ISAAC-64 seeding and its u64->f64 conversion, the scene construction, the PNG/JPEG texture decoding (sky and floor
+    crops), the estimator and the whole post chain.  (Interior of the crop only: the 3x3 bilateral needs neighbours.)"""
+    from PIL import Image
+    ref = np.asarray(Image.open(os.path.join(GOLD, "reference_rtcamp6_1000x4spp.png")).convert("RGB")).astype(int)
+    _, o = scenes("rtcamp6_v3_1")
+    rw, rh = 12, 8
+    acc = o.render_region(1920, 1080, x0, y0, rw, rh, 1, 1001, threads=0)
+    img = orc.resolve(acc, 1000).astype(int)
+    d = np.abs(img[1:-1, 1:-1] - ref[y0 + 1:y0 + rh - 1, x0 + 1:x0 + rw - 1])
+    assert d.max() <= 1 and (d == 0).mean() >= 0.98, (d.max(), (d == 0).mean())
