@@ -213,6 +213,21 @@ static void build_rtcamp6_v3(Builder &b) {
     b.skybox("textures/cube/Powerlines", V3(1, 1, 1));
 }
 
+// main.rs:54-136: GGX floor with image albedo AND image roughness, two coloured NEE emitters,
+// aperture 0, skybox intensity 0 (so the cubemap's content is irrelevant — the build ships Powerlines, the
+// reference names LancellottiChapel)
+static void build_simple(Builder &b) {
+    hh_camera_new(V3(0.0, 2.0, 9.0).c(), V3(0.0, 1.0, 0.0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8, &b.sc->desc.camera);
+    double radius = 0.6;
+    b.add_sphere(V3(0.0, radius, 0.0), radius, mat(HR_DIFFUSE, 0, tex_one(1), tex_one(0), tex_one(0.99)));
+    b.add_sphere(V3(3.0, 2.0 + radius, -2.0), radius * 0.2, mat(HR_DIFFUSE, 0, tex_one(0), tex_color(V3(200.0, 10.0, 10.0)), tex_one(0.05)));
+    b.add_sphere(V3(-3.0, 2.0 + radius, -2.0), radius * 0.2, mat(HR_DIFFUSE, 0, tex_one(0), tex_color(V3(10.0, 200.0, 10.0)), tex_one(0.05)));
+    int albedo = b.add_image_file("textures/2d/checkered_diagonal_10_0.5_1.0_512.png");
+    int rough = b.add_image_file("textures/2d/checkered_diagonal_10_0.1_0.6_512.png");
+    b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_GGX, 0.8, tex_image(albedo), tex_one(0), tex_image(rough)));
+    b.skybox("textures/cube/Powerlines", V3(0, 0, 0));
+}
+
 // BASELINE config 2 (build-defined): sphere generator of main.rs:862-905
 static void build_spheres(Builder &b) {
     const uint64_t seed[4] = {870, 2000, 304, 2};  // main.rs:805
@@ -335,6 +350,7 @@ int hh_scene_create(const char *name, const char *asset_root, hh_scene **out) {
     if (n == "rtcamp6_v3_1") build_rtcamp6_v3_1(b, false);
     else if (n == "rtcamp6_dodeca") build_rtcamp6_v3_1(b, true);
     else if (n == "rtcamp6_v3") build_rtcamp6_v3(b);
+    else if (n == "simple") build_simple(b);
     else if (n == "spheres") build_spheres(b);
     else if (n == "cornell_mini") build_cornell_mini(b);
     else { set_error("unknown scene '%s'", name); return HR_ERR_INVALID; }

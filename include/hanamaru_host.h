@@ -27,6 +27,7 @@ const char *hh_last_error(void);
  *   "rtcamp6_dodeca"— BASELINE config 5: rtcamp6_v3_1 + models/fractal_dodecahedron.obj with the
  *                     Refraction-1.5 material of main.rs:910-915
  *   "rtcamp6_v3"    — main.rs:928-1017: two emissive spheres (one of radius 1 mm next to the camera), aperture 0.2
+ *   "simple"        — main.rs:54-136: GGX floor with image albedo + image roughness, two coloured emitters, black sky
  *   "cornell_mini"  — tiny build-defined scene touching all five surface types + textured sphere (tests)
  */
 int hh_scene_create(const char *name, const char *asset_root, hh_scene **out);

@@ -63,7 +63,7 @@ def test_axis_aligned_and_degenerate_rays(emu_scenes):
     assert np.allclose(got[hit, 1], ref[hit, 1], rtol=1e-5)
 
 
-@pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 96, 54, 2), ("cornell_mini", 64, 48, 3), ("spheres", 80, 45, 1), ("rtcamp6_dodeca", 50, 29, 1), ("rtcamp6_v3", 72, 40, 2)])
+@pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 96, 54, 2), ("cornell_mini", 64, 48, 3), ("spheres", 80, 45, 1), ("rtcamp6_dodeca", 50, 29, 1), ("rtcamp6_v3", 72, 40, 2), ("simple", 80, 45, 2)])
 def test_radiance_accumulator(emu_scenes, name, w, h, s):
     _, o, e = emu_scenes(name)
     acc, cn = e.render(w, h, 1, s + 1, threads=0)
