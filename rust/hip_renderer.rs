@@ -1,0 +1,178 @@
+// UNTESTED (no Rust toolchain in the build environment).
+// `Renderer` implementation that replaces the rayon pixel loop (renderer.rs:32-43) by the HIP back end and keeps the
+// reference's progress / time-limit policy (renderer.rs:205-251) on the host clock.
+extern crate image;
+extern crate time;
+
+use std::ffi::CStr;
+use std::ptr;
+use image::{ImageBuffer, Rgb, GenericImage};
+
+use camera::{Camera, LensShape};
+use color::Color;
+use config;
+use hip_ffi::*;
+use material::{Material, SurfaceType};
+use renderer::Renderer;
+use scene::{Intersectable, SceneTrait, BvhScene};
+use texture::Texture;
+use vector::{Vector2, Vector3};
+
+/// What `Intersectable::describe()` (added to scene.rs, see README.md) hands back.
+pub enum ElementRef<'a> {
+    Sphere { center: &'a Vector3, radius: f64, material: &'a Material },
+    Cuboid { min: &'a Vector3, max: &'a Vector3, material: &'a Material },
+    Mesh { vertexes: &'a Vec<Vector3>, faces: Vec<[u64; 3]>, material: &'a Material },
+}
+
+const BATCH: u32 = 16; // samplings between two report_progress calls (one host sync each)
+
+pub struct HipRenderer {
+    ctx: *mut HrCtx,
+    sampling: u32,
+    time_limit_sec: f64,
+    report_interval_sec: f64,
+    begin: time::Tm,
+    last_report_progress: time::Tm,
+    last_report_image: time::Tm,
+    report_image_counter: u32,
+}
+unsafe impl Sync for HipRenderer {} // the context is only touched from render(), on the calling thread
+
+fn check(rc: i32) {
+    if rc != 0 {
+        let msg = unsafe { CStr::from_ptr(hr_last_error()) }.to_string_lossy().into_owned();
+        panic!("hanamaru_hip error {}: {}", rc, msg); // the reference panics on every error too
+    }
+}
+
+struct Flat { // keeps everything the hr_scene_desc points into alive during hr_upload_scene
+    elements: Vec<HrElement>, faces: Vec<Vec<[u64; 3]>>, images: Vec<HrImage>, pixels: Vec<Vec<u8>>,
+}
+impl Flat {
+    fn texture(&mut self, t: &Texture) -> HrTexture {
+        let image = match t.image_texture {
+            Some(ref it) => { // texture.rs:10-12: DynamicImage -> RGBA8, row 0 = top
+                let rgba = it.image.to_rgba();
+                let (w, h) = (rgba.width(), rgba.height());
+                self.pixels.push(rgba.into_raw());
+                self.images.push(HrImage { rgba: self.pixels.last().unwrap().as_ptr(), width: w, height: h });
+                (self.images.len() - 1) as i32
+            }
+            None => -1,
+        };
+        HrTexture { color: t.color, image, _pad: 0 }
+    }
+    fn material(&mut self, m: &Material) -> HrMaterial {
+        let (surface, param) = match m.surface { // material.rs:9-15
+            SurfaceType::Diffuse => (0, 0.0),
+            SurfaceType::Specular => (1, 0.0),
+            SurfaceType::Refraction { refractive_index } => (2, refractive_index),
+            SurfaceType::GGX { f0 } => (3, f0),
+            SurfaceType::GGXRefraction { refractive_index } => (4, refractive_index),
+        };
+        HrMaterial { surface, _pad: 0, param, albedo: self.texture(&m.albedo), emission: self.texture(&m.emission),
+                     roughness: self.texture(&m.roughness) }
+    }
+}
+
+impl HipRenderer {
+    pub fn new(sampling: u32, time_limit_sec: f64, report_interval_sec: f64) -> HipRenderer {
+        let mut ctx: *mut HrCtx = ptr::null_mut();
+        check(unsafe { hr_create(0, &mut ctx) });
+        let now = time::now();
+        HipRenderer { ctx, sampling, time_limit_sec, report_interval_sec, begin: now, last_report_progress: now,
+                      last_report_image: now, report_image_counter: 0 }
+    }
+
+    fn upload(&mut self, scene: &BvhScene, camera: &Camera) {
+        let zero = Vector3::zero();
+        let mut flat = Flat { elements: vec![], faces: vec![], images: vec![], pixels: vec![] };
+        for e in &scene.scene.elements {
+            let mut h = HrElement { kind: 0, _pad: 0, material: flat.material(e.material()), center: zero, radius: 0.0,
+                                    aabb_min: zero, aabb_max: zero, vertexes: ptr::null(), num_vertexes: 0, faces: ptr::null(), num_faces: 0 };
+            match e.describe() {
+                ElementRef::Sphere { center, radius, .. } => { h.kind = HR_SPHERE; h.center = *center; h.radius = radius; }
+                ElementRef::Cuboid { min, max, .. } => { h.kind = HR_CUBOID; h.aabb_min = *min; h.aabb_max = *max; }
+                ElementRef::Mesh { vertexes, faces, .. } => {
+                    h.kind = HR_MESH;
+                    h.vertexes = vertexes.as_ptr(); h.num_vertexes = vertexes.len() as u64;
+                    flat.faces.push(faces);
+                    let f = flat.faces.last().unwrap();
+                    h.faces = f.as_ptr() as *const u64; h.num_faces = f.len() as u64;
+                }
+            }
+            flat.elements.push(h);
+        }
+        let sky = &scene.scene.skybox; // scene.rs:268-276: px, nx, py, ny, pz, nz
+        let mut face_image = [0i32; 6];
+        for (i, t) in [&sky.px_texture, &sky.nx_texture, &sky.py_texture, &sky.ny_texture, &sky.pz_texture, &sky.nz_texture].iter().enumerate() {
+            let rgba = t.image.to_rgba();
+            let (w, h) = (rgba.width(), rgba.height());
+            flat.pixels.push(rgba.into_raw());
+            flat.images.push(HrImage { rgba: flat.pixels.last().unwrap().as_ptr(), width: w, height: h });
+            face_image[i] = (flat.images.len() - 1) as i32;
+        }
+        let desc = HrSceneDesc {
+            elements: flat.elements.as_ptr(), num_elements: flat.elements.len() as u32,
+            images: flat.images.as_ptr(), num_images: flat.images.len() as u32,
+            skybox: HrSkybox { face_image, intensity: sky.intensity },
+            camera: HrCamera { eye: camera.eye, right: camera.right, up: camera.up, forward: camera.forward,
+                               plane_half_right: camera.plane_half_right, plane_half_up: camera.plane_half_up,
+                               lens_radius: camera.lens_radius, focus_distance: camera.focus_distance,
+                               lens_shape: match camera.lens_shape { LensShape::Square => 0, LensShape::Circle => 1 }, _pad: 0 },
+        };
+        check(unsafe { hr_upload_scene(self.ctx, &desc) }); // copies everything: `flat` may be dropped afterwards
+    }
+}
+
+impl Renderer for HipRenderer {
+    fn max_sampling(&self) -> u32 { self.sampling }
+
+    // never called: the per-path work runs on the GPU
+    fn calc_pixel(&self, _: &SceneTrait, _: &Camera, _: &Vec<&Box<Intersectable>>, _: &Vector2, _: u32) -> Color { unreachable!() }
+
+    fn render(&mut self, scene: &SceneTrait, camera: &Camera, imgbuf: &mut ImageBuffer<Rgb<u8>, Vec<u8>>) -> u32 {
+        // main.rs:1216 always passes a BvhScene; the trait object needs `fn as_bvh_scene(&self) -> &BvhScene` (one line in scene.rs)
+        self.upload(scene.as_bvh_scene(), camera);
+        check(unsafe { hr_set_resolution(self.ctx, imgbuf.width(), imgbuf.height()) });
+        let mut s = 1;
+        while s <= self.sampling {
+            let e = (s + BATCH).min(self.sampling + 1);
+            check(unsafe { hr_render(self.ctx, s, e, 1) });
+            check(unsafe { hr_synchronize(self.ctx) });
+            if self.report_progress(&Vec::new(), e - 1, imgbuf) { return e - 1; }
+            s = e;
+        }
+        self.sampling
+    }
+
+    // renderer.rs:205-251 with update_imgbuf (renderer.rs:64-90) replaced by hr_resolve
+    fn report_progress(&mut self, _acc: &Vec<Vector3>, sampling: u32, imgbuf: &mut ImageBuffer<Rgb<u8>, Vec<u8>>) -> bool {
+        let now = time::now();
+        let used = (now - self.begin).num_milliseconds() as f64 * 0.001;
+        let last = (now - self.last_report_progress).num_milliseconds() as f64 * 0.001;
+        println!("rendering: {}x{} sampled (last {:.3} sec). total: {:.3} sec ({:.2} %).", sampling,
+                 config::SUPERSAMPLING * config::SUPERSAMPLING, last, used, used / self.time_limit_sec * 100.0);
+        let stop_time = used + last * 1.1 > self.time_limit_sec;
+        let stop_max = sampling >= self.sampling;
+        let interval = (now - self.last_report_image).num_milliseconds() as f64 * 0.001 >= self.report_interval_sec;
+        if stop_time || stop_max || interval {
+            let path = format!("{:>03}.png", self.report_image_counter);
+            if stop_time { println!("reached time limit"); } else if stop_max { println!("reached max sampling"); }
+            if stop_time || stop_max { println!("output final image: {}", path); println!("remain: {:.3} sec.", self.time_limit_sec - used); }
+            else { println!("output progress image: {}", path); }
+            check(unsafe { hr_resolve(self.ctx, sampling, imgbuf.as_mut_ptr()) }); // RGB8, row-major, top row first
+            let _ = image::ImageRgb8(imgbuf.clone()).save(&path);
+            if stop_time || stop_max { return true; }
+            self.report_image_counter += 1;
+            self.last_report_image = now;
+        }
+        self.last_report_progress = now;
+        false
+    }
+}
+
+impl Drop for HipRenderer {
+    fn drop(&mut self) { unsafe { hr_destroy(self.ctx); } }
+}
