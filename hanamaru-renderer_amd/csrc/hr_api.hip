@@ -412,50 +412,49 @@ struct EventPair { hipEvent_t a, b; };
 
 struct hr_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;       // trace / post stream (own or caller's)
-    hipStream_t own_stream = nullptr;
-    hipStream_t seed_stream = nullptr;  // seed kernel of the next batch runs here, concurrently
+    int num_cus = 256;
+    // streams: trace + post on `stream` (own or the caller's), the seed kernel of the NEXT batch on `seed_stream`,
+    // the optional init kernel (split seeding) on `init_stream`
+    hipStream_t stream = nullptr, own_stream = nullptr, seed_stream = nullptr, init_stream = nullptr;
+    // scene
     std::vector<void *> scene_allocs;
     Scene dsc{};
     bool have_scene = false;
+    uint64_t st_nodes = 0, st_tris = 0, st_spheres = 0, st_cuboids = 0;
+    // target
     uint32_t W = 0, H = 0;
     float *accum_own = nullptr, *accum = nullptr;
-    u64 *tails[2] = {nullptr, nullptr};
-    u64 *minit[2] = {nullptr, nullptr};   // split seeding: initialised generator states, 2 KiB per path
-    size_t minit_cap = 0;                 // items per buffer
-    hipStream_t init_stream = nullptr;
-    hipEvent_t init_done[2] = {nullptr, nullptr};
-    bool seed_pending[2] = {false, false};
-    int seed_mode = 0;                    // 0 = fused seed kernel, 1 = init kernel + round kernel
-    uint32_t init_wgs_per_cu = 1;
-    uint32_t seed_prio = 3;               // s_setprio of the seed / round kernel's waves
-    int debug_skip = 0;                   // timing experiments only: 1 = skip the init kernel, 2 = skip the seed/round kernel (garbage image)         // split seeding: resident 256-thread workgroups of the init kernel per CU
-    uint64_t max_state_bytes = 40ull << 30;  // per minit buffer
-    std::vector<EventPair> init_events;
-    double init_ms = 0;
-    uint64_t init_launches = 0;
-    uint32_t *lens[2] = {nullptr, nullptr};
-    size_t draws_cap = 0;  // items (tile x sampling) per buffer
-    hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
-    bool trace_pending[2] = {false, false};
-    Counters *d_counters = nullptr;
-    uint32_t *d_tile_counter = nullptr;  // [2]: next tile of the trace launch in each slot
     float *post_tmp = nullptr;
     uint8_t *d_rgb8 = nullptr;
-    bool counters = false;
-    uint32_t batch = 4;
-    uint32_t adv_den = 2, leaf_den = 2;
-    int min_waves = 5;
-    int max_leaf = 4;
-    double split_ratio = 0.0;
-    uint64_t max_tail_bytes = 20ull << 30;  // per buffer (two buffers)
-    int num_cus = 256;
-    std::vector<EventPair> seed_events, trace_events, post_events;
-    double seed_ms = 0, trace_ms = 0, post_ms = 0;
-    uint64_t seed_launches = 0, trace_launches = 0;
-    uint64_t paths_rendered = 0;
-    uint64_t st_nodes = 0, st_tris = 0, st_spheres = 0, st_cuboids = 0;
+    // seed -> trace hand-off, double buffered (slot = batch & 1)
+    u64 *tails[2] = {nullptr, nullptr};
+    uint32_t *lens[2] = {nullptr, nullptr};
+    size_t draws_cap = 0;                    // items (tile x sampling) per buffer
+    u64 *minit[2] = {nullptr, nullptr};      // split seeding: initialised generator states, 2 KiB per path
+    size_t minit_cap = 0;
+    hipEvent_t init_done[2] = {nullptr, nullptr}, seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
+    bool seed_pending[2] = {false, false}, trace_pending[2] = {false, false};
     uint64_t batch_counter = 0;
+    Counters *d_counters = nullptr;
+    uint32_t *d_tile_counter = nullptr;      // [2]: next tile of the trace launch in each slot
+    // options (hr_set_option)
+    bool counters = false;
+    uint32_t batch = 4;                      // samplings per launch
+    uint32_t adv_den = 2, leaf_den = 2;      // trace-kernel phase thresholds
+    int min_waves = 5;                       // occupancy variant of the trace kernel
+    int max_leaf = 4;                        // BVH leaf size (next upload)
+    double split_ratio = 0.0;                // early split clipping (0 = off)
+    uint64_t max_tail_bytes = 20ull << 30;   // cap of each raw-draw buffer
+    uint64_t max_state_bytes = 40ull << 30;  // cap of each generator-state buffer (split seeding)
+    int seed_mode = 0;                       // 0 = fused seed kernel, 1 = init kernel + round kernel
+    uint32_t init_wgs_per_cu = 1;            // split seeding: resident 256-thread workgroups of the init kernel per CU
+    uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
+    int debug_skip = 0;                      // timing experiments only: 1 = skip init kernel, 2 = skip seed kernel (garbage image)
+    // timing (HIP events around every launch, summed when the streams are drained)
+    std::vector<EventPair> seed_events, trace_events, post_events, init_events;
+    double seed_ms = 0, trace_ms = 0, post_ms = 0, init_ms = 0;
+    uint64_t seed_launches = 0, trace_launches = 0, init_launches = 0;
+    uint64_t paths_rendered = 0;
 };
 
 static void free_scene(hr_ctx *c) {
@@ -503,6 +502,8 @@ static int sync_all(hr_ctx *c) {
 
 // ------------------------------------------------------------------------------------------ C ABI
 
+static int create_resources(hr_ctx *c);
+
 extern "C" {
 
 const char *hr_last_error(void) { return g_err.c_str(); }
@@ -516,6 +517,14 @@ int hr_create(int device_id, hr_ctx **out) {
     HIP_TRY(hipSetDevice(device_id));
     hr_ctx *c = new hr_ctx;
     c->device = device_id;
+    int rc = create_resources(c);
+    if (rc) { (void)hr_destroy(c); return rc; }
+    *out = c;
+    return HR_OK;
+}
+
+static int create_resources(hr_ctx *c) {
+    const int device_id = c->device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -534,7 +543,6 @@ int hr_create(int device_id, hr_ctx **out) {
     HIP_TRY(hipFuncSetAttribute((const void *)seed_isaac64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
-    *out = c;
     return HR_OK;
 }
 
