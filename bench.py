@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--leaf-den", type=int, default=0)
     ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--max-leaf", type=int, default=0)
+    ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH")
     ap.add_argument("--split-ratio", type=float, default=0.0)
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--init-wgs", type=int, default=0)
@@ -91,6 +92,8 @@ def main():
     r = ha.Renderer(local_rank)
     if args.max_leaf:
         r.set_option("max_leaf", args.max_leaf)
+    if args.bvh_builder:
+        r.set_option("bvh_builder", args.bvh_builder)
     if args.split_ratio:
         r.set_option("split_ratio", args.split_ratio)
     r.upload_scene(scene)
@@ -180,7 +183,8 @@ def main():
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
-                "init_kernel_avg_ms": round(st["init_kernel_ms"] / max(1, st["init_launches"]), 4) if st["init_launches"] else None}
+                "init_kernel_avg_ms": round(st["init_kernel_ms"] / max(1, st["init_launches"]), 4) if st["init_launches"] else None,
+                "bvh_builder": "device-lbvh" if args.bvh_builder else "host-sah", "bvh_build_ms": round(st["bvh_build_ms"], 4)}
         if bytes_per_path is not None and avg_ms > 0:
             gbs = bytes_per_path * paths_per_launch / (avg_ms * 1e-3) / 1e9
             roof.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_path": round(bytes_per_path, 1),

@@ -88,7 +88,7 @@ Scene HostScene::view() const {
     return d;
 }
 
-int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf, double split_ratio) {
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf, double split_ratio, bool host_bvh) {
     if (!sd) return ferr(err, HR_ERR_INVALID, "null scene");
     if (!sd->elements || sd->num_elements == 0) return ferr(err, HR_ERR_INVALID, "scene has no elements");
     struct TriD { double v0[3], v1[3], v2[3]; int32_t elem; };
@@ -170,7 +170,16 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         return ferr(err, HR_ERR_UNSUPPORTED, "more than 2^20 primitives of one type");
 
     BuiltBvh bvh;
-    build_bvh(prims, max_leaf, bvh);
+    if (host_bvh) {
+        build_bvh(prims, max_leaf, bvh);
+    } else {
+        // the tree is built on the device (csrc/gpu_bvh.h): primitives stay in input order, only the scene bounds are needed
+        for (int a = 0; a < 3; a++) { out.scene_min[a] = 1e300; out.scene_max[a] = -1e300; }
+        for (const BuildPrim &p : prims) {
+            bvh.order[p.type].push_back(p.index);
+            for (int a = 0; a < 3; a++) { out.scene_min[a] = std::fmin(out.scene_min[a], p.bmin[a]); out.scene_max[a] = std::fmax(out.scene_max[a], p.bmax[a]); }
+        }
+    }
     out.nodes = bvh.nodes; out.num_nodes = bvh.num_nodes;
     out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves;
 

@@ -23,6 +23,7 @@
 #include "bvh_build.h"
 #include "device_scene.h"
 #include "flatten.h"
+#include "gpu_bvh.h"
 #include "hanamaru_hip.h"
 #include "isaac_core.h"
 #include "post_core.h"
@@ -444,6 +445,8 @@ struct hr_ctx {
     int min_waves = 5;                       // occupancy variant of the trace kernel
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = 0.0;                // early split clipping (0 = off)
+    int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH (gpu_bvh.h); next upload
+    double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each raw-draw buffer
     uint64_t max_state_bytes = 40ull << 30;  // cap of each generator-state buffer (split seeding)
     int seed_mode = 0;                       // 0 = fused seed kernel, 1 = init kernel + round kernel
@@ -573,6 +576,81 @@ int hr_destroy(hr_ctx *c) {
     return HR_OK;
 }
 
+// Device LBVH (option bvh_builder = 1): the primitive arrays were uploaded in input order; build the tree over them,
+// re-store the primitives in leaf order and point the scene at the results.  Scratch is freed before returning.
+static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
+    using namespace lbvh;
+    Scene &d = c->dsc;
+    const int n = (int)(d.num_tris + d.num_spheres + d.num_cuboids);
+    const int N = 2 * n - 1;
+    Prims p{};
+    p.tris = d.tris; p.num_tris = d.num_tris; p.spheres = d.spheres; p.num_spheres = d.num_spheres; p.cuboids = d.cuboids; p.num_cuboids = d.num_cuboids;
+    for (int a = 0; a < 3; a++) {
+        double ext = hs.scene_max[a] - hs.scene_min[a];
+        p.smin[a] = (float)hs.scene_min[a];
+        p.sinv[a] = ext > 0 ? (float)(1.0 / ext) : 0.0f;
+    }
+    std::vector<void *> scratch;
+    auto cleanup = [&]() { for (void *q : scratch) (void)hipFree(q); };
+    auto alloc = [&](size_t bytes, bool keep) -> void * {
+        void *q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        (keep ? c->scene_allocs : scratch).push_back(q);
+        return q;
+    };
+#define LBVH_ALLOC(var, type, count, keep)                                                                        \
+    type *var = (type *)alloc(sizeof(type) * (size_t)(count), keep);                                                \
+    if (!var) { cleanup(); return fail(HR_ERR_DEVICE, "hr_upload_scene: out of device memory in the BVH build"); }
+    LBVH_ALLOC(keys_in, mkey_t, n, false)
+    LBVH_ALLOC(keys, mkey_t, n, false)
+    Work w{};
+    LBVH_ALLOC(parent, uint32_t, N, false) LBVH_ALLOC(left, uint32_t, n, false) LBVH_ALLOC(right, uint32_t, n, false)
+    LBVH_ALLOC(first, uint32_t, n, false) LBVH_ALLOC(last, uint32_t, n, false) LBVH_ALLOC(flags, uint32_t, n, false)
+    LBVH_ALLOC(bmin, float, 3 * (size_t)N, false) LBVH_ALLOC(bmax, float, 3 * (size_t)N, false)
+    LBVH_ALLOC(word, uint32_t, N, false) LBVH_ALLOC(axis_low, uint32_t, n, false)
+    w.parent = parent; w.left = left; w.right = right; w.first = first; w.last = last; w.flags = flags;
+    w.bmin = bmin; w.bmax = bmax; w.word = word; w.axis_low = axis_low;
+    LBVH_ALLOC(nodes, Node, 8 * (size_t)N, true)
+    LBVH_ALLOC(tris, Tri, d.num_tris, true)
+    LBVH_ALLOC(spheres, f4, d.num_spheres, true)
+    LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
+    LBVH_ALLOC(cuboids, f4, 2 * (size_t)d.num_cuboids, true)
+    size_t sort_bytes = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys, n, 0, 64, c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "hipcub sort (size query): %s", hipGetErrorString(e)); }
+    LBVH_ALLOC(sort_tmp, unsigned char, sort_bytes, false)
+#undef LBVH_ALLOC
+    hipEvent_t ea = nullptr, eb = nullptr;
+    (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+    const int T = 256;
+    hipStream_t st = c->stream;
+    (void)hipEventRecord(ea, st);
+    e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, st);
+    if (e == hipSuccess) e = hipMemsetAsync(parent, 0xff, sizeof(uint32_t) * (size_t)N, st);   // n == 1: the lone leaf is the root
+    if (e == hipSuccess) {
+        key_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, n, keys_in);
+        e = hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys_in, keys, n, 0, 64, st);
+    }
+    if (e == hipSuccess) {
+        if (n > 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
+        fit_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, (uint32_t)c->max_leaf, w);
+        emit_kernel<<<(8 * N + T - 1) / T, T, 0, st>>>(n, w, nodes);
+        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, tris, spheres, sphere_elem, d.sphere_elem, cuboids);
+        e = hipGetLastError();
+    }
+    (void)hipEventRecord(eb, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    float ms = 0;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ea, eb);
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    cleanup();
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "device BVH build: %s", hipGetErrorString(e));
+    c->bvh_build_ms = ms;
+    d.nodes = nodes; d.num_nodes = (uint32_t)N;
+    d.tris = tris; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
+    return HR_OK;
+}
+
 int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if (!c || !sd) return fail(HR_ERR_INVALID, "hr_upload_scene: null argument");
     if (!sd->elements || sd->num_elements == 0) return fail(HR_ERR_INVALID, "hr_upload_scene: scene has no elements");
@@ -583,12 +661,12 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
 
     HostScene hs;
     std::string ferr;
-    rc = flatten_scene(sd, hs, ferr, c->max_leaf, c->split_ratio);
+    const bool gpu_build = c->bvh_builder == 1;
+    rc = flatten_scene(sd, hs, ferr, c->max_leaf, gpu_build ? 0.0 : c->split_ratio, !gpu_build);
     if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());
     Scene &d = c->dsc;
     d = hs.view();
     int r;
-    if ((r = upload(c, hs.nodes, &d.nodes))) return r;
     if ((r = upload(c, hs.tris, &d.tris))) return r;
     if ((r = upload(c, hs.spheres, &d.spheres))) return r;
     if ((r = upload(c, hs.sphere_elem, &d.sphere_elem))) return r;
@@ -597,6 +675,9 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.images, &d.images))) return r;
     if ((r = upload(c, hs.emitters, &d.emitters))) return r;
     if ((r = upload(c, hs.texels, &d.texels))) return r;
+    c->bvh_build_ms = 0;
+    if (gpu_build) { if ((r = build_bvh_on_device(c, hs))) return r; }
+    else if ((r = upload(c, hs.nodes, &d.nodes))) return r;
     c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
     c->have_scene = true;
     return HR_OK;
@@ -863,6 +944,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
     out->init_kernel_ms = c->init_ms; out->init_launches = c->init_launches;
+    out->bvh_build_ms = c->bvh_build_ms;
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
     out->bvh_nodes = c->st_nodes; out->triangles = c->st_tris; out->spheres = c->st_spheres; out->cuboids = c->st_cuboids;
@@ -916,6 +998,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "split_ratio") {  // early split clipping of triangle references (0 = off), next hr_upload_scene
         if (value < 0 || value > 1000) return fail(HR_ERR_INVALID, "split_ratio must be in [0,1000]");
         c->split_ratio = value;
+        return HR_OK;
+    }
+    if (k == "bvh_builder") {  // 0 = host binned SAH, 1 = device LBVH; takes effect at the next hr_upload_scene
+        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "bvh_builder must be 0 (host SAH) or 1 (device LBVH)");
+        c->bvh_builder = (int)value;
         return HR_OK;
     }
     if (k == "max_leaf") {  // takes effect at the next hr_upload_scene

@@ -43,8 +43,10 @@ HD V3f operator*(V3f a, V3f b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 HD V3f operator*(V3f a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 HD V3f operator*(float s, V3f a) { return v3(a.x * s, a.y * s, a.z * s); }
 HD V3f operator-(V3f a) { return v3(-a.x, -a.y, -a.z); }
-HD float dot(V3f a, V3f b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-HD V3f cross(V3f a, V3f b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// explicit FMAs: the contraction is then the same in every inlined copy, so a primitive test returns the same bits
+// wherever the primitive sits in a leaf (closest hits do not depend on the tree)
+HD float dot(V3f a, V3f b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+HD V3f cross(V3f a, V3f b) { return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
 HD V3f normalize(V3f a) { return a * HR_RSQ(dot(a, a)); }
 HD V3f reflect(V3f v, V3f n) { return v - (2.0f * dot(v, n)) * n; }  // vector.rs:60-62
 HD bool is_zero(V3f a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }

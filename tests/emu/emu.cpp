@@ -11,9 +11,11 @@
 #include <thread>
 #include <atomic>
 #include <vector>
+#include <algorithm>
 
 #include "flatten.h"
 #include "isaac_core.h"
+#include "lbvh_core.h"
 #include "post_core.h"
 #include "pt_core.h"
 
@@ -51,13 +53,72 @@ extern "C" {
 
 static int g_max_leaf = 4;
 static double g_split_ratio = 0.0;
+static int g_builder = 0;   // 0 = host SAH (bvh_build.cpp), 1 = LBVH (lbvh_core.h, the device builder's per-thread code run sequentially)
 void emu_set_build_options(int max_leaf, double split_ratio) { g_max_leaf = max_leaf; g_split_ratio = split_ratio; }
+void emu_set_builder(int builder) { g_builder = builder; }
+
+// what build_bvh_on_device (hr_api.hip) does, with std::sort for the radix sort and loops for the kernels
+static void lbvh_build_host(HostScene &hs, int max_leaf) {
+    using namespace lbvh;
+    Prims p{};
+    p.tris = hs.tris.data(); p.num_tris = (uint32_t)hs.tris.size();
+    p.spheres = hs.spheres.data(); p.num_spheres = (uint32_t)hs.spheres.size();
+    p.cuboids = hs.cuboids.data(); p.num_cuboids = (uint32_t)(hs.cuboids.size() / 2);
+    for (int a = 0; a < 3; a++) {
+        double ext = hs.scene_max[a] - hs.scene_min[a];
+        p.smin[a] = (float)hs.scene_min[a];
+        p.sinv[a] = ext > 0 ? (float)(1.0 / ext) : 0.0f;
+    }
+    const int n = (int)(p.num_tris + p.num_spheres + p.num_cuboids), N = 2 * n - 1;
+    std::vector<mkey_t> keys(n);
+    for (int i = 0; i < n; i++) keys[i] = prim_key(p, (uint32_t)i);
+    std::sort(keys.begin(), keys.end());
+    std::vector<uint32_t> parent(N, NODE_END), left(n), right(n), first(n), last(n), flags(n, 0), word(N, 0), axis_low(n, 0);
+    std::vector<float> bmin(3 * (size_t)N), bmax(3 * (size_t)N);
+    Work w{parent.data(), left.data(), right.data(), first.data(), last.data(), flags.data(), bmin.data(), bmax.data(), word.data(), axis_low.data()};
+    for (int i = 0; i < n - 1; i++) hierarchy_node(keys.data(), n, i, w);
+    for (int k = 0; k < n; k++) {
+        fit_leaf(p, keys.data(), n, k, w);
+        if (n == 1) break;
+        uint32_t cur = parent[n - 1 + k];
+        while (cur != NODE_END) {
+            if (flags[cur]++ == 0) break;
+            fit_inner(n, cur, (uint32_t)max_leaf, w);
+            cur = parent[cur];
+        }
+    }
+    hs.nodes.resize(8 * (size_t)N);
+    for (int o = 0; o < 8; o++)
+        for (int i = 0; i < N; i++) hs.nodes[(size_t)o * N + i] = emit_node(n, i, o, w);
+    hs.num_nodes = (uint32_t)N;
+    std::vector<Tri> tris(hs.tris.size());
+    std::vector<f4> spheres(hs.spheres.size()), cuboids(hs.cuboids.size());
+    std::vector<int32_t> sphere_elem(hs.sphere_elem.size());
+    for (int k = 0; k < n; k++) {
+        uint32_t i = key_index(keys[k]);
+        if (i < p.num_tris) tris[k] = hs.tris[i];
+        else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris, d = k - p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; }
+        else { uint32_t l = i - p.num_tris - p.num_spheres, d = k - p.num_tris - p.num_spheres; cuboids[2 * d] = hs.cuboids[2 * l]; cuboids[2 * d + 1] = hs.cuboids[2 * l + 1]; }
+    }
+    hs.tris.swap(tris); hs.spheres.swap(spheres); hs.sphere_elem.swap(sphere_elem); hs.cuboids.swap(cuboids);
+    // reachable leaves / depth for the stats call
+    hs.bvh_leaves = 0; hs.bvh_max_depth = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}};
+    while (!st.empty()) {
+        auto [id, depth] = st.back();
+        st.pop_back();
+        hs.bvh_max_depth = std::max(hs.bvh_max_depth, depth);
+        if (word[id]) { hs.bvh_leaves++; continue; }
+        st.push_back({left[id], depth + 1}); st.push_back({right[id], depth + 1});
+    }
+}
 
 int emu_scene_create(const hr_scene_desc *sd, emu_scene **out) {
     emu_scene *e = new emu_scene;
     std::string err;
-    int rc = flatten_scene(sd, e->hs, err, g_max_leaf, g_split_ratio);
+    int rc = flatten_scene(sd, e->hs, err, g_max_leaf, g_builder ? 0.0 : g_split_ratio, g_builder == 0);
     if (rc) { fprintf(stderr, "emu: %s\n", err.c_str()); delete e; return rc; }
+    if (g_builder) lbvh_build_host(e->hs, g_max_leaf);
     e->view = e->hs.view();
     *out = e;
     return 0;

@@ -16,6 +16,7 @@ def lib():
         L.emu_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.emu_scene_destroy.argtypes = [C.c_void_p]
         L.emu_set_build_options.argtypes = [C.c_int, C.c_double]
+        L.emu_set_builder.argtypes = [C.c_int]
         L.emu_scene_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_path_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
@@ -69,8 +70,10 @@ class EmuScene:
         return out, el
 
 
-def set_build_options(max_leaf=4, split_ratio=0.0):
+def set_build_options(max_leaf=4, split_ratio=0.0, builder=0):
+    """builder: 0 = host SAH, 1 = LBVH (the device builder's per-thread code, run sequentially)."""
     lib().emu_set_build_options(max_leaf, split_ratio)
+    lib().emu_set_builder(builder)
 
 
 def path_draws(w, h, x, y, sub, sampling, lens_shape=1):

@@ -391,3 +391,53 @@ def test_matches_the_reference_binarys_committed_render(gpu, scenes):
     print("PSNR %.2f dB, mean abs diff %.4f, exact channels %.4f, within 1 LSB %.4f, max %d" % (psnr, d.mean(), (d == 0).mean(), (d <= 1).mean(), d.max()))
     # measured: PSNR 74.2 dB, 99.80 % of the channels identical, 99.99 % within 1 LSB, max 7
     assert psnr > 65.0 and (d == 0).mean() > 0.99 and (d <= 1).mean() > 0.999
+
+
+@pytest.mark.parametrize("name,max_leaf", [("rtcamp6_v3_1", 4), ("rtcamp6_dodeca", 4), ("spheres", 2), ("cornell_mini", 1)])
+def test_device_bvh_build_is_interchangeable(gpu, scenes, name, max_leaf):
+    """Option bvh_builder = 1 builds the tree on the GPU (LBVH, csrc/gpu_bvh.h).  Closest hits do not depend on the tree:
+    against the host-SAH tree over the same fp32 primitives the hit flag and t are identical bit for bit (pt_core.h
+    spells its FMAs out, so a primitive test returns the same bits in every leaf slot); the radiance accumulator then
+    differs only through equal-t ties between adjacent triangles and the atomics' summation order."""
+    sc, o = scenes(name)
+    rng = np.random.default_rng(5)
+    n = 20000
+    eye = np.array(sc.desc.camera.eye.tuple())
+    org = eye + rng.normal(size=(n, 3)) * 0.3
+    tgt = rng.uniform(-2.5, 2.5, size=(n, 3)) * np.array([1.0, 0.6, 1.0]) + np.array([0, 0.8, 0])
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    res = {}
+    try:
+        for builder in (0, 1):
+            gpu.set_option("bvh_builder", builder)
+            gpu.set_option("max_leaf", max_leaf)
+            gpu.upload_scene(sc)
+            st = gpu.stats()
+            if builder:
+                nprim = st["triangles"] + st["spheres"] + st["cuboids"]
+                assert st["bvh_nodes"] == 2 * nprim - 1 and 0 < st["bvh_build_ms"] < 50.0
+            else:
+                assert st["bvh_build_ms"] == 0
+            hit, el = gpu.debug_intersect(rays)
+            gpu.set_resolution(160, 90)
+            gpu.clear()
+            gpu.render(1, 3)
+            res[builder] = (hit, el, gpu.read_accumulator().astype(np.float64))
+    finally:
+        gpu.set_option("bvh_builder", 0)
+        gpu.set_option("max_leaf", 4)
+    (h0, e0, a0), (h1, e1, a1) = res[0], res[1]
+    assert np.array_equal(h0[:, 0], h1[:, 0])
+    hit = h0[:, 0] == 1
+    dt = np.abs(h0[hit, 1].astype(np.float64) - h1[hit, 1]) / np.maximum(1.0, h0[hit, 1])
+    print("device-vs-host tree: exact t %.5f, max rel dt %.3g, same element %.5f" % ((dt == 0).mean(), dt.max(), (e0[hit] == e1[hit]).mean()))
+    assert dt.max() == 0
+    assert (e0[hit] == e1[hit]).mean() > 0.999
+    assert np.isfinite(a1).all()
+    frac, m1, m0 = _compare(a1, a0)
+    assert frac > FRAC_OK and abs(m1 - m0) <= 2e-3 * max(1e-3, abs(m0))
+    ref, _ = o.render(160, 90, 1, 3, threads=0, counters=True)
+    frac, m1, mr = _compare(a1, ref)
+    assert frac > FRAC_OK and abs(m1 - mr) <= 2e-3 * max(1e-3, abs(mr))
