@@ -47,8 +47,9 @@ def main():
     ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH")
     ap.add_argument("--split-ratio", type=float, default=0.0)
     ap.add_argument("--seed-mode", type=int, default=-1)
-    ap.add_argument("--init-wgs", type=int, default=0)
     ap.add_argument("--seed-prio", type=int, default=-1)
+    ap.add_argument("--init-prio", type=int, default=-1)
+    ap.add_argument("--seed-head", type=int, default=-1)
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
@@ -107,10 +108,12 @@ def main():
         r.set_option("min_waves", args.min_waves)
     if args.seed_mode >= 0:
         r.set_option("seed_mode", args.seed_mode)
-    if args.init_wgs:
-        r.set_option("init_wgs_per_cu", args.init_wgs)
     if args.seed_prio >= 0:
         r.set_option("seed_prio", args.seed_prio)
+    if args.seed_head >= 0:
+        r.set_option("seed_head", args.seed_head)
+    if args.init_prio >= 0:
+        r.set_option("init_prio", args.init_prio)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
     paths_per_step_gpu = W * H * 4 * SPS
@@ -183,7 +186,6 @@ def main():
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
-                "init_kernel_avg_ms": round(st["init_kernel_ms"] / max(1, st["init_launches"]), 4) if st["init_launches"] else None,
                 "bvh_builder": "device-lbvh" if args.bvh_builder else "host-sah", "bvh_build_ms": round(st["bvh_build_ms"], 4)}
         if bytes_per_path is not None and avg_ms > 0:
             gbs = bytes_per_path * paths_per_launch / (avg_ms * 1e-3) / 1e9

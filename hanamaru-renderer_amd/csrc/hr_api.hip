@@ -8,7 +8,8 @@
 //                         one lane per path, stackless threaded-BVH traversal in box / leaf phases, finished lanes
 //                         are refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed
 //                         kernel of the NEXT batch (own stream).
-//   seed_init_kernel + seed_round_kernel   optional split form of the seeding (seed_mode = 1), see DESIGN.md.
+//   seed_pc_kernel        the default seeding (seed_mode = 1): producer waves run the init in registers, consumer waves the
+//                         LDS-bound round; seed_isaac64_kernel is the fused form (seed_mode = 0).
 //   debug_render_kernel   DebugRenderer modes (renderer.rs:101-146).
 //   tonemap_gamma_kernel, bilateral_quantise_kernel   the post chain.
 #include <hip/hip_runtime.h>
@@ -51,12 +52,19 @@ static int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------------------------------ kernels
 
+// 32-bit LDS address of a generic pointer into shared memory / load from such an address (isaac_round keeps the address of
+// its next gather in a register across a scheduling fence)
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) void *)p; }
+__device__ __forceinline__ u64 lds_load64(uint32_t a) { return *(const __attribute__((address_space(3))) u64 *)(size_t)a; }
+
 // One generator per LDS bank column: mem[i][col], SEED_COLS columns per workgroup.
 static const int SEED_COLS = 80;               // 80 x 2 KiB = 160 KiB = the whole LDS of a CU
 static const int SEED_WAVES = 2, SEED_LANES = SEED_COLS / SEED_WAVES;   // 2 waves x 40 active lanes
 struct LdsMem {
     u64 *col;  // &mem[0][col]
     __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_COLS]; }
+    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(SEED_COLS * 8); }
+    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
     __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_COLS] = v; }
 };
 // global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
@@ -119,47 +127,72 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
     }
 }
 
-// ---- split seeding (option seed_mode = 1) -------------------------------------------------------------------
-// seed_init_kernel: the two ISAAC-64 init passes, scratch-free (isaac_init_final), one lane per path at full
-// occupancy, result (2 KiB per path) streamed to `minit` as [item][i][64 lanes] u64.
-// seed_round_kernel: the LDS-bound part only — load 80 states into the LDS columns, one round, lens loop, tails.
-// The LDS holds a generator for ~half as long as in the fused kernel, at the price of 4 KiB of HBM traffic per path.
-// `minit` layout = the LDS image of the round kernel: [group of SEED_COLS paths][i = 0..255][column] u64, 160 KiB per
-// group, so the round kernel fills its LDS with a straight linear copy (global_load_lds, no VGPR round trip).
-struct GlobalState {
-    u64 *col;  // &minit[group][0][column]
-    // agent-scope relaxed store = `global_store_dwordx2 ... sc1`: written through, the line is not kept in the XCD's L2
-    // (MI355X_MICROARCH.md), so the 2 KiB-per-path stream does not evict the BVH the trace kernel lives on
-    __device__ __forceinline__ void st(int i, u64 v) { __hip_atomic_store(col + i * SEED_COLS, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ---- producer / consumer seeding (option seed_mode = 1, the default) -----------------------------------------------------------
+// One workgroup per CU, four waves, a contiguous range of path groups (80 paths = one LDS fill) per workgroup.
+// Waves 2,3 (producers) run the scratch-free init of the paths AHEAD in registers, 64 lanes = one chunk of 64 consecutive
+// paths per pass, and scatter the states into a small ring of group buffers in global memory that belongs to this
+// workgroup (written and re-read on the same CU within ~40 us: L2 / Infinity Cache traffic, not HBM); waves 0,1
+// (consumers) fill their half of the LDS from the ring with straight global_load_lds copies and run the round on 40
+// lanes each.  A generator state then sits in LDS only for fill + round (~2/3 of the fused kernel's residency, and LDS
+// capacity is what bounds seeding), and the init runs on full waves.
+// The ring traffic is what this costs (it slows the trace kernel next door), so only the blocks >= SEED_HEAD of a state
+// travel: the consumer recomputes blocks < SEED_HEAD from the pass-1 end state (8 words) while its fill is in flight
+// (isaac_init_head / isaac_init_tail).
+// Group buffer, per half: [row = 0 .. SEED_RING_ROWS)[40 columns] u64; rows 0 .. 256 - 8*SEED_HEAD are the LDS image of
+// generator words 8*SEED_HEAD .. 255, the last 8 rows hold the pass-1 end state.  One __syncthreads per group: in
+// iteration `it` the consumers work on group it-1 while the producers complete group `it` (5 chunks per 4 groups).
+template <int HEAD>   // blocks (of 8 words) redone by the consumer; even
+struct PcLayout {
+    static const int SHIP_ROWS = 256 - 8 * HEAD;
+    static const int RING_ROWS = SHIP_ROWS + 8;
+    static const size_t HALF_WORDS = (size_t)RING_ROWS * SEED_LANES;    // u64 per half in the ring
+    static const size_t GROUP_WORDS = 2 * HALF_WORDS;
+    static_assert((SHIP_ROWS * SEED_LANES * 8) % 1024 == 0, "fill copies 1 KiB per wave instruction");
 };
-__global__ __launch_bounds__(256) void seed_init_kernel(RenderParams rp, u64 *__restrict__ minit) {
-    // persistent, grid-stride: the launch decides how many waves trickle the states out (it only has to keep ahead
-    // of the round kernel; flooding the chip with init waves takes issue slots from the trace kernel)
-    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
-    const IsaacWarm warm = isaac_warm();
-    for (uint64_t pid = (uint64_t)blockIdx.x * 256u + threadIdx.x; pid < paths; pid += (uint64_t)gridDim.x * 256u) {
-        const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
-        uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
-        uint32_t px, py, sub;
-        tile_lane_pixel(rp, tile, j, px, py, sub);
-        if (px >= rp.width || py >= rp.height) continue;
-        u64 s, t;
-        path_seed_words(rp.width, rp.height, px, py, sub, s, t);
-        const uint64_t group = pid / SEED_COLS;
-        const uint32_t column = (uint32_t)(pid - group * SEED_COLS);
-        GlobalState out{minit + (size_t)group * 256 * SEED_COLS + column};
-        isaac_init_final(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
-    }
-}
+static const int SEED_RING_GROUPS = 4;                                   // group g lives in buffer g & 3
+static const size_t SEED_RING_WORDS_MAX = SEED_RING_GROUPS * PcLayout<0>::GROUP_WORDS;   // per workgroup, any HEAD
+static const size_t SEED_LDS_HALF_BYTES = (size_t)256 * SEED_LANES * 8;  // 80 KiB
 
-__global__ __launch_bounds__(64 * SEED_WAVES) void seed_round_kernel(RenderParams rp, int lens_shape, const u64 *__restrict__ minit,
-                                                                    u64 *__restrict__ tails, uint32_t *__restrict__ lens, Counters *cnt) {
+// Ring stores: a lane owns one column, so its words i and i + 1 are a row (320 B) apart.  Lane pairs (l, l ^ 1) swap one
+// word each so that the even lane stores row i and the odd lane row i + 1 as 16-byte pieces {column 2k, column 2k + 1}:
+// one dwordx4 store instruction then writes whole rows.
+template <int HEAD>
+struct RingState {
+    u64 *pair;   // even lane: &row0[col]; odd lane: &row1[col - 1]
+    bool on, odd;
+    __device__ __forceinline__ RingState(u64 *col, bool on_, uint32_t lane) : on(on_), odd(lane & 1u) { pair = odd ? col + SEED_LANES - 1 : col; }
+    static __device__ __forceinline__ u64 swap_pair(u64 v) {   // value of lane ^ 1
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+        hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xf, 0xf, true);
+        return ((u64)hi << 32) | lo;
+    }
+    __device__ __forceinline__ void row2(int row, u64 v0, u64 v1) {   // rows `row` (v0) and `row + 1` (v1) of this lane's column
+        u64 got = swap_pair(odd ? v0 : v1);            // even receives the partner's v0, odd the partner's v1
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 q;
+        q.x = odd ? got : v0;
+        q.y = odd ? v1 : got;
+        if (on) *reinterpret_cast<u64x2 *>(pair + row * SEED_LANES) = q;
+    }
+    __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i - 8 * HEAD, v0, v1); }
+    __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) { row2(PcLayout<HEAD>::SHIP_ROWS + j, v0, v1); }
+};
+struct LdsHalfMem {
+    u64 *col;
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_LANES]; }
+    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(SEED_LANES * 8); }
+    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_LANES] = v; }
+};
+template <int SEED_HEAD>
+__global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, u64 *__restrict__ tails,
+                                                      uint32_t *__restrict__ lens, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
-    u64 *mem = reinterpret_cast<u64 *>(smem);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const bool worker = lane < (uint32_t)SEED_LANES;       // 40 lanes per wave own a generator column
-    const uint32_t col = wave * SEED_LANES + (worker ? lane : 0u);
-    switch (rp.pad[0]) {  // s_setprio takes an immediate
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
+    const bool consumer = wave < 2u;
+    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1];
+    switch (prio) {  // s_setprio takes an immediate
         case 0: break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -167,36 +200,82 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_round_kernel(RenderParam
     }
     const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     const uint64_t groups = (paths + SEED_COLS - 1) / SEED_COLS;
-    constexpr int CHUNKS = (int)(SEED_LDS_BYTES / 1024) / SEED_WAVES;   // 1 KiB per wave-instruction, 80 per wave
-    for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
-        __syncthreads();   // both waves are done with the previous group's columns
-        // ---- linear copy of the group's 160 KiB state image into the LDS, all 64 lanes of both waves, asynchronous
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(minit + (size_t)g * 256 * SEED_COLS);
-#pragma unroll 8
-        for (int q = 0; q < CHUNKS; q++) {
-            const uint32_t off = (uint32_t)((wave * CHUNKS + q) * 1024);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + off + lane * 16u),
-                                             (void __attribute__((address_space(3))) *)(smem + off), 16, 0, 2 /* nt */);
+    const uint64_t G0 = groups * blockIdx.x / gridDim.x, G1 = groups * (blockIdx.x + 1) / gridDim.x;   // this workgroup's groups
+    const uint64_t first_path = G0 * SEED_COLS, end_path = G1 * SEED_COLS < paths ? G1 * SEED_COLS : paths;
+    u64 *ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
+    const IsaacWarm warm = isaac_warm();
+    typedef PcLayout<SEED_HEAD> L;
+    constexpr int SEED_SHIP_ROWS = L::SHIP_ROWS;
+    constexpr size_t SEED_HALF_WORDS = L::HALF_WORDS, SEED_GROUP_WORDS = L::GROUP_WORDS;
+    constexpr int CHUNKS = SEED_SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
+    uint64_t frontier = first_path & ~63ull;                   // first path not yet produced (chunk aligned)
+    for (uint64_t it = 0; it <= G1 - G0; it++) {
+        // ---- producers: complete group G0 + it
+        const uint64_t need = it < G1 - G0 ? (G0 + it + 1) * SEED_COLS : 0;      // paths below `need` must be in the ring
+        uint32_t n = 0;
+        while (frontier < need && frontier < end_path) {
+            if (!consumer && (n & 1u) == half) {
+                const uint64_t pid0 = frontier + lane;
+                const bool on = pid0 >= first_path && pid0 < end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
+                const uint64_t pid = pid0 >= first_path && pid0 < end_path ? pid0 : end_path - 1;
+                const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
+                uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+                uint32_t px, py, sub;
+                tile_lane_pixel(rp, tile, j, px, py, sub);
+                bool valid = px < rp.width && py < rp.height;
+                u64 s, t;
+                path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
+                const uint64_t g = pid / SEED_COLS;
+                const uint32_t c80 = (uint32_t)(pid - g * SEED_COLS);
+                RingState<SEED_HEAD> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
+                              on, lane);
+                isaac_init_tail<SEED_HEAD>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+            }
+            frontier += 64;
+            n++;
         }
-        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the wave's own pieces have landed
-        __syncthreads();
-        if (worker) {
-            const uint64_t pid = g * SEED_COLS + col;
+        // ---- consumers: group G0 + it - 1
+        if (consumer && it > 0) {
+            const uint64_t g = G0 + it - 1;
+            const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
+            unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+            const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+            u64 end8[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) end8[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
+            if (!(rp.pad[2] & 8u)) {
+                const unsigned char *srcb = reinterpret_cast<const unsigned char *>(src);
+                unsigned char *dst = lds_half + (size_t)8 * SEED_HEAD * SEED_LANES * 8;   // generator words 8*SEED_HEAD.. of every column
+#pragma unroll 8
+                for (int q = 0; q < CHUNKS; q++)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(srcb + q * 1024 + lane * 16u),
+                                                     (void __attribute__((address_space(3))) *)(dst + q * 1024), 16, 0, 2 /* nt */);
+            }
+            const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
             const bool in_range = pid < paths;
             const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
-            uint32_t tile = item / rp.num_k;
+            uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
             uint32_t px, py, sub;
             tile_lane_pixel(rp, tile, j, px, py, sub);
             bool valid = in_range && px < rp.width && py < rp.height;
-            LdsMem m{mem + col};
-            GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
-            RawLensTail<GlobalTail> lt(gt, lens_shape);
-            isaac_round(m, lt);
-            lt.lens_slow();
-            bool ok = lt.in_window();
-            if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
-            if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+            LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
+            if (lane < (uint32_t)SEED_LANES) {
+                u64 s, t;
+                path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
+                isaac_init_head<SEED_HEAD>(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, end8);   // while the fill is in flight
+            }
+            __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's half has landed (no other wave touches it)
+            if (lane < (uint32_t)SEED_LANES) {
+                GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
+                RawLensTail<GlobalTail> lt(gt, lens_shape);
+                isaac_round(m, lt);
+                lt.lens_slow();
+                bool ok = lt.in_window();
+                if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
+                if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+            }
         }
+        __syncthreads();   // group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
     }
 }
 
@@ -208,6 +287,8 @@ struct RawTail {
 struct LdsMem64 {
     u64 *col;
     __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
+    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(64 * 8); }
+    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
     __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
 };
 __global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
@@ -415,8 +496,7 @@ struct hr_ctx {
     int device = 0;
     int num_cus = 256;
     // streams: trace + post on `stream` (own or the caller's), the seed kernel of the NEXT batch on `seed_stream`,
-    // the optional init kernel (split seeding) on `init_stream`
-    hipStream_t stream = nullptr, own_stream = nullptr, seed_stream = nullptr, init_stream = nullptr;
+    hipStream_t stream = nullptr, own_stream = nullptr, seed_stream = nullptr;
     // scene
     std::vector<void *> scene_allocs;
     Scene dsc{};
@@ -431,9 +511,10 @@ struct hr_ctx {
     u64 *tails[2] = {nullptr, nullptr};
     uint32_t *lens[2] = {nullptr, nullptr};
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
-    u64 *minit[2] = {nullptr, nullptr};      // split seeding: initialised generator states, 2 KiB per path
-    size_t minit_cap = 0;
-    hipEvent_t init_done[2] = {nullptr, nullptr}, seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
+    u64 *ring = nullptr;                     // producer / consumer seeding: ring of group buffers, <= 640 KiB per CU
+    int seed_head = 16;                      // init blocks redone by the consumer (8, 12, 16, 20, 24)
+    uint32_t init_prio = 1;                  // s_setprio of the producer waves
+    hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
     bool seed_pending[2] = {false, false}, trace_pending[2] = {false, false};
     uint64_t batch_counter = 0;
     Counters *d_counters = nullptr;
@@ -448,15 +529,13 @@ struct hr_ctx {
     int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH (gpu_bvh.h); next upload
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each raw-draw buffer
-    uint64_t max_state_bytes = 40ull << 30;  // cap of each generator-state buffer (split seeding)
-    int seed_mode = 0;                       // 0 = fused seed kernel, 1 = init kernel + round kernel
-    uint32_t init_wgs_per_cu = 1;            // split seeding: resident 256-thread workgroups of the init kernel per CU
+    int seed_mode = 1;                       // 1 = producer / consumer seed kernel, 0 = fused seed kernel
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
-    int debug_skip = 0;                      // timing experiments only: 1 = skip init kernel, 2 = skip seed kernel (garbage image)
+    int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills
     // timing (HIP events around every launch, summed when the streams are drained)
-    std::vector<EventPair> seed_events, trace_events, post_events, init_events;
-    double seed_ms = 0, trace_ms = 0, post_ms = 0, init_ms = 0;
-    uint64_t seed_launches = 0, trace_launches = 0, init_launches = 0;
+    std::vector<EventPair> seed_events, trace_events, post_events;
+    double seed_ms = 0, trace_ms = 0, post_ms = 0;
+    uint64_t seed_launches = 0, trace_launches = 0;
     uint64_t paths_rendered = 0;
 };
 
@@ -491,11 +570,9 @@ static int drain_events(hr_ctx *c) {
     HIP_TRY(sum(c->seed_events, c->seed_ms));
     HIP_TRY(sum(c->trace_events, c->trace_ms));
     HIP_TRY(sum(c->post_events, c->post_ms));
-    HIP_TRY(sum(c->init_events, c->init_ms));
     return HR_OK;
 }
 static int sync_all(hr_ctx *c) {
-    HIP_TRY(hipStreamSynchronize(c->init_stream));
     HIP_TRY(hipStreamSynchronize(c->seed_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->trace_pending[0] = c->trace_pending[1] = false;
@@ -533,18 +610,20 @@ static int create_resources(hr_ctx *c) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->seed_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->init_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipEventCreateWithFlags(&c->seed_done[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->trace_done[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->init_done[i], hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(Counters)));
     HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
     HIP_TRY(hipMalloc((void **)&c->d_tile_counter, 2 * sizeof(uint32_t)));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_isaac64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)seed_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
     return HR_OK;
 }
@@ -554,24 +633,22 @@ int hr_destroy(hr_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     free_scene(c);
-    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events, &c->init_events})
+    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events})
         for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (int i = 0; i < 2; i++) {
         if (c->tails[i]) (void)hipFree(c->tails[i]);
         if (c->lens[i]) (void)hipFree(c->lens[i]);
-        if (c->minit[i]) (void)hipFree(c->minit[i]);
-        if (c->init_done[i]) (void)hipEventDestroy(c->init_done[i]);
         if (c->seed_done[i]) (void)hipEventDestroy(c->seed_done[i]);
         if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
     }
+    if (c->ring) (void)hipFree(c->ring);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->post_tmp) (void)hipFree(c->post_tmp);
     if (c->d_rgb8) (void)hipFree(c->d_rgb8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->seed_stream) (void)hipStreamDestroy(c->seed_stream);
-    if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c;
     return HR_OK;
 }
@@ -729,8 +806,8 @@ int hr_clear(hr_ctx *c) {
     HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->seed_ms = c->trace_ms = c->post_ms = c->init_ms = 0;
-    c->seed_launches = c->trace_launches = c->init_launches = 0;
+    c->seed_ms = c->trace_ms = c->post_ms = 0;
+    c->seed_launches = c->trace_launches = 0;
     c->paths_rendered = 0;
     return HR_OK;
 }
@@ -747,17 +824,6 @@ static int ensure_draws(hr_ctx *c, size_t items) {
     return HR_OK;
 }
 
-static int ensure_states(hr_ctx *c, size_t items) {
-    if (items <= c->minit_cap) return HR_OK;
-    for (int i = 0; i < 2; i++) {
-        if (c->minit[i]) { HIP_TRY(hipFree(c->minit[i])); c->minit[i] = nullptr; }
-        // items * 64 paths, rounded up to whole groups of SEED_COLS, 2 KiB each
-        HIP_TRY(hipMalloc((void **)&c->minit[i], ((items * 64 + SEED_COLS - 1) / SEED_COLS) * SEED_COLS * 256 * sizeof(u64)));
-    }
-    c->minit_cap = items;
-    return HR_OK;
-}
-
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
@@ -766,10 +832,18 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
     if (c->debug_skip & 2) {
-    } else if (c->seed_mode == 1)
-        hipLaunchKernelGGL(seed_round_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->minit[slot],
-                           c->tails[slot], c->lens[slot], c->d_counters);
-    else
+    } else if (c->seed_mode == 1) {
+        if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
+#define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->tails[slot], c->lens[slot], c->d_counters)
+        switch (c->seed_head) {
+            case 8: HR_LAUNCH_PC(8); break;
+            case 12: HR_LAUNCH_PC(12); break;
+            case 20: HR_LAUNCH_PC(20); break;
+            case 24: HR_LAUNCH_PC(24); break;
+            default: HR_LAUNCH_PC(16); break;
+        }
+#undef HR_LAUNCH_PC
+    } else
         hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot],
                            c->lens[slot], c->d_counters);
     HIP_TRY(hipGetLastError());
@@ -793,6 +867,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
     rp.pad[0] = c->seed_prio;
+    rp.pad[1] = c->init_prio;
+    rp.pad[2] = (uint32_t)c->debug_skip;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     // the raw-draw hand-off costs 32 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
     uint32_t batch = std::max<uint32_t>(1, c->batch);
@@ -800,14 +876,9 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         uint64_t per_sampling = (uint64_t)tiles * ISAAC_TAIL * 64 * sizeof(u64);
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
         batch = (uint32_t)std::min<uint64_t>(batch, fit);
-        if (c->seed_mode == 1) {
-            uint64_t fit2 = std::max<uint64_t>(1, c->max_state_bytes / std::max<uint64_t>(1, per_sampling * 4));  // 128 KiB per item
-            batch = (uint32_t)std::min<uint64_t>(batch, fit2);
-        }
     }
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
-    if (c->seed_mode == 1 && (rc = ensure_states(c, (size_t)tiles * batch))) return rc;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
         rp.sampling_begin = s_begin + done * stride;
@@ -816,23 +887,6 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         c->batch_counter++;
         hipStream_t sstream = c->seed_stream;  // (alternating two seed streams to overlap kernel tails was measured: no gain)
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
-        if (c->seed_mode == 1) {
-            // init kernel of this batch: its state buffer was last read by the round kernel two batches ago
-            if (c->seed_pending[slot]) HIP_TRY(hipStreamWaitEvent(c->init_stream, c->seed_done[slot], 0));
-            uint64_t paths = (uint64_t)tiles * nk * 64u;
-            EventPair iev;
-            HIP_TRY(hipEventCreate(&iev.a));
-            HIP_TRY(hipEventCreate(&iev.b));
-            HIP_TRY(hipEventRecord(iev.a, c->init_stream));
-            uint32_t igrid = (uint32_t)std::min<uint64_t>((paths + 255) / 256, (uint64_t)c->num_cus * c->init_wgs_per_cu);
-            if (!(c->debug_skip & 1)) hipLaunchKernelGGL(seed_init_kernel, dim3(igrid), dim3(256), 0, c->init_stream, rp, c->minit[slot]);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(iev.b, c->init_stream));
-            c->init_events.push_back(iev);
-            c->init_launches++;
-            HIP_TRY(hipEventRecord(c->init_done[slot], c->init_stream));
-            HIP_TRY(hipStreamWaitEvent(sstream, c->init_done[slot], 0));
-        }
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(sstream, c->trace_done[slot], 0));
         if ((rc = launch_seed(c, rp, slot, sstream))) return rc;
         HIP_TRY(hipEventRecord(c->seed_done[slot], sstream));
@@ -943,7 +997,6 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow;
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
-    out->init_kernel_ms = c->init_ms; out->init_launches = c->init_launches;
     out->bvh_build_ms = c->bvh_build_ms;
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
@@ -982,14 +1035,19 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->seed_prio = (uint32_t)value;
         return HR_OK;
     }
-    if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
-    if (k == "init_wgs_per_cu") {
-        if (value < 1 || value > 8) return fail(HR_ERR_INVALID, "init_wgs_per_cu must be in [1,8]");
-        c->init_wgs_per_cu = (uint32_t)value;
+    if (k == "seed_head") {
+        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24) return fail(HR_ERR_INVALID, "seed_head must be 8, 12, 16, 20 or 24");
+        c->seed_head = (int)value;
         return HR_OK;
     }
+    if (k == "init_prio") {
+        if (value < 0 || value > 3) return fail(HR_ERR_INVALID, "init_prio must be in [0,3]");
+        c->init_prio = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
     if (k == "seed_mode") {
-        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "seed_mode must be 0 (fused) or 1 (init + round kernels)");
+        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "seed_mode must be 1 (producer / consumer waves, default) or 0 (fused kernel)");
         int rc = sync_all(c);
         if (rc) return rc;
         c->seed_mode = (int)value;

@@ -50,7 +50,8 @@ HD double isaac_to_f64(u64 v) {
 // The two init passes of `Isaac64Rng::init(true)` WITHOUT a 2 KiB scratch array: pass 2 needs the end state of
 // pass 1 before it can start, so pass 1 is run once "dry" (registers only) and then regenerated block by block
 // next to pass 2.  96 mixes instead of 64, but no LDS: this is what lets the init run at full occupancy in its own
-// kernel while the LDS-bound round kernel only has to load the result.  Out: void st(int i, u64 v), i = 0..255.
+// kernel / wave while the LDS-bound round only has to load the result.  Out: void st2(int i, u64 v0, u64 v1) stores
+// words i (even) and i + 1.
 template <class Out>
 HD void isaac_init_final(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3) {
     u64 a = w.r[0] + s0, b = w.r[1] + s1, c = w.r[2] + s2, d = w.r[3] + s3, e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
@@ -63,12 +64,51 @@ HD void isaac_init_final(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u
         HR_ISAAC_MIX(a, b, c, d, e, f, g, h)                       // pass-1 block: what rsl-pass stored in mem[i..i+8)
         A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
         HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
-        out.st(i, A); out.st(i + 1, B); out.st(i + 2, C); out.st(i + 3, D);
-        out.st(i + 4, E); out.st(i + 5, F); out.st(i + 6, G); out.st(i + 7, H);
+        out.st2(i, A, B); out.st2(i + 2, C, D); out.st2(i + 4, E, F); out.st2(i + 6, G, H);
     }
 }
 
-// Mem: u64 ld(int i) / void st(int i, u64 v).  Tail: void put(int step, u64 value) for step >= 256 - ISAAC_TAIL.
+// isaac_init_final cut in two for the producer / consumer seed kernel: the PRODUCER (isaac_init_tail) runs the dry pass 1
+// and the whole pass-2 sweep but stores only blocks >= HEAD plus the pass-1 end state (8 words, out.end2); the CONSUMER
+// (isaac_init_head) redoes blocks < HEAD from that end state straight into its generator memory while the stored part is
+// still in flight.  Together they produce exactly the state of isaac_init_final; what travels shrinks to (32 - HEAD) / 32.
+template <int HEAD, class Out>
+HD void isaac_init_tail(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3) {
+    u64 a = w.r[0] + s0, b = w.r[1] + s1, c = w.r[2] + s2, d = w.r[3] + s3, e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
+    HR_NOUNROLL
+    for (int i = 0; i < 32; i++) { HR_ISAAC_MIX(a, b, c, d, e, f, g, h) }
+    u64 A = a, B = b, C = c, D = d, E = e, F = f, G = g, H = h;
+    out.end2(0, A, B); out.end2(2, C, D); out.end2(4, E, F); out.end2(6, G, H);
+    a = w.r[0] + s0; b = w.r[1] + s1; c = w.r[2] + s2; d = w.r[3] + s3; e = w.r[4]; f = w.r[5]; g = w.r[6]; h = w.r[7];
+    HR_NOUNROLL
+    for (int i = 0; i < 8 * HEAD; i += 8) {
+        HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
+        A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
+        HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
+    }
+    HR_NOUNROLL
+    for (int i = 8 * HEAD; i < 256; i += 8) {
+        HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
+        A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
+        HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
+        out.st2(i, A, B); out.st2(i + 2, C, D); out.st2(i + 4, E, F); out.st2(i + 6, G, H);
+    }
+}
+template <int HEAD, class Mem>
+HD void isaac_init_head(Mem &mem, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3, const u64 *end8) {
+    u64 a = w.r[0] + s0, b = w.r[1] + s1, c = w.r[2] + s2, d = w.r[3] + s3, e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
+    u64 A = end8[0], B = end8[1], C = end8[2], D = end8[3], E = end8[4], F = end8[5], G = end8[6], H = end8[7];
+    HR_NOUNROLL
+    for (int i = 0; i < 8 * HEAD; i += 8) {
+        HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
+        A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
+        HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
+        mem.st(i, A); mem.st(i + 1, B); mem.st(i + 2, C); mem.st(i + 3, D);
+        mem.st(i + 4, E); mem.st(i + 5, F); mem.st(i + 6, G); mem.st(i + 7, H);
+    }
+}
+
+// Mem: u64 ld(int i) / void st(int i, u64 v) / uint32_t off(int i) + u64 ldo(uint32_t) (offset of word i, load from it).  Tail: void put(int step, u64 value) for step >= 256 - ISAAC_TAIL.
 template <class Mem, class Tail>
 HD void isaac_round(Mem &mem, Tail &tail);
 
@@ -95,64 +135,96 @@ HD void isaac_seed_round(Mem &mem, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u
     isaac_round(mem, tail);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_OPAQUE64(v) asm volatile("" : "+v"(v))   // keeps an off-chain partial sum from being re-associated onto the serial chain
+#define HR_OPAQUE32(p) asm volatile("" : "+v"(p))
+#define HR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // nothing is scheduled across: keeps off-chain work out of the chain
+#else
+#define HR_OPAQUE64(v)
+#define HR_OPAQUE32(p)
+#define HR_SCHED_FENCE()
+#endif
+
 template <class Mem, class Tail>
 HD void isaac_round(Mem &mem, Tail &tail) {
-    // one isaac64() round: a = b = 0, c = 1  ->  aa = 0, bb = 1.
-    // Step n (0..255) reads x = mem[n] and mem[(n+128)&255], gathers mem[(x>>3)&255], stores y to mem[n],
-    // gathers mem[(y>>11)&255].  The only serial chain is bb -> y -> second gather -> bb; everything else
-    // (x two steps ahead, the +128 operand and the first gather of the NEXT step) is issued in the same
-    // batch as the second gather, so a step costs one LDS round trip.  The two halves of the reference
-    // loop are kept as two loops so that every static index is affine in the loop counter (no "& 255").
-    u64 aa = 0, bb = 1;
-    u64 x = mem.ld(0), xn = mem.ld(1), m2v = mem.ld(128);
+    // one isaac64() round: a = b = 0, c = 1  ->  aa = 0, bb = 1.  Reference step n:
+    //     x = mem[n]; aa = mix(aa) + mem[(n+128)&255]; y = mem[(x>>3)&255] + aa + bb; mem[n] = y; bb = mem[(y>>11)&255] + x; out[n] = bb
+    // With g1_n = mem[(x_n>>3)&255] (read after the store of y_{n-1}) and g2_n = mem[(y_n>>11)&255] (read after the store of
+    // y_n):  y_{n+1} = (g1_{n+1} + aa_{n+1} + x_n) + g2_n.  The bracket T_{n+1} does not depend on g2_n, so the only serial
+    // chain is  g2 arrives -> ONE 64-bit add -> store -> index of the next g2 -> LDS round trip.  g1_{n+1} is issued between
+    // the store of y_n and the g2_n gather (its address is known early), so it is back first; x three steps ahead and the
+    // +128 operand ride in the same LDS batch.  The two halves of the reference loop are kept as two loops so that every
+    // static index is affine in the loop counter (no "& 255").  out[n] = g2_n + x_n is formed one step later, off the chain.
+    u64 aa = 0;
+    u64 x = mem.ld(0), xn = mem.ld(1), xnn = mem.ld(2), m2v = mem.ld(128);
     u64 g1 = mem.ld((int)((x >> 3) & 255));
-#define HR_ISAAC_STEP(N, MIXEXPR, XNN_IDX, M2N_IDX, TAIL)                 \
-    {                                                                     \
-        u64 mixv = MIXEXPR;                                               \
-        aa = mixv + m2v;                                                  \
-        u64 y = g1 + aa + bb;                                             \
-        mem.st(N, y);                                                     \
-        u64 g2 = mem.ld((int)((y >> 11) & 255));                          \
-        g1 = mem.ld((int)((xn >> 3) & 255));                              \
-        u64 xnn = mem.ld(XNN_IDX);                                        \
-        m2v = mem.ld(M2N_IDX);                                            \
-        bb = g2 + x;                                                      \
-        if (TAIL) tail.put(N, bb);                                        \
-        x = xn; xn = xnn;                                                 \
+    // step 0's T: y_0 = g1_0 + aa_0 + bb with bb = 1 and aa_0 = mix(0) + mem[128]
+    aa = ~(aa ^ (aa << 21)) + m2v;
+    m2v = mem.ld(129);
+    u64 T = g1 + aa + 1, g2 = 0, xprev = 0;
+    uint32_t p1 = mem.off((int)((xn >> 3) & 255));   // where g1 of the next step lives (known early)
+#define HR_ISAAC_STEP(N, MIXEXPR_NEXT, XN3_IDX, M2N_IDX, TAIL, TAILPREV)                                               \
+    {                                                                                                                  \
+        HR_OPAQUE32(p1);                                                                                               \
+        HR_SCHED_FENCE();                                                                                              \
+        u64 y = T + g2;                            /* the chain: one add after g2_{N-1} is back */                      \
+        mem.st(N, y);                                                                                                  \
+        g1 = mem.ldo(p1);                          /* g1_{N+1}: after the store of y_N, before the g2_N gather */        \
+        u64 g2n = mem.ld((int)((y >> 11) & 255));                                                                      \
+        HR_SCHED_FENCE();                                                                                              \
+        if (TAILPREV) tail.put((N) - 1, g2 + xprev);                                                                   \
+        g2 = g2n;                                                                                                      \
+        p1 = mem.off((int)((xnn >> 3) & 255));                                                                         \
+        u64 xn3 = mem.ld(XN3_IDX);                                                                                     \
+        u64 m2n = mem.ld(M2N_IDX);                                                                                     \
+        aa = (MIXEXPR_NEXT) + m2v;                 /* aa_{N+1} */                                                       \
+        T = g1 + (aa + x);                         /* T_{N+1} = g1_{N+1} + aa_{N+1} + x_N */                             \
+        HR_OPAQUE64(T);                                                                                                \
+        xprev = x; x = xn; xn = xnn; xnn = xn3; m2v = m2n;                                                             \
     }
-    // first half: n in [0,128): x from mem[n..], +128 operand from mem[n+128..]; the last group is peeled
-    // because its "next" +128 operand is mem[0]
+    // mix schedule: aa_{n+1} uses the mix of step n+1: n+1 = 0 mod 4: ~(a ^ a<<21), 1: a ^ a>>5, 2: a ^ a<<12, 3: a ^ a>>33
+    // first half: n in [0,128): x from mem[n..], +128 operand from mem[n+128..]; the last groups are peeled because their
+    // look-ahead operands wrap
+    HR_ISAAC_STEP(0, aa ^ (aa >> 5), 3, 130, false, false)
+    HR_ISAAC_STEP(1, aa ^ (aa << 12), 4, 131, false, false)
+    HR_ISAAC_STEP(2, aa ^ (aa >> 33), 5, 132, false, false)
+    HR_ISAAC_STEP(3, ~(aa ^ (aa << 21)), 6, 133, false, false)
     HR_NOUNROLL
-    for (int n = 0; n < 124; n += 4) {
-        HR_ISAAC_STEP(n, ~(aa ^ (aa << 21)), n + 2, n + 129, false)
-        HR_ISAAC_STEP(n + 1, aa ^ (aa >> 5), n + 3, n + 130, false)
-        HR_ISAAC_STEP(n + 2, aa ^ (aa << 12), n + 4, n + 131, false)
-        HR_ISAAC_STEP(n + 3, aa ^ (aa >> 33), n + 5, n + 132, false)
+    for (int n = 4; n < 124; n += 4) {
+        HR_ISAAC_STEP(n, aa ^ (aa >> 5), n + 3, n + 130, false, false)
+        HR_ISAAC_STEP(n + 1, aa ^ (aa << 12), n + 4, n + 131, false, false)
+        HR_ISAAC_STEP(n + 2, aa ^ (aa >> 33), n + 5, n + 132, false, false)
+        HR_ISAAC_STEP(n + 3, ~(aa ^ (aa << 21)), n + 6, n + 133, false, false)
     }
-    HR_ISAAC_STEP(124, ~(aa ^ (aa << 21)), 126, 253, false)
-    HR_ISAAC_STEP(125, aa ^ (aa >> 5), 127, 254, false)
-    HR_ISAAC_STEP(126, aa ^ (aa << 12), 128, 255, false)
-    HR_ISAAC_STEP(127, aa ^ (aa >> 33), 129, 0, false)
+    HR_ISAAC_STEP(124, aa ^ (aa >> 5), 127, 254, false, false)
+    HR_ISAAC_STEP(125, aa ^ (aa << 12), 128, 255, false, false)
+    HR_ISAAC_STEP(126, aa ^ (aa >> 33), 129, 0, false, false)       // m2v for step 128 is mem[0]
+    HR_ISAAC_STEP(127, ~(aa ^ (aa << 21)), 130, 1, false, false)
     // second half: n in [128,256): +128 operand from mem[n-128..]
     HR_NOUNROLL
     for (int n = 128; n < 256 - ISAAC_TAIL; n += 4) {
-        HR_ISAAC_STEP(n, ~(aa ^ (aa << 21)), n + 2, n - 127, false)
-        HR_ISAAC_STEP(n + 1, aa ^ (aa >> 5), n + 3, n - 126, false)
-        HR_ISAAC_STEP(n + 2, aa ^ (aa << 12), n + 4, n - 125, false)
-        HR_ISAAC_STEP(n + 3, aa ^ (aa >> 33), n + 5, n - 124, false)
+        HR_ISAAC_STEP(n, aa ^ (aa >> 5), n + 3, n - 126, false, false)
+        HR_ISAAC_STEP(n + 1, aa ^ (aa << 12), n + 4, n - 125, false, false)
+        HR_ISAAC_STEP(n + 2, aa ^ (aa >> 33), n + 5, n - 124, false, false)
+        HR_ISAAC_STEP(n + 3, ~(aa ^ (aa << 21)), n + 6, n - 123, false, false)
     }
+    HR_ISAAC_STEP(256 - ISAAC_TAIL, aa ^ (aa >> 5), 256 - ISAAC_TAIL + 3, 256 - ISAAC_TAIL - 126, true, false)
+    HR_ISAAC_STEP(256 - ISAAC_TAIL + 1, aa ^ (aa << 12), 256 - ISAAC_TAIL + 4, 256 - ISAAC_TAIL - 125, true, true)
+    HR_ISAAC_STEP(256 - ISAAC_TAIL + 2, aa ^ (aa >> 33), 256 - ISAAC_TAIL + 5, 256 - ISAAC_TAIL - 124, true, true)
+    HR_ISAAC_STEP(256 - ISAAC_TAIL + 3, ~(aa ^ (aa << 21)), 256 - ISAAC_TAIL + 6, 256 - ISAAC_TAIL - 123, true, true)
     HR_NOUNROLL
-    for (int n = 256 - ISAAC_TAIL; n < 252; n += 4) {
-        HR_ISAAC_STEP(n, ~(aa ^ (aa << 21)), n + 2, n - 127, true)
-        HR_ISAAC_STEP(n + 1, aa ^ (aa >> 5), n + 3, n - 126, true)
-        HR_ISAAC_STEP(n + 2, aa ^ (aa << 12), n + 4, n - 125, true)
-        HR_ISAAC_STEP(n + 3, aa ^ (aa >> 33), n + 5, n - 124, true)
+    for (int n = 256 - ISAAC_TAIL + 4; n < 252; n += 4) {
+        HR_ISAAC_STEP(n, aa ^ (aa >> 5), n + 3, n - 126, true, true)
+        HR_ISAAC_STEP(n + 1, aa ^ (aa << 12), n + 4, n - 125, true, true)
+        HR_ISAAC_STEP(n + 2, aa ^ (aa >> 33), n + 5, n - 124, true, true)
+        HR_ISAAC_STEP(n + 3, ~(aa ^ (aa << 21)), n + 6, n - 123, true, true)
     }
     // last group: the look-ahead loads past the end are never used; point them at valid slots
-    HR_ISAAC_STEP(252, ~(aa ^ (aa << 21)), 254, 125, true)
-    HR_ISAAC_STEP(253, aa ^ (aa >> 5), 255, 126, true)
-    HR_ISAAC_STEP(254, aa ^ (aa << 12), 255, 127, true)
-    HR_ISAAC_STEP(255, aa ^ (aa >> 33), 255, 127, true)
+    HR_ISAAC_STEP(252, aa ^ (aa >> 5), 255, 126, true, true)
+    HR_ISAAC_STEP(253, aa ^ (aa << 12), 255, 127, true, true)
+    HR_ISAAC_STEP(254, aa ^ (aa >> 33), 255, 127, true, true)
+    HR_ISAAC_STEP(255, ~(aa ^ (aa << 21)), 255, 127, true, true)
+    tail.put(255, g2 + xprev);
 #undef HR_ISAAC_STEP
 }
 

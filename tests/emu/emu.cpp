@@ -23,7 +23,14 @@ using namespace hr;
 
 struct emu_scene { HostScene hs; Scene view; };
 
-struct ArrMem { u64 m[256]; u64 ld(int i) const { return m[i]; } void st(int i, u64 v) { m[i] = v; } };
+struct ArrMem {
+    u64 m[256];
+    u64 ld(int i) const { return m[i]; }
+    uint32_t off(int i) const { return (uint32_t)i; }
+    u64 ldo(uint32_t o) const { return m[o]; }
+    void st(int i, u64 v) { m[i] = v; }
+    void st2(int i, u64 v0, u64 v1) { m[i] = v0; m[i + 1] = v1; }
+};
 struct ArrStore { u64 t[ISAAC_TAIL]; u64 ld(int k) const { return t[k]; } void st(int k, u64 v) { t[k] = v; } };
 
 // what the seed kernel produces for one path: raw tail + accepted lens attempt
@@ -47,6 +54,27 @@ static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_
     out20[1] = draw_lens_f32(st.t[2 * a + 1]);
     for (int d = 2; d < DRAWS_PER_PATH; d++) out20[d] = draw_f32(st.t[2 * a + d]);
     return ok;
+}
+
+struct RawTailPc { uint64_t *out; int window; void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; } };
+// same again through the producer / consumer split (isaac_init_tail stores blocks >= HEAD + the pass-1 end state,
+// isaac_init_head redoes the rest), then isaac_round
+struct TailSink {
+    u64 m[256]; u64 end[8];
+    void st2(int i, u64 v0, u64 v1) { m[i] = v0; m[i + 1] = v1; }
+    void end2(int j, u64 v0, u64 v1) { end[j] = v0; end[j + 1] = v1; }
+};
+template <int HEAD>
+static void raw_draws_pc(u64 s, u64 t, uint32_t sampling, int window, uint64_t *out) {
+    static const IsaacWarm warm = isaac_warm();
+    TailSink sink;
+    for (int i = 0; i < 256; i++) sink.m[i] = 0xdeadbeefdeadbeefULL;
+    isaac_init_tail<HEAD>(sink, warm, 8700304ULL, (u64)sampling, s, t);
+    ArrMem mem;
+    for (int i = 0; i < 256; i++) mem.st(i, sink.m[i]);
+    isaac_init_head<HEAD>(mem, warm, 8700304ULL, (u64)sampling, s, t, sink.end);
+    RawTailPc rt{out, window};
+    isaac_round(mem, rt);
 }
 
 extern "C" {
@@ -158,6 +186,19 @@ int emu_raw_draws_split(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     RawTail rt{out, window};
     isaac_round(mem, rt);
     return 0;
+}
+
+int emu_raw_draws_pc(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int window, int head, uint64_t *out) {
+    u64 s, t;
+    path_seed_words(W, H, px, py, sub, s, t);
+    switch (head) {
+        case 0: raw_draws_pc<0>(s, t, sampling, window, out); return 0;
+        case 8: raw_draws_pc<8>(s, t, sampling, window, out); return 0;
+        case 16: raw_draws_pc<16>(s, t, sampling, window, out); return 0;
+        case 24: raw_draws_pc<24>(s, t, sampling, window, out); return 0;
+        case 32: raw_draws_pc<32>(s, t, sampling, window, out); return 0;
+        default: return 1;
+    }
 }
 
 // counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests

@@ -191,7 +191,7 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 0), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("rng_window", 32)]:
+    for key, bad in [("batch", 0), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_head", 10), ("bvh_builder", 2), ("rng_window", 32)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
     with pytest.raises(ha.HipError):
@@ -292,22 +292,32 @@ def test_cli_checkpoint_resume_and_debug(tmp_path):
     assert img.shape == (36, 64, 3) and img.std() > 5
 
 
-def test_split_seeding_is_bit_identical(gpu, scenes):
-    """seed_mode 1 (scratch-free init kernel + LDS round kernel) must hand the trace kernel exactly the draws of
-    seed_mode 0 (fused kernel): same raw tails -> the accumulators agree up to the atomics' fp32 summation order."""
+def test_seed_kernels_are_bit_identical(gpu, scenes):
+    """The producer / consumer seed kernel (seed_mode 1, default: init in registers on producer waves, only the blocks
+    >= seed_head travel through the ring, the consumer redoes the rest and runs the round) must hand the trace kernel
+    exactly the draws of the fused kernel (seed_mode 0): same raw tails -> the accumulators agree up to the atomics'
+    fp32 summation order."""
     sc, _ = scenes("rtcamp6_v3_1")
     gpu.upload_scene(sc)
-    gpu.set_resolution(130, 71)        # ragged: tiles hang over the right and bottom edges
-    import ctypes as C
     outs = []
-    for mode in (0, 1):
-        gpu.set_option("seed_mode", mode)
-        gpu.clear()
-        gpu.render(1, 6)
-        outs.append(gpu.read_accumulator().astype(np.float64))
-    gpu.set_option("seed_mode", 0)
-    assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max())
-    assert outs[0].sum() > 0
+    try:
+        for (w, h, s) in [(130, 71, 6), (640, 360, 9)]:   # ragged: tiles hang over the right and bottom edges; many groups per CU
+            gpu.set_resolution(w, h)
+            ref = None
+            for mode, head in [(0, 16), (1, 16), (1, 8), (1, 24)]:
+                gpu.set_option("seed_mode", mode)
+                gpu.set_option("seed_head", head)
+                gpu.clear()
+                gpu.render(1, s + 1)
+                acc = gpu.read_accumulator().astype(np.float64)
+                if ref is None:
+                    ref = acc
+                    assert ref.sum() > 0
+                else:
+                    assert np.abs(ref - acc).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (w, h, mode, head)
+    finally:
+        gpu.set_option("seed_mode", 1)
+        gpu.set_option("seed_head", 16)
 
 
 def test_bench_multirank_path_on_one_gpu(tmp_path):

@@ -67,6 +67,9 @@ def test_kernel_generator_core_matches_oracle(emu, orc):
             assert np.array_equal(emu.raw_draws(w, h, x, y, sub, s, 64), ref)
             # split form: scratch-free init (pass 1 regenerated next to pass 2) + round on the loaded state
             assert np.array_equal(emu.raw_draws_split(w, h, x, y, sub, s, 64), ref)
+            # producer / consumer form: the producer ships blocks >= HEAD + the pass-1 end state, the consumer redoes the rest
+            for head in (0, 8, 16, 24, 32):
+                assert np.array_equal(emu.raw_draws_pc(w, h, x, y, sub, s, head, 64), ref)
 
 
 def test_kernel_lens_rejection_matches_oracle(emu, orc):

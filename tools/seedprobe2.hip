@@ -3,7 +3,8 @@
 #include <cstdio>
 #include "isaac_core.h"
 using namespace hr;
-struct LdsMem { u64 *col; __device__ u64 ld(int i) const { return col[i * 64]; } __device__ void st(int i, u64 v) { col[i * 64] = v; } };
+struct LdsMem { u64 *col; __device__ u64 ld(int i) const { return col[i * 64]; } __device__ uint32_t off(int i) const { return (uint32_t)i * (uint32_t)(64 * 8); }
+    __device__ u64 ldo(uint32_t o) const { return *reinterpret_cast<const u64 *>(reinterpret_cast<const unsigned char *>(col) + o); } __device__ void st(int i, u64 v) { col[i * 64] = v; } };
 struct Sink { u64 acc; __device__ void put(int, u64 v) { acc ^= v; } };
 
 // 1 wave of 64 lanes  vs  2 waves with 32 active lanes each (same 64 LDS columns)
