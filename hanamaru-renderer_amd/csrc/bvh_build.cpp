@@ -169,8 +169,8 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
     if (prims.empty()) {
         // a single box that nothing hits
         Node n{};
-        n.bmin[0] = n.bmin[1] = n.bmin[2] = 1e30f;
-        n.bmax[0] = n.bmax[1] = n.bmax[2] = -1e30f;
+        const float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+        node_set_box(n, mn, mx, 0);   // near > far on every axis: nothing hits it in any octant
         n.a = NODE_END; n.b = NODE_END;
         out.nodes.assign(8, n);
         out.num_nodes = 1;
@@ -197,7 +197,9 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
         Node *nd = &out.nodes[(size_t)o * N];
         for (size_t i = 0; i < N; i++) {
             const BNode &bn = b.nodes[i];
-            for (int a = 0; a < 3; a++) { nd[i].bmin[a] = round_down(bn.box.mn[a], 2); nd[i].bmax[a] = round_up(bn.box.mx[a], 2); }
+            float mn[3], mx[3];
+            for (int a = 0; a < 3; a++) { mn[a] = round_down(bn.box.mn[a], 2); mx[a] = round_up(bn.box.mx[a], 2); }
+            node_set_box(nd[i], mn, mx, o);
         }
         // iterative assignment of the successors with an explicit stack of (node, next_after_subtree)
         std::vector<std::pair<int, uint32_t>> st;

@@ -1,6 +1,6 @@
 // Device-side scene layout (fp32, SoA-ish, all in HBM; the geometry part is ~1 MB and lives in L2).
 //
-//   nodes[o][]   32 B   one AABB + the two successors of the node for ray-direction octant o (stackless
+//   nodes[o][]   32 B   one AABB as near / far planes for octant o (see Node) + the two successors of the node for ray-direction octant o (stackless
 //                       threaded traversal, near child first by the sign of the ray direction on the split
 //                       axis).  One record = two 16-byte loads; the 8 octant copies (8 x ~350 KB) stay in L2.
 //   tris[]       48 B   leaf-ordered: v0, e1 = v1-v0, e2 = v2-v0 (edges formed in f64, then rounded) + element id
@@ -24,12 +24,21 @@ namespace hr {
 
 struct alignas(16) f4 { float x, y, z, w; };
 
+// The box is stored per ray-direction octant as NEAR and FAR planes (near = min where the ray travels in +axis, max where it
+// travels in -axis), in the pairs the slab test consumes with packed fp32 math (v_pk_add_f32 / v_pk_mul_f32):
+// {near.x, near.y} {far.x, far.y} | {near.z, far.z} a b — two 16-byte loads.  Entry distance = max3 of the near terms, exit
+// distance = min3 of the far terms: no per-axis min / max (bvh.rs:26-33 needs them because it does not know the direction).
 struct alignas(16) Node {
-    float bmin[3];
+    float nearx, neary, farx, fary;
+    float nearz, farz;
     uint32_t a;       // box hit -> inner: next node; leaf: (type+1) << 28 | count << 20 | first  (type: 0 tri, 1 sphere, 2 cuboid)
-    float bmax[3];
     uint32_t b;       // box missed (or leaf done) -> next node in this octant's order, NODE_END = finished
 };
+HD void node_set_box(Node &n, const float *mn, const float *mx, int octant) {
+    n.nearx = (octant & 1) ? mx[0] : mn[0]; n.farx = (octant & 1) ? mn[0] : mx[0];
+    n.neary = (octant & 2) ? mx[1] : mn[1]; n.fary = (octant & 2) ? mn[1] : mx[1];
+    n.nearz = (octant & 4) ? mx[2] : mn[2]; n.farz = (octant & 4) ? mn[2] : mx[2];
+}
 HD bool node_word_is_leaf(uint32_t a) { return (a >> 28) != 0u && a != 0xffffffffu; }
 static const uint32_t NODE_END = 0xffffffffu;
 

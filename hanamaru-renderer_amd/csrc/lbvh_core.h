@@ -161,7 +161,9 @@ HD float pad_up(float v) { return nextafterf(nextafterf(v, INFINITY), INFINITY);
 // record of node i for ray-direction octant o.  Nodes below a collapsed ancestor are unreachable; their records are inert.
 HD Node emit_node(int n, int i, int o, const Work &w) {
     Node nd;
-    for (int a = 0; a < 3; a++) { nd.bmin[a] = pad_down(w.bmin[i * 3 + a]); nd.bmax[a] = pad_up(w.bmax[i * 3 + a]); }  // slack like bvh_build.cpp
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = pad_down(w.bmin[i * 3 + a]); mx[a] = pad_up(w.bmax[i * 3 + a]); }  // slack like bvh_build.cpp
+    node_set_box(nd, mn, mx, o);
     uint32_t word = w.word[i];
     if (word) nd.a = word;
     else {

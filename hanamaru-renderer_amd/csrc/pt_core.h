@@ -58,6 +58,7 @@ static const float EPS_F = 1e-4f;      // config.rs:7-8
 static const float OFFSET_F = 1e-4f;
 static const float T_INF = 3.0e38f;    // config.rs:9 INF = 1e100 (f64); fp32 stand-in
 
+typedef float f2v __attribute__((vector_size(8)));   // one packed-fp32 operand (v_pk_add_f32 / v_pk_mul_f32 on gfx950)
 struct Ray {
     V3f o, d, inv;
     uint32_t oct;     // direction octant (bit k set = component k negative)
@@ -65,7 +66,9 @@ struct Ray {
 HD void ray_set(Ray &r, V3f o, V3f d) {
     r.o = o; r.d = d;
     r.inv = v3(HR_RCP(d.x), HR_RCP(d.y), HR_RCP(d.z));  // bvh.rs:21-25 (±inf for zero components)
-    r.oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    // by SIGN BIT (so that -0.0, whose reciprocal is -inf, counts as negative): the near / far planes of the per-octant
+    // nodes must agree with the sign of r.inv
+    r.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u);
 }
 
 struct TraceState {
@@ -144,7 +147,16 @@ HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *
     const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
     if (CNT) cn->node_tests++;
     float tmin, tmax;
-    const bool hit = slab(nd.bmin, nd.bmax, r, tmin, tmax) && tmin <= ts.t;
+    // slab test of bvh.rs:20-39 with the planes already sorted along the ray (near / far per octant, device_scene.h): entry
+    // distance = max of the near terms, exit distance = min of the far terms.  A NaN term (origin exactly on a plane the ray
+    // runs parallel to) is ignored by max3 / min3, which keeps the test conservative.  Packed pairs: three subtracts, three
+    // multiplies.
+    const f2v oxy = {r.o.x, r.o.y}, ozz = {r.o.z, r.o.z}, ixy = {r.inv.x, r.inv.y}, izz = {r.inv.z, r.inv.z};
+    const f2v nxy = {nd.nearx, nd.neary}, fxy = {nd.farx, nd.fary}, zz = {nd.nearz, nd.farz};
+    const f2v tn = (nxy - oxy) * ixy, tf = (fxy - oxy) * ixy, tz = (zz - ozz) * izz;
+    tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
+    tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
+    const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
     const bool leaf = node_word_is_leaf(nd.a);
     ts.cur = (hit && !leaf) ? nd.a : nd.b;
     ts.leaf = (hit && leaf) ? nd.a : 0u;
