@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--seed-prio", type=int, default=-1)
     ap.add_argument("--init-prio", type=int, default=-1)
-    ap.add_argument("--seed-head", type=int, default=-1)
+    ap.add_argument("--seed-split", type=int, default=-1)
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
@@ -110,8 +110,8 @@ def main():
         r.set_option("seed_mode", args.seed_mode)
     if args.seed_prio >= 0:
         r.set_option("seed_prio", args.seed_prio)
-    if args.seed_head >= 0:
-        r.set_option("seed_head", args.seed_head)
+    if args.seed_split >= 0:
+        r.set_option("seed_split", args.seed_split)
     if args.init_prio >= 0:
         r.set_option("init_prio", args.init_prio)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)

@@ -135,22 +135,22 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
 // (consumers) fill their half of the LDS from the ring with straight global_load_lds copies and run the round on 40
 // lanes each.  A generator state then sits in LDS only for fill + round (~2/3 of the fused kernel's residency, and LDS
 // capacity is what bounds seeding), and the init runs on full waves.
-// The ring traffic is what this costs (it slows the trace kernel next door), so only the blocks >= SEED_HEAD of a state
-// travel: the consumer recomputes blocks < SEED_HEAD from the pass-1 end state (8 words) while its fill is in flight
-// (isaac_init_head / isaac_init_tail).
-// Group buffer, per half: [row = 0 .. SEED_RING_ROWS)[40 columns] u64; rows 0 .. 256 - 8*SEED_HEAD are the LDS image of
-// generator words 8*SEED_HEAD .. 255, the last 8 rows hold the pass-1 end state.  One __syncthreads per group: in
+// The ring traffic is what this costs (it slows the trace kernel next door), so the producers stop after SPLIT of the 32
+// init blocks and ship those plus the 16 registers the sweep continues from; the consumer does blocks >= SPLIT itself
+// while its fill is in flight (isaac_init_front / isaac_init_back) — no mix is computed twice.
+// Group buffer, per half: [row = 0 .. RING_ROWS)[40 columns] u64; rows 0 .. 8*SPLIT are the LDS image of generator words
+// 0 .. 8*SPLIT - 1, the last 16 rows hold the registers.  One __syncthreads per group: in
 // iteration `it` the consumers work on group it-1 while the producers complete group `it` (5 chunks per 4 groups).
-template <int HEAD>   // blocks (of 8 words) redone by the consumer; even
+template <int SPLIT>   // init blocks (of 8 words) done by the producer; even
 struct PcLayout {
-    static const int SHIP_ROWS = 256 - 8 * HEAD;
-    static const int RING_ROWS = SHIP_ROWS + 8;
+    static const int SHIP_ROWS = 8 * SPLIT;
+    static const int RING_ROWS = SHIP_ROWS + 16;
     static const size_t HALF_WORDS = (size_t)RING_ROWS * SEED_LANES;    // u64 per half in the ring
     static const size_t GROUP_WORDS = 2 * HALF_WORDS;
     static_assert((SHIP_ROWS * SEED_LANES * 8) % 1024 == 0, "fill copies 1 KiB per wave instruction");
 };
 static const int SEED_RING_GROUPS = 4;                                   // group g lives in buffer g & 3
-static const size_t SEED_RING_WORDS_MAX = SEED_RING_GROUPS * PcLayout<0>::GROUP_WORDS;   // per workgroup, any HEAD
+static const size_t SEED_RING_WORDS_MAX = SEED_RING_GROUPS * PcLayout<32>::GROUP_WORDS;   // per workgroup, any SPLIT
 static const size_t SEED_LDS_HALF_BYTES = (size_t)256 * SEED_LANES * 8;  // 80 KiB
 
 // Ring stores: a lane owns one column, so its words i and i + 1 are a row (320 B) apart.  Lane pairs (l, l ^ 1) swap one
@@ -175,7 +175,7 @@ struct RingState {
         q.y = odd ? v1 : got;
         if (on) *reinterpret_cast<u64x2 *>(pair + row * SEED_LANES) = q;
     }
-    __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i - 8 * HEAD, v0, v1); }
+    __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i, v0, v1); }
     __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) { row2(PcLayout<HEAD>::SHIP_ROWS + j, v0, v1); }
 };
 struct LdsHalfMem {
@@ -185,7 +185,7 @@ struct LdsHalfMem {
     __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
     __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_LANES] = v; }
 };
-template <int SEED_HEAD>
+template <int SEED_SPLIT>   // = SPLIT: init blocks done by the producers
 __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, u64 *__restrict__ tails,
                                                       uint32_t *__restrict__ lens, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     const uint64_t first_path = G0 * SEED_COLS, end_path = G1 * SEED_COLS < paths ? G1 * SEED_COLS : paths;
     u64 *ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
     const IsaacWarm warm = isaac_warm();
-    typedef PcLayout<SEED_HEAD> L;
+    typedef PcLayout<SEED_SPLIT> L;
     constexpr int SEED_SHIP_ROWS = L::SHIP_ROWS;
     constexpr size_t SEED_HALF_WORDS = L::HALF_WORDS, SEED_GROUP_WORDS = L::GROUP_WORDS;
     constexpr int CHUNKS = SEED_SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
@@ -227,9 +227,9 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
                 path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
                 const uint64_t g = pid / SEED_COLS;
                 const uint32_t c80 = (uint32_t)(pid - g * SEED_COLS);
-                RingState<SEED_HEAD> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
+                RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
                               on, lane);
-                isaac_init_tail<SEED_HEAD>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+                isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
             }
             frontier += 64;
             n++;
@@ -240,30 +240,25 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
             const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
             unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
             const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
-            u64 end8[8];
+            u64 st16[16];
 #pragma unroll
-            for (int q = 0; q < 8; q++) end8[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
+            for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
             if (!(rp.pad[2] & 8u)) {
                 const unsigned char *srcb = reinterpret_cast<const unsigned char *>(src);
-                unsigned char *dst = lds_half + (size_t)8 * SEED_HEAD * SEED_LANES * 8;   // generator words 8*SEED_HEAD.. of every column
 #pragma unroll 8
-                for (int q = 0; q < CHUNKS; q++)
+                for (int q = 0; q < CHUNKS; q++)      // generator words 0 .. 8*SPLIT - 1 of every column
                     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(srcb + q * 1024 + lane * 16u),
-                                                     (void __attribute__((address_space(3))) *)(dst + q * 1024), 16, 0, 2 /* nt */);
+                                                     (void __attribute__((address_space(3))) *)(lds_half + q * 1024), 16, 0, 2 /* nt */);
             }
             const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
             const bool in_range = pid < paths;
             const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
-            uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+            uint32_t tile = item / rp.num_k;
             uint32_t px, py, sub;
             tile_lane_pixel(rp, tile, j, px, py, sub);
             bool valid = in_range && px < rp.width && py < rp.height;
             LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
-            if (lane < (uint32_t)SEED_LANES) {
-                u64 s, t;
-                path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
-                isaac_init_head<SEED_HEAD>(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, end8);   // while the fill is in flight
-            }
+            if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);   // while the fill is in flight
             __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's half has landed (no other wave touches it)
             if (lane < (uint32_t)SEED_LANES) {
                 GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
@@ -512,7 +507,7 @@ struct hr_ctx {
     uint32_t *lens[2] = {nullptr, nullptr};
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
     u64 *ring = nullptr;                     // producer / consumer seeding: ring of group buffers, <= 640 KiB per CU
-    int seed_head = 16;                      // init blocks redone by the consumer (8, 12, 16, 20, 24)
+    int seed_split = 12;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24)
     uint32_t init_prio = 1;                  // s_setprio of the producer waves
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
     bool seed_pending[2] = {false, false}, trace_pending[2] = {false, false};
@@ -835,12 +830,12 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     } else if (c->seed_mode == 1) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
 #define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->tails[slot], c->lens[slot], c->d_counters)
-        switch (c->seed_head) {
+        switch (c->seed_split) {
             case 8: HR_LAUNCH_PC(8); break;
-            case 12: HR_LAUNCH_PC(12); break;
+            case 16: HR_LAUNCH_PC(16); break;
             case 20: HR_LAUNCH_PC(20); break;
             case 24: HR_LAUNCH_PC(24); break;
-            default: HR_LAUNCH_PC(16); break;
+            default: HR_LAUNCH_PC(12); break;
         }
 #undef HR_LAUNCH_PC
     } else
@@ -1035,9 +1030,9 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->seed_prio = (uint32_t)value;
         return HR_OK;
     }
-    if (k == "seed_head") {
-        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24) return fail(HR_ERR_INVALID, "seed_head must be 8, 12, 16, 20 or 24");
-        c->seed_head = (int)value;
+    if (k == "seed_split") {
+        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24) return fail(HR_ERR_INVALID, "seed_split must be 8, 12, 16, 20 or 24");
+        c->seed_split = (int)value;
         return HR_OK;
     }
     if (k == "init_prio") {

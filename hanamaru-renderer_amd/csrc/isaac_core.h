@@ -68,38 +68,34 @@ HD void isaac_init_final(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u
     }
 }
 
-// isaac_init_final cut in two for the producer / consumer seed kernel: the PRODUCER (isaac_init_tail) runs the dry pass 1
-// and the whole pass-2 sweep but stores only blocks >= HEAD plus the pass-1 end state (8 words, out.end2); the CONSUMER
-// (isaac_init_head) redoes blocks < HEAD from that end state straight into its generator memory while the stored part is
-// still in flight.  Together they produce exactly the state of isaac_init_final; what travels shrinks to (32 - HEAD) / 32.
-template <int HEAD, class Out>
-HD void isaac_init_tail(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3) {
+// isaac_init_final cut in two for the producer / consumer seed kernel: the PRODUCER (isaac_init_front) runs the dry pass 1
+// and blocks < SPLIT of the pass-2 sweep, stores those blocks (out.st2) and the 16 registers the sweep continues from
+// (out.end2: a..h of the regenerated pass 1, then A..H of pass 2); the CONSUMER (isaac_init_back) continues with blocks
+// >= SPLIT straight into its generator memory while the stored part is still in flight.  Together they produce exactly
+// the state of isaac_init_final in 32 + 64 mixes; what travels is SPLIT / 32 of the state plus 128 bytes.
+template <int SPLIT, class Out>
+HD void isaac_init_front(Out &out, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3) {
     u64 a = w.r[0] + s0, b = w.r[1] + s1, c = w.r[2] + s2, d = w.r[3] + s3, e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
     HR_NOUNROLL
     for (int i = 0; i < 32; i++) { HR_ISAAC_MIX(a, b, c, d, e, f, g, h) }
     u64 A = a, B = b, C = c, D = d, E = e, F = f, G = g, H = h;
-    out.end2(0, A, B); out.end2(2, C, D); out.end2(4, E, F); out.end2(6, G, H);
     a = w.r[0] + s0; b = w.r[1] + s1; c = w.r[2] + s2; d = w.r[3] + s3; e = w.r[4]; f = w.r[5]; g = w.r[6]; h = w.r[7];
     HR_NOUNROLL
-    for (int i = 0; i < 8 * HEAD; i += 8) {
-        HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
-        A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
-        HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
-    }
-    HR_NOUNROLL
-    for (int i = 8 * HEAD; i < 256; i += 8) {
+    for (int i = 0; i < 8 * SPLIT; i += 8) {
         HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
         A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
         HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
         out.st2(i, A, B); out.st2(i + 2, C, D); out.st2(i + 4, E, F); out.st2(i + 6, G, H);
     }
+    out.end2(0, a, b); out.end2(2, c, d); out.end2(4, e, f); out.end2(6, g, h);
+    out.end2(8, A, B); out.end2(10, C, D); out.end2(12, E, F); out.end2(14, G, H);
 }
-template <int HEAD, class Mem>
-HD void isaac_init_head(Mem &mem, const IsaacWarm &w, u64 s0, u64 s1, u64 s2, u64 s3, const u64 *end8) {
-    u64 a = w.r[0] + s0, b = w.r[1] + s1, c = w.r[2] + s2, d = w.r[3] + s3, e = w.r[4], f = w.r[5], g = w.r[6], h = w.r[7];
-    u64 A = end8[0], B = end8[1], C = end8[2], D = end8[3], E = end8[4], F = end8[5], G = end8[6], H = end8[7];
+template <int SPLIT, class Mem>
+HD void isaac_init_back(Mem &mem, const u64 *st16) {
+    u64 a = st16[0], b = st16[1], c = st16[2], d = st16[3], e = st16[4], f = st16[5], g = st16[6], h = st16[7];
+    u64 A = st16[8], B = st16[9], C = st16[10], D = st16[11], E = st16[12], F = st16[13], G = st16[14], H = st16[15];
     HR_NOUNROLL
-    for (int i = 0; i < 8 * HEAD; i += 8) {
+    for (int i = 8 * SPLIT; i < 256; i += 8) {
         HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
         A += a; B += b; C += c; D += d; E += e; F += f; G += g; H += h;
         HR_ISAAC_MIX(A, B, C, D, E, F, G, H)

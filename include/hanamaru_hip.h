@@ -164,8 +164,8 @@ int hr_resolve(hr_ctx *ctx, uint32_t samplings_done, uint8_t *host_rgb8);
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* keys: "counters" (0/1), "batch" (samplings per launch, default 4), "adv_den" / "leaf_den" (trace-kernel phase
  * thresholds), "min_waves" (3..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
- * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_head" (8 | 12 | 16 | 20 | 24:
- * init blocks the consumer waves redo instead of receiving them through the ring, default 16),
+ * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24: how many
+ * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 12),
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH built on the device — replaces the reference's CPU build of
  * bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);

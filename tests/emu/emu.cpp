@@ -57,10 +57,10 @@ static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_
 }
 
 struct RawTailPc { uint64_t *out; int window; void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; } };
-// same again through the producer / consumer split (isaac_init_tail stores blocks >= HEAD + the pass-1 end state,
-// isaac_init_head redoes the rest), then isaac_round
+// same again through the producer / consumer split (isaac_init_front stores blocks < SPLIT + the 16 registers the sweep
+// continues from, isaac_init_back does the rest), then isaac_round
 struct TailSink {
-    u64 m[256]; u64 end[8];
+    u64 m[256]; u64 end[16];
     void st2(int i, u64 v0, u64 v1) { m[i] = v0; m[i + 1] = v1; }
     void end2(int j, u64 v0, u64 v1) { end[j] = v0; end[j + 1] = v1; }
 };
@@ -69,10 +69,10 @@ static void raw_draws_pc(u64 s, u64 t, uint32_t sampling, int window, uint64_t *
     static const IsaacWarm warm = isaac_warm();
     TailSink sink;
     for (int i = 0; i < 256; i++) sink.m[i] = 0xdeadbeefdeadbeefULL;
-    isaac_init_tail<HEAD>(sink, warm, 8700304ULL, (u64)sampling, s, t);
+    isaac_init_front<HEAD>(sink, warm, 8700304ULL, (u64)sampling, s, t);
     ArrMem mem;
     for (int i = 0; i < 256; i++) mem.st(i, sink.m[i]);
-    isaac_init_head<HEAD>(mem, warm, 8700304ULL, (u64)sampling, s, t, sink.end);
+    isaac_init_back<HEAD>(mem, sink.end);
     RawTailPc rt{out, window};
     isaac_round(mem, rt);
 }

@@ -191,7 +191,7 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 0), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_head", 10), ("bvh_builder", 2), ("rng_window", 32)]:
+    for key, bad in [("batch", 0), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_split", 10), ("bvh_builder", 2), ("rng_window", 32)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
     with pytest.raises(ha.HipError):
@@ -294,7 +294,7 @@ def test_cli_checkpoint_resume_and_debug(tmp_path):
 
 def test_seed_kernels_are_bit_identical(gpu, scenes):
     """The producer / consumer seed kernel (seed_mode 1, default: init in registers on producer waves, only the blocks
-    >= seed_head travel through the ring, the consumer redoes the rest and runs the round) must hand the trace kernel
+    < seed_split come from producer waves through the ring, the consumer does the rest and runs the round) must hand the trace kernel
     exactly the draws of the fused kernel (seed_mode 0): same raw tails -> the accumulators agree up to the atomics'
     fp32 summation order."""
     sc, _ = scenes("rtcamp6_v3_1")
@@ -304,9 +304,9 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
         for (w, h, s) in [(130, 71, 6), (640, 360, 9)]:   # ragged: tiles hang over the right and bottom edges; many groups per CU
             gpu.set_resolution(w, h)
             ref = None
-            for mode, head in [(0, 16), (1, 16), (1, 8), (1, 24)]:
+            for mode, head in [(0, 12), (1, 12), (1, 8), (1, 16), (1, 24)]:
                 gpu.set_option("seed_mode", mode)
-                gpu.set_option("seed_head", head)
+                gpu.set_option("seed_split", head)
                 gpu.clear()
                 gpu.render(1, s + 1)
                 acc = gpu.read_accumulator().astype(np.float64)
@@ -317,7 +317,7 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
                     assert np.abs(ref - acc).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (w, h, mode, head)
     finally:
         gpu.set_option("seed_mode", 1)
-        gpu.set_option("seed_head", 16)
+        gpu.set_option("seed_split", 12)
 
 
 def test_bench_multirank_path_on_one_gpu(tmp_path):
