@@ -416,7 +416,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
                 if (n) { ph[4]++; ph[5] += n; }
             }
-            if (trav && p.ts.leaf != 0) trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
+            if (trav && p.ts.leaf != 0) {
+                trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
+                shadow_early_out(p);
+            }
         }
     }
     if (CNT) {

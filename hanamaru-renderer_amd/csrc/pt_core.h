@@ -426,6 +426,13 @@ HD void nee_setup(const Scene &sc, Path &p) {
     p.phase = 1;
 }
 
+// A shadow ray only contributes when its closest hit lies within 0.02 of the sample point (renderer.rs:280-282 with
+// vector.rs:89-91: |dp|^2 < 4e-4).  As soon as ANY hit is farther than that in front of the sample point the closest hit
+// is too, so the rest of the walk cannot change the outcome: stop (called after every leaf).
+HD void shadow_early_out(Path &p) {
+    if (p.phase == 1 && p.ts.t < p.shadow_len - 0.0201f) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
+}
+
 HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
     return (ts.type == 0) ? sc.tris[ts.prim].element : (ts.type == 1 ? sc.sphere_elem[ts.prim] : float_as_int(sc.cuboids[2 * ts.prim].w));
 }

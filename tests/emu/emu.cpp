@@ -227,7 +227,7 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
                         path_start(sc, rp, p, x, y, sub, draws.data());
                         LaneCounters lc = {0, 0, 0, 0, 0};
                         for (;;) {
-                            while (p.ts.cur != NODE_END) trace_step<true>(sc, p.ray, p.ts, &lc);
+                            while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
                             if (path_advance<true>(sc, p, draws.data(), &lc)) break;
                         }
                         sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
