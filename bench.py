@@ -197,7 +197,9 @@ def main():
                          "lanes_per_shade_call": round(counters["shade_lanes"] / max(1, counters["shade_calls"]), 1),
                          "lanes_per_box_pass": round(counters["box_lanes"] / max(1, counters["box_passes"]), 1),
                          "lanes_per_leaf_call": round(counters["leaf_lanes"] / max(1, counters["leaf_calls"]), 1),
-                         "wave_passes_per_path": {k: round(counters[k] / max(1, counters["paths"]), 3) for k in ("shade_calls", "box_passes", "leaf_calls")}})
+                         "wave_passes_per_path": {k: round(counters[k] / max(1, counters["paths"]), 3) for k in ("shade_calls", "box_passes", "leaf_calls")},
+                         "phase_share_of_wave_cycles": dict(zip(("shade", "refill", "box", "leaf"),
+                                                                [round(float(v) / max(1.0, float(sum(counters["phase_cycles"]))), 3) for v in counters["phase_cycles"]]))})
             out["rays_per_s_M"] = round(value * counters["rays"] / max(1, counters["paths"]), 1)
         # HBM traffic is a PMC measurement (separate rocprofv3 --pmc pass, see profiles/); scaled per launch
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")

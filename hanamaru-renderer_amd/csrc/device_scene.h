@@ -101,6 +101,8 @@ struct Counters {
     unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, pad;
     // wave-level phase statistics of the trace kernel (counters build): invocations and lanes served
     unsigned long long shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters, pad2;
+    // wave-cycles (s_memtime deltas, summed over the waves) spent in: A shade, B refill, C box phase, C leaf phase
+    unsigned long long phase_cycles[4];
 };
 
 }  // namespace hr

@@ -326,6 +326,9 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     LaneCounters lc = {0, 0, 0, 0, 0};
     uint32_t npaths = 0;
     uint32_t ph[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform phase statistics (counters build only)
+    unsigned long long pc[4] = {0, 0, 0, 0}, tmark = 0;   // wave-cycles per phase (counters build only)
+#define HR_PHASE_BEGIN() do { if (CNT) tmark = __builtin_readcyclecounter(); } while (0)
+#define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
     const uint32_t total = 64u * rp.num_k;   // paths per tile in this launch: slot q = k * 64 + j
     const size_t tile_stride = (size_t)rp.num_k * ISAAC_TAIL * 64;
     uint32_t cur_tile = 0, next = total;      // wave-uniform: the tile being handed out and its queue head
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             ph[6]++;
             if (n) { ph[0]++; ph[1] += n; }
         }
+        HR_PHASE_BEGIN();
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
             if (path_advance<CNT>(sc, p, tails + (size_t)p.tile * tile_stride, &lc)) {
                 // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
@@ -359,7 +363,9 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 p.q = PATH_IDLE;
             }
         }
+        HR_PHASE_END(0);
         // ---- B: refill idle lanes (ballot + prefix rank = live-lane compaction); pull a new tile when the queue is dry
+        HR_PHASE_BEGIN();
         unsigned long long idle = __ballot(p.q == PATH_IDLE);
         if (idle) {
             if (next >= total && !exhausted) {
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 next += (uint32_t)__popcll(idle);
             }
         }
+        HR_PHASE_END(1);
         const bool active = p.q != PATH_IDLE;
         const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
         if (!n_active) {
@@ -402,6 +409,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             // lanes allowed to be still walking when the leaf phase starts
             const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
             const uint32_t walk_max = n_trav - park;
+            HR_PHASE_BEGIN();
             for (;;) {
                 const bool go = trav && p.ts.leaf == 0 && p.ts.cur != NODE_END;
                 const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
@@ -412,6 +420,8 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                     if (NODE_UNROLL > 1 && p.ts.leaf == 0 && p.ts.cur != NODE_END) trace_node<CNT>(sc, p.ray, p.ts, &lc);
                 }
             }
+            HR_PHASE_END(2);
+            HR_PHASE_BEGIN();
             if (CNT) {
                 uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
                 if (n) { ph[4]++; ph[5] += n; }
@@ -420,8 +430,11 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
                 shadow_early_out(p);
             }
+            HR_PHASE_END(3);
         }
     }
+#undef HR_PHASE_BEGIN
+#undef HR_PHASE_END
     if (CNT) {
         // wave reduction, one atomic per counter per wave
         unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             atomicAdd(&cnt->box_passes, (unsigned long long)ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ph[3]);
             atomicAdd(&cnt->leaf_calls, (unsigned long long)ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ph[5]);
             atomicAdd(&cnt->outer_iters, (unsigned long long)ph[6]);
+            for (int i = 0; i < 4; i++) atomicAdd(&cnt->phase_cycles[i], pc[i]);
         }
     }
 }
@@ -510,7 +524,7 @@ struct hr_ctx {
     uint32_t *lens[2] = {nullptr, nullptr};
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
     u64 *ring = nullptr;                     // producer / consumer seeding: ring of group buffers, <= 640 KiB per CU
-    int seed_split = 12;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24)
+    int seed_split = 16;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24)
     uint32_t init_prio = 1;                  // s_setprio of the producer waves
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
     bool seed_pending[2] = {false, false}, trace_pending[2] = {false, false};
@@ -529,7 +543,7 @@ struct hr_ctx {
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each raw-draw buffer
     int seed_mode = 1;                       // 1 = producer / consumer seed kernel, 0 = fused seed kernel
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
-    int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills
+    int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
     std::vector<EventPair> seed_events, trace_events, post_events;
     double seed_ms = 0, trace_ms = 0, post_ms = 0;
@@ -835,10 +849,10 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
 #define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->tails[slot], c->lens[slot], c->d_counters)
         switch (c->seed_split) {
             case 8: HR_LAUNCH_PC(8); break;
-            case 16: HR_LAUNCH_PC(16); break;
+            case 12: HR_LAUNCH_PC(12); break;
             case 20: HR_LAUNCH_PC(20); break;
             case 24: HR_LAUNCH_PC(24); break;
-            default: HR_LAUNCH_PC(12); break;
+            default: HR_LAUNCH_PC(16); break;
         }
 #undef HR_LAUNCH_PC
     } else
@@ -901,7 +915,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
 #define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
-            if (c->counters) HR_LAUNCH_TRACE(true, 3);
+            if (c->debug_skip & 16) {
+            } else if (c->counters) HR_LAUNCH_TRACE(true, 3);
             else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4);
             else if (c->min_waves == 5) HR_LAUNCH_TRACE(false, 5);
             else if (c->min_waves == 6) HR_LAUNCH_TRACE(false, 6);
@@ -998,6 +1013,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->bvh_build_ms = c->bvh_build_ms;
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
+    for (int i = 0; i < 4; i++) out->phase_cycles[i] = h.phase_cycles[i];
     out->bvh_nodes = c->st_nodes; out->triangles = c->st_tris; out->spheres = c->st_spheres; out->cuboids = c->st_cuboids;
     return HR_OK;
 }

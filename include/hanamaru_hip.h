@@ -119,6 +119,7 @@ typedef struct hr_stats {
     uint64_t bvh_nodes, triangles, spheres, cuboids;
     /* counters build only: wave-level phase statistics of the trace kernel (invocations, lanes served) */
     uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
+    uint64_t phase_cycles[4];  /* counters build: wave-cycles in A shade, B refill, C box phase, C leaf phase */
     double bvh_build_ms;       /* device BVH build of the last hr_upload_scene (option bvh_builder = 1), else 0 */
 } hr_stats;
 
@@ -165,7 +166,7 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* keys: "counters" (0/1), "batch" (samplings per launch, default 4), "adv_den" / "leaf_den" (trace-kernel phase
  * thresholds), "min_waves" (3..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
  * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24: how many
- * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 12),
+ * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH built on the device — replaces the reference's CPU build of
  * bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
