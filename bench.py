@@ -162,8 +162,20 @@ def main():
         all_reduce_(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = r.stats()
+    # ---- the trace kernel with the chip to itself (seed kernel skipped: the hand-off buffers still hold the previous
+    #      batches' draws, so the workload is the same) — outside the timed region, reported next to the concurrent figure
+    alone_ms = None
+    if rank == 0 and not args.debug_skip and not args.no_counters:
+        if os.environ.get("HR_BENCH_CHECKSUM") == "1":
+            sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % float(acc.mean().item()))
+        r.set_option("debug_skip", 2)
+        r.render(*step_range(0, SPS, world, rank))
+        r.synchronize()
+        st2 = r.stats()
+        r.set_option("debug_skip", 0)
+        alone_ms = (st2["trace_kernel_ms"] - st["trace_kernel_ms"]) / max(1, st2["trace_launches"] - st["trace_launches"])
 
-    if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0:
+    if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0 and alone_ms is None:
         sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % float(acc.mean().item()))
     if rank == 0:
         total_paths = paths_per_step_gpu * world * args.steps
@@ -201,6 +213,11 @@ def main():
                          "phase_share_of_wave_cycles": dict(zip(("shade", "refill", "box", "leaf"),
                                                                 [round(float(v) / max(1.0, float(sum(counters["phase_cycles"]))), 3) for v in counters["phase_cycles"]]))})
             out["rays_per_s_M"] = round(value * counters["rays"] / max(1, counters["paths"]), 1)
+            if alone_ms:
+                gbs_alone = bytes_per_path * paths_per_launch / (alone_ms * 1e-3) / 1e9
+                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs_alone, 1), "frac_alone": round(gbs_alone / HBM_PEAK_GBS, 4),
+                             "note": "achieved / frac: trace kernel running concurrently with the seed kernel of the next batch (the production schedule); "
+                                     "*_alone: the same kernel on the same workload with the chip to itself"})
         # HBM traffic is a PMC measurement (separate rocprofv3 --pmc pass, see profiles/); scaled per launch
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tfile) and (W, H, args.scene) == (1920, 1080, "rtcamp6_v3_1"):
