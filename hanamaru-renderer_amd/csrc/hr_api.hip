@@ -245,10 +245,18 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
             for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
             if (!(rp.pad[2] & 8u)) {
                 const unsigned char *srcb = reinterpret_cast<const unsigned char *>(src);
-#pragma unroll 8
-                for (int q = 0; q < CHUNKS; q++)      // generator words 0 .. 8*SPLIT - 1 of every column
-                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(srcb + q * 1024 + lane * 16u),
-                                                     (void __attribute__((address_space(3))) *)(lds_half + q * 1024), 16, 0, 2 /* nt */);
+                // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
+                // address pair serves two 1 KiB copies
+                static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
+                const unsigned char *gsrc = srcb + lane * 16u;
+                unsigned char *ldst = lds_half;
+#pragma unroll 5
+                for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
+                    const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
+                    void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
+                }
             }
             const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
             const bool in_range = pid < paths;
