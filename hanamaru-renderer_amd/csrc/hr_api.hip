@@ -68,11 +68,11 @@ struct LdsMem {
     __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_COLS] = v; }
 };
 // global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
+// (the padding lanes of the last group write into two spare slabs behind the last item: no predicate in the hot loop)
 struct GlobalTail {
     u64 *col;  // &tail[item][0][lane]
-    bool on;   // false for the padding lanes of the last pass
     __device__ __forceinline__ u64 ld(int k) const { return col[k * 64]; }
-    __device__ __forceinline__ void st(int k, u64 v) { if (on) col[k * 64] = v; }
+    __device__ __forceinline__ void st(int k, u64 v) { col[k * 64] = v; }
 };
 
 static const size_t SEED_LDS_BYTES = (size_t)256 * SEED_COLS * 8;  // 160 KiB: mem[256][80 columns] u64
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
         u64 s, t;
         path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
         LdsMem m{mem + col};
-        GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
+        GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
         RawLensTail<GlobalTail> lt(gt, lens_shape);
         isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
         lt.lens_slow();
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
             if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);   // while the fill is in flight
             __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's half has landed (no other wave touches it)
             if (lane < (uint32_t)SEED_LANES) {
-                GlobalTail gt{tails + (size_t)item * ISAAC_TAIL * 64 + j, in_range};
+                GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
                 RawLensTail<GlobalTail> lt(gt, lens_shape);
                 isaac_round(m, lt);
                 lt.lens_slow();
@@ -837,7 +837,7 @@ static int ensure_draws(hr_ctx *c, size_t items) {
     for (int i = 0; i < 2; i++) {
         if (c->tails[i]) { HIP_TRY(hipFree(c->tails[i])); c->tails[i] = nullptr; }
         if (c->lens[i]) { HIP_TRY(hipFree(c->lens[i])); c->lens[i] = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->tails[i], items * ISAAC_TAIL * 64 * sizeof(u64)));
+        HIP_TRY(hipMalloc((void **)&c->tails[i], (items + 2) * ISAAC_TAIL * 64 * sizeof(u64)));   // + 2 slabs for the padding lanes of the last group
         HIP_TRY(hipMalloc((void **)&c->lens[i], items * 64 * sizeof(uint32_t)));
     }
     c->draws_cap = items;
