@@ -47,7 +47,7 @@ static void usage(const char *prog) {
            "    -i, --interval INTERVAL\n                        report interval sec\n"
            "        --scene NAME    rtcamp6_v3_1 (default) | rtcamp6_v3 | simple | spheres | rtcamp6_dodeca | cornell_mini\n"
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
-           "        --batch N       samplings per progress report (default 16; the library launches 4 at a time)\n"
+           "        --batch N       samplings per progress report (default 32; the library launches 4 at a time)\n"
            "        --checkpoint F  write accumulator + sampling count to F when the render stops\n"
            "        --resume F      continue from a checkpoint file\n",
            prog);
@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     uint32_t width = 1920, height = 1080, sampling = 1000;  // main.rs:1249-1251
     double time_limit = 123.0, interval = 15.0;              // main.rs:1255-1256
     std::string scene_name = "rtcamp6_v3_1", assets, ckpt_out, ckpt_in;
-    int batch = 16;  // samplings between two report_progress calls; one host sync per report
+    int batch = 32;  // samplings between two report_progress calls; one host sync (pipeline drain) per report
     bool debug = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
