@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     Path p;
     p.q = PATH_IDLE;
     p.tile = 0;
-    p.ts.cur = NODE_END; p.ts.leaf = 0;
+    p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0;
     const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
 
@@ -419,13 +419,14 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             const uint32_t walk_max = n_trav - park;
             HR_PHASE_BEGIN();
             for (;;) {
-                const bool go = trav && p.ts.leaf == 0 && p.ts.cur != NODE_END;
+                // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
+                const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
                 const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
                 if (n_go <= walk_max) break;
                 if (CNT) { ph[2]++; ph[3] += n_go; }
                 if (go) {
-                    trace_node<CNT>(sc, p.ray, p.ts, &lc);
-                    if (NODE_UNROLL > 1 && p.ts.leaf == 0 && p.ts.cur != NODE_END) trace_node<CNT>(sc, p.ray, p.ts, &lc);
+                    trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (NODE_UNROLL > 1 && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
                 }
             }
             HR_PHASE_END(2);
@@ -435,7 +436,9 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 if (n) { ph[4]++; ph[5] += n; }
             }
             if (trav && p.ts.leaf != 0) {
-                trace_leaf<CNT>(sc, p.ray, p.ts, &lc);
+                trace_leaf<CNT>(sc, p.ray, p.ts, &lc);   // clears ts.leaf
+                p.ts.leaf = p.ts.leaf2;
+                p.ts.leaf2 = 0;
                 shadow_early_out(p);
             }
             HR_PHASE_END(3);

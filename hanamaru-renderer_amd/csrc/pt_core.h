@@ -78,8 +78,9 @@ struct TraceState {
     int32_t type;     // 0 tri, 1 sphere, 2 cuboid
     float u, v;       // barycentrics (triangles)
     uint32_t leaf;    // pending leaf word (node visited, primitives not yet tested), 0 = none
+    uint32_t leaf2;   // a second pending leaf, found while `leaf` was still waiting for the leaf phase (trace kernel only)
 };
-HD void trace_begin(TraceState &ts, float tmax) { ts.cur = 0; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; ts.leaf = 0; }
+HD void trace_begin(TraceState &ts, float tmax) { ts.cur = 0; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; ts.leaf = 0; ts.leaf2 = 0; }
 HD bool trace_done(const TraceState &ts) { return ts.cur == NODE_END && ts.leaf == 0; }
 
 struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests; };
@@ -142,7 +143,10 @@ HD void cuboid_test(const f4 &mn, const f4 &mx, const Ray &r, TraceState &ts, in
 // ("while-while"): trace_node() is ONE box test of the stackless threaded walk and parks a hit leaf in
 // ts.leaf; trace_leaf() tests that leaf's primitives.  Nodes whose entry distance exceeds the closest hit
 // so far are skipped (the reference visits them, bvh.rs:214,240 — the closest hit is the same).
-template <bool CNT>
+// SPEC (trace kernel): a lane whose first leaf is still parked keeps walking until it finds a second one ("postponed
+// leaf": fuller box AND leaf phases); the box it tests meanwhile is culled against a closest hit that does not yet include
+// the parked leaf's primitives, which can only add node visits, never lose a hit.  Leaves are still tested in walk order.
+template <bool CNT, bool SPEC = false>
 HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
     const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
     if (CNT) cn->node_tests++;
@@ -159,7 +163,14 @@ HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *
     const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
     const bool leaf = node_word_is_leaf(nd.a);
     ts.cur = (hit && !leaf) ? nd.a : nd.b;
-    ts.leaf = (hit && leaf) ? nd.a : 0u;
+    if (SPEC) {
+        const uint32_t found = (hit && leaf) ? nd.a : 0u;
+        const bool first = ts.leaf == 0u;
+        ts.leaf2 = first ? 0u : found;
+        ts.leaf = first ? found : ts.leaf;
+    } else {
+        ts.leaf = (hit && leaf) ? nd.a : 0u;
+    }
 }
 template <bool CNT>
 HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
@@ -430,7 +441,7 @@ HD void nee_setup(const Scene &sc, Path &p) {
 // vector.rs:89-91: |dp|^2 < 4e-4).  As soon as ANY hit is farther than that in front of the sample point the closest hit
 // is too, so the rest of the walk cannot change the outcome: stop (called after every leaf).
 HD void shadow_early_out(Path &p) {
-    if (p.phase == 1 && p.ts.t < p.shadow_len - 0.0201f) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
+    if (p.phase == 1 && p.ts.t < p.shadow_len - 0.0201f) { p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0; }
 }
 
 HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
