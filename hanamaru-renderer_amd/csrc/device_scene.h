@@ -91,6 +91,15 @@ struct RenderParams {
     uint32_t pad[3];
 };
 
+// lane j of tile `tile` -> pixel and sub-sample (tile = 4x4 pixels x 4 sub-samples = 64 paths per sampling)
+HD void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint32_t &px, uint32_t &py, uint32_t &sub) {
+    uint32_t tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
+    uint32_t pix = j >> 2;
+    sub = j & 3u;
+    px = tx * 4u + (pix & 3u);
+    py = ty * 4u + (pix >> 2);
+}
+
 // Hand-off from the seed kernel to the trace kernel, per path: the last ISAAC_TAIL raw generator outputs
 // (draw k = k-th next_u64) as [item][k][64 lanes] u64, plus the index of the accepted lens attempt.
 // A path consumes draws 2*a, 2*a+1 (lens) and 2*(a+i), 2*(a+i)+1 for iteration i = 1..9.

@@ -1,17 +1,12 @@
-// hr_api.hip — HIP kernels (gfx950) and the C ABI of include/hanamaru_hip.h.
-//
-// Kernels
-//   seed_isaac64_kernel   one lane = one path's ISAAC-64 generator, state in an LDS column: 80 columns x 2 KiB =
-//                         all 160 KiB of a CU's LDS, one workgroup (2 waves x 40 lanes) per CU; decides the lens
-//                         rejection loop in f64 and stores the last 64 raw outputs of every path (`tails`).
-//   trace_kernel          the path-tracing megakernel: persistent waves pull 4x4-pixel tiles from a global counter,
-//                         one lane per path, stackless threaded-BVH traversal in box / leaf phases, finished lanes
-//                         are refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed
-//                         kernel of the NEXT batch (own stream).
-//   seed_pc_kernel        the default seeding (seed_mode = 1): producer waves run the init in registers, consumer waves the
-//                         LDS-bound round; seed_isaac64_kernel is the fused form (seed_mode = 0).
-//   debug_render_kernel   DebugRenderer modes (renderer.rs:101-146).
-//   tonemap_gamma_kernel, bilateral_quantise_kernel   the post chain.
+// hr_api.hip — the device context and the C ABI of include/hanamaru_hip.h (gfx950).  One translation unit with its kernels:
+//   seed_kernels.h   seed_pc_kernel (default: producer waves run the ISAAC-64 init in registers, consumer waves the
+//                    LDS-bound round, hand-off through a per-CU ring), seed_isaac64_kernel (fused form), seed_debug_kernel
+//   trace_kernel.h   trace_kernel — the path-tracing megakernel: persistent waves pull 4x4-pixel tiles from a global
+//                    counter, one lane per path, stackless threaded-BVH traversal in box / leaf phases, finished lanes are
+//                    refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed kernel of the NEXT
+//                    batch (own stream) — plus intersect_debug_kernel and debug_render_kernel (renderer.rs:101-146)
+//   post_kernels.h   tonemap_gamma_kernel, bilateral_quantise_kernel
+//   gpu_bvh.h        the device LBVH builder's kernels (option bvh_builder = 1)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -50,466 +45,9 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(HR_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// ------------------------------------------------------------------------------------------ kernels
-
-// 32-bit LDS address of a generic pointer into shared memory / load from such an address (isaac_round keeps the address of
-// its next gather in a register across a scheduling fence)
-__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) void *)p; }
-__device__ __forceinline__ u64 lds_load64(uint32_t a) { return *(const __attribute__((address_space(3))) u64 *)(size_t)a; }
-
-// One generator per LDS bank column: mem[i][col], SEED_COLS columns per workgroup.
-static const int SEED_COLS = 80;               // 80 x 2 KiB = 160 KiB = the whole LDS of a CU
-static const int SEED_WAVES = 2, SEED_LANES = SEED_COLS / SEED_WAVES;   // 2 waves x 40 active lanes
-struct LdsMem {
-    u64 *col;  // &mem[0][col]
-    __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_COLS]; }
-    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(SEED_COLS * 8); }
-    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
-    __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_COLS] = v; }
-};
-// global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
-// (the padding lanes of the last group write into two spare slabs behind the last item: no predicate in the hot loop)
-struct GlobalTail {
-    u64 *col;  // &tail[item][0][lane]
-    __device__ __forceinline__ u64 ld(int k) const { return col[k * 64]; }
-    __device__ __forceinline__ void st(int k, u64 v) { col[k * 64] = v; }
-};
-
-static const size_t SEED_LDS_BYTES = (size_t)256 * SEED_COLS * 8;  // 160 KiB: mem[256][80 columns] u64
-
-__device__ __forceinline__ void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint32_t &px, uint32_t &py, uint32_t &sub) {
-    uint32_t tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
-    uint32_t pix = j >> 2;
-    sub = j & 3u;
-    px = tx * 4u + (pix & 3u);
-    py = ty * 4u + (pix >> 2);
-}
-
-// tails layout: [item = tile * num_k + k][ISAAC_TAIL][64 lanes] u64;  lens layout: [item][64 lanes] u32.
-// The LDS holds 80 generators, so a workgroup walks the flat path index (item * 64 + j) in strides of 80:
-// its two waves (40 active lanes each) run concurrently on two SIMDs — the time of one seeding pass does not
-// depend on the lane count (one wave issues at most one instruction every ~4-5 cycles), only on how many
-// generator states fit in the CU's LDS.
-__global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ tails,
-                                                                      uint32_t *__restrict__ lens, Counters *cnt) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    u64 *mem = reinterpret_cast<u64 *>(smem);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane >= (uint32_t)SEED_LANES) return;
-    const uint32_t col = wave * SEED_LANES + lane;
-    // latency-bound waves next to the trace kernel's waves: win issue arbitration (priority is a launch parameter)
-    switch (rp.pad[0]) {
-        case 0: break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-    const IsaacWarm warm = isaac_warm();
-    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
-    for (uint64_t base = (uint64_t)blockIdx.x * SEED_COLS; base < paths; base += (uint64_t)gridDim.x * SEED_COLS) {
-        const uint64_t pid = base + col;
-        const bool in_range = pid < paths;
-        const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
-        uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
-        uint32_t px, py, sub;
-        tile_lane_pixel(rp, tile, j, px, py, sub);
-        bool valid = in_range && px < rp.width && py < rp.height;
-        u64 s, t;
-        path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
-        LdsMem m{mem + col};
-        GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
-        RawLensTail<GlobalTail> lt(gt, lens_shape);
-        isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
-        lt.lens_slow();
-        bool ok = lt.in_window();
-        if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
-        if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
-    }
-}
-
-// ---- producer / consumer seeding (option seed_mode = 1, the default) -----------------------------------------------------------
-// One workgroup per CU, four waves, a contiguous range of path groups (80 paths = one LDS fill) per workgroup.
-// Waves 2,3 (producers) run the scratch-free init of the paths AHEAD in registers, 64 lanes = one chunk of 64 consecutive
-// paths per pass, and scatter the states into a small ring of group buffers in global memory that belongs to this
-// workgroup (written and re-read on the same CU within ~40 us: L2 / Infinity Cache traffic, not HBM); waves 0,1
-// (consumers) fill their half of the LDS from the ring with straight global_load_lds copies and run the round on 40
-// lanes each.  A generator state then sits in LDS only for fill + round (~2/3 of the fused kernel's residency, and LDS
-// capacity is what bounds seeding), and the init runs on full waves.
-// The ring traffic is what this costs (it slows the trace kernel next door), so the producers stop after SPLIT of the 32
-// init blocks and ship those plus the 16 registers the sweep continues from; the consumer does blocks >= SPLIT itself
-// while its fill is in flight (isaac_init_front / isaac_init_back) — no mix is computed twice.
-// Group buffer, per half: [row = 0 .. RING_ROWS)[40 columns] u64; rows 0 .. 8*SPLIT are the LDS image of generator words
-// 0 .. 8*SPLIT - 1, the last 16 rows hold the registers.  One __syncthreads per group: in
-// iteration `it` the consumers work on group it-1 while the producers complete group `it` (5 chunks per 4 groups).
-template <int SPLIT>   // init blocks (of 8 words) done by the producer; even
-struct PcLayout {
-    static const int SHIP_ROWS = 8 * SPLIT;
-    static const int RING_ROWS = SHIP_ROWS + 16;
-    static const size_t HALF_WORDS = (size_t)RING_ROWS * SEED_LANES;    // u64 per half in the ring
-    static const size_t GROUP_WORDS = 2 * HALF_WORDS;
-    static_assert((SHIP_ROWS * SEED_LANES * 8) % 1024 == 0, "fill copies 1 KiB per wave instruction");
-};
-static const int SEED_RING_GROUPS = 4;                                   // group g lives in buffer g & 3
-static const size_t SEED_RING_WORDS_MAX = SEED_RING_GROUPS * PcLayout<32>::GROUP_WORDS;   // per workgroup, any SPLIT
-static const size_t SEED_LDS_HALF_BYTES = (size_t)256 * SEED_LANES * 8;  // 80 KiB
-
-// Ring stores: a lane owns one column, so its words i and i + 1 are a row (320 B) apart.  Lane pairs (l, l ^ 1) swap one
-// word each so that the even lane stores row i and the odd lane row i + 1 as 16-byte pieces {column 2k, column 2k + 1}:
-// one dwordx4 store instruction then writes whole rows.
-template <int HEAD>
-struct RingState {
-    u64 *pair;   // even lane: &row0[col]; odd lane: &row1[col - 1]
-    bool on, odd;
-    __device__ __forceinline__ RingState(u64 *col, bool on_, uint32_t lane) : on(on_), odd(lane & 1u) { pair = odd ? col + SEED_LANES - 1 : col; }
-    static __device__ __forceinline__ u64 swap_pair(u64 v) {   // value of lane ^ 1
-        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-        hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xf, 0xf, true);
-        return ((u64)hi << 32) | lo;
-    }
-    __device__ __forceinline__ void row2(int row, u64 v0, u64 v1) {   // rows `row` (v0) and `row + 1` (v1) of this lane's column
-        u64 got = swap_pair(odd ? v0 : v1);            // even receives the partner's v0, odd the partner's v1
-        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-        u64x2 q;
-        q.x = odd ? got : v0;
-        q.y = odd ? v1 : got;
-        if (on) *reinterpret_cast<u64x2 *>(pair + row * SEED_LANES) = q;
-    }
-    __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i, v0, v1); }
-    __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) { row2(PcLayout<HEAD>::SHIP_ROWS + j, v0, v1); }
-};
-struct LdsHalfMem {
-    u64 *col;
-    __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_LANES]; }
-    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(SEED_LANES * 8); }
-    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
-    __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_LANES] = v; }
-};
-template <int SEED_SPLIT>   // = SPLIT: init blocks done by the producers
-__global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, u64 *__restrict__ tails,
-                                                      uint32_t *__restrict__ lens, Counters *cnt) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
-    const bool consumer = wave < 2u;
-    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1];
-    switch (prio) {  // s_setprio takes an immediate
-        case 0: break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
-    const uint64_t groups = (paths + SEED_COLS - 1) / SEED_COLS;
-    const uint64_t G0 = groups * blockIdx.x / gridDim.x, G1 = groups * (blockIdx.x + 1) / gridDim.x;   // this workgroup's groups
-    const uint64_t first_path = G0 * SEED_COLS, end_path = G1 * SEED_COLS < paths ? G1 * SEED_COLS : paths;
-    u64 *ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
-    const IsaacWarm warm = isaac_warm();
-    typedef PcLayout<SEED_SPLIT> L;
-    constexpr int SEED_SHIP_ROWS = L::SHIP_ROWS;
-    constexpr size_t SEED_HALF_WORDS = L::HALF_WORDS, SEED_GROUP_WORDS = L::GROUP_WORDS;
-    constexpr int CHUNKS = SEED_SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
-    uint64_t frontier = first_path & ~63ull;                   // first path not yet produced (chunk aligned)
-    for (uint64_t it = 0; it <= G1 - G0; it++) {
-        // ---- producers: complete group G0 + it
-        const uint64_t need = it < G1 - G0 ? (G0 + it + 1) * SEED_COLS : 0;      // paths below `need` must be in the ring
-        uint32_t n = 0;
-        while (frontier < need && frontier < end_path) {
-            if (!consumer && (n & 1u) == half) {
-                const uint64_t pid0 = frontier + lane;
-                const bool on = pid0 >= first_path && pid0 < end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
-                const uint64_t pid = pid0 >= first_path && pid0 < end_path ? pid0 : end_path - 1;
-                const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
-                uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
-                uint32_t px, py, sub;
-                tile_lane_pixel(rp, tile, j, px, py, sub);
-                bool valid = px < rp.width && py < rp.height;
-                u64 s, t;
-                path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
-                const uint64_t g = pid / SEED_COLS;
-                const uint32_t c80 = (uint32_t)(pid - g * SEED_COLS);
-                RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
-                              on, lane);
-                isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
-            }
-            frontier += 64;
-            n++;
-        }
-        // ---- consumers: group G0 + it - 1
-        if (consumer && it > 0) {
-            const uint64_t g = G0 + it - 1;
-            const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
-            unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
-            const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
-            u64 st16[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
-            if (!(rp.pad[2] & 8u)) {
-                const unsigned char *srcb = reinterpret_cast<const unsigned char *>(src);
-                // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
-                // address pair serves two 1 KiB copies
-                static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
-                const unsigned char *gsrc = srcb + lane * 16u;
-                unsigned char *ldst = lds_half;
-#pragma unroll 5
-                for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
-                    const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
-                    void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
-                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
-                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
-                }
-            }
-            const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
-            const bool in_range = pid < paths;
-            const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
-            uint32_t tile = item / rp.num_k;
-            uint32_t px, py, sub;
-            tile_lane_pixel(rp, tile, j, px, py, sub);
-            bool valid = in_range && px < rp.width && py < rp.height;
-            LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
-            if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);   // while the fill is in flight
-            __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's half has landed (no other wave touches it)
-            if (lane < (uint32_t)SEED_LANES) {
-                GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
-                RawLensTail<GlobalTail> lt(gt, lens_shape);
-                isaac_round(m, lt);
-                lt.lens_slow();
-                bool ok = lt.in_window();
-                if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
-                if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
-            }
-        }
-        __syncthreads();   // group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
-    }
-}
-
-// raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
-struct RawTail {
-    u64 *out; int window;
-    __device__ __forceinline__ void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; }
-};
-struct LdsMem64 {
-    u64 *col;
-    __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
-    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(64 * 8); }
-    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
-    __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
-};
-__global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
-                                                        int window, u64 *__restrict__ out) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    u64 *mem = reinterpret_cast<u64 *>(smem);
-    const uint32_t lane = threadIdx.x;
-    const IsaacWarm warm = isaac_warm();
-    uint32_t idx = blockIdx.x * 64 + lane;
-    bool valid = idx < num_paths;
-    uint32_t p = first_path + (valid ? idx : 0u);
-    uint32_t pix = p >> 2, sub = p & 3u;
-    u64 s, t;
-    path_seed_words(W, H, pix % W, pix / W, sub, s, t);
-    LdsMem64 m{mem + lane};
-    u64 dummy[ISAAC_TAIL];
-    RawTail rt{valid ? out + (size_t)idx * window : dummy, window};
-    isaac_seed_round(m, warm, 8700304ULL, (u64)sampling, s, t, rt);
-}
-
-__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-// Persistent waves: a workgroup is 4 independent waves (single-wave workgroups cap residency at ~8 waves per CU);
-// every wave pulls 4x4-pixel tiles from a global counter until none are left.  A tile = 64 paths per sampling of
-// the batch; finished lanes are refilled from the tile's path queue, and when that runs dry the wave pulls the
-// next tile while its slow lanes are still working, so lanes only starve at the very end of a launch
-// (measured before: with one tile per wave the mean box-phase pass had 19.6 of 64 lanes active).
-// No barriers, no LDS.
-static const int TRACE_WAVES = 4;
-static const int NODE_UNROLL = 2;   // box tests per pass of the box-phase loop (amortises the ballot / branch overhead)
-
-template <bool CNT, int MINW>
-__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails,
-                                                                       const uint32_t *__restrict__ lens, float *__restrict__ accum,
-                                                                       Counters *cnt, uint32_t *tile_counter) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tiles = rp.tiles_x * rp.tiles_y;
-    LaneCounters lc = {0, 0, 0, 0, 0};
-    uint32_t npaths = 0;
-    uint32_t ph[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform phase statistics (counters build only)
-    unsigned long long pc[4] = {0, 0, 0, 0}, tmark = 0;   // wave-cycles per phase (counters build only)
-#define HR_PHASE_BEGIN() do { if (CNT) tmark = __builtin_readcyclecounter(); } while (0)
-#define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
-    const uint32_t total = 64u * rp.num_k;   // paths per tile in this launch: slot q = k * 64 + j
-    const size_t tile_stride = (size_t)rp.num_k * ISAAC_TAIL * 64;
-    uint32_t cur_tile = 0, next = total;      // wave-uniform: the tile being handed out and its queue head
-    bool exhausted = false;
-    Path p;
-    p.q = PATH_IDLE;
-    p.tile = 0;
-    p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0;
-    const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
-    const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
-
-    for (;;) {
-        // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
-        if (CNT) {
-            uint32_t n = (uint32_t)__popcll(__ballot(p.q != PATH_IDLE && trace_done(p.ts)));
-            ph[6]++;
-            if (n) { ph[0]++; ph[1] += n; }
-        }
-        HR_PHASE_BEGIN();
-        if (p.q != PATH_IDLE && trace_done(p.ts)) {
-            if (path_advance<CNT>(sc, p, tails + (size_t)p.tile * tile_stride, &lc)) {
-                // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
-                // path adds its radiance straight into the accumulator.  A tile belongs to exactly one wave of
-                // one launch, so only lanes of this wave ever touch these addresses: workgroup-scope atomics
-                // (executed in the XCD's L2) are sufficient.
-                uint32_t pix = (p.q & 63u) >> 2;
-                uint32_t px = (p.tile % rp.tiles_x) * 4u + (pix & 3u), py = (p.tile / rp.tiles_x) * 4u + (pix >> 2);
-                float *dst = accum + ((size_t)py * rp.width + px) * 3;
-                __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(dst + 2, p.accum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                p.q = PATH_IDLE;
-            }
-        }
-        HR_PHASE_END(0);
-        // ---- B: refill idle lanes (ballot + prefix rank = live-lane compaction); pull a new tile when the queue is dry
-        HR_PHASE_BEGIN();
-        unsigned long long idle = __ballot(p.q == PATH_IDLE);
-        if (idle) {
-            if (next >= total && !exhausted) {
-                uint32_t t = 0;
-                if (lane == 0) t = atomicAdd(tile_counter, 1u);
-                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                if (t >= tiles) exhausted = true;
-                else { cur_tile = t; next = 0; }
-            }
-            if (next < total) {
-                uint32_t q = next + lane_rank(idle);
-                if (p.q == PATH_IDLE && q < total) {
-                    uint32_t k = q >> 6, j = q & 63u, px, py, sub;
-                    tile_lane_pixel(rp, cur_tile, j, px, py, sub);
-                    if (px < rp.width && py < rp.height) {
-                        p.q = q;
-                        p.tile = cur_tile;
-                        p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
-                        p.lens_a = lens[((size_t)cur_tile * rp.num_k + k) * 64 + j];
-                        path_start(sc, rp, p, px, py, sub, tails + (size_t)cur_tile * tile_stride);
-                        npaths++;
-                    }
-                }
-                next += (uint32_t)__popcll(idle);
-            }
-        }
-        HR_PHASE_END(1);
-        const bool active = p.q != PATH_IDLE;
-        const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
-        if (!n_active) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- C: traversal as two well-filled phases.  Box phase: lanes walk nodes until 1/leaf_den of the
-        //         traversing lanes have parked a leaf; leaf phase: those lanes test their primitives together.
-        //         The whole of C is left as soon as 1/adv_den of the live lanes wait for phase A.
-        for (;;) {
-            const bool trav = active && !trace_done(p.ts);
-            const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
-            if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
-            // lanes allowed to be still walking when the leaf phase starts
-            const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
-            const uint32_t walk_max = n_trav - park;
-            HR_PHASE_BEGIN();
-            for (;;) {
-                // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
-                const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
-                const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
-                if (n_go <= walk_max) break;
-                if (CNT) { ph[2]++; ph[3] += n_go; }
-                if (go) {
-                    trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                    if (NODE_UNROLL > 1 && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                }
-            }
-            HR_PHASE_END(2);
-            HR_PHASE_BEGIN();
-            if (CNT) {
-                uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
-                if (n) { ph[4]++; ph[5] += n; }
-            }
-            if (trav && p.ts.leaf != 0) {
-                trace_leaf<CNT>(sc, p.ray, p.ts, &lc);   // clears ts.leaf
-                p.ts.leaf = p.ts.leaf2;
-                p.ts.leaf2 = 0;
-                shadow_early_out(p);
-            }
-            HR_PHASE_END(3);
-        }
-    }
-#undef HR_PHASE_BEGIN
-#undef HR_PHASE_END
-    if (CNT) {
-        // wave reduction, one atomic per counter per wave
-        unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
-        for (int i = 0; i < 6; i++) {
-            unsigned long long x = v[i];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            v[i] = x;
-        }
-        if (lane == 0) {
-            atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
-            atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
-            atomicAdd(&cnt->shade_calls, (unsigned long long)ph[0]); atomicAdd(&cnt->shade_lanes, (unsigned long long)ph[1]);
-            atomicAdd(&cnt->box_passes, (unsigned long long)ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ph[3]);
-            atomicAdd(&cnt->leaf_calls, (unsigned long long)ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ph[5]);
-            atomicAdd(&cnt->outer_iters, (unsigned long long)ph[6]);
-            for (int i = 0; i < 4; i++) atomicAdd(&cnt->phase_cycles[i], pc[i]);
-        }
-    }
-}
-
-__global__ void intersect_debug_kernel(Scene sc, uint32_t n, const float *__restrict__ rays, float *__restrict__ out, int32_t *__restrict__ out_elem) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Ray r;
-    ray_set(r, v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
-    TraceState ts;
-    trace_begin(ts, T_INF);
-    LaneCounters lc;
-    while (ts.cur != NODE_END) trace_step<false>(sc, r, ts, &lc);
-    float *o = out + (size_t)i * 8;
-    int32_t elem = -1;
-    if (ts.prim >= 0) {
-        Surf s;
-        hit_surface(sc, r, ts, true, s);
-        elem = s.elem;
-        o[0] = 1.0f; o[1] = ts.t; o[2] = s.pos.x; o[3] = s.pos.y; o[4] = s.pos.z; o[5] = s.n.x; o[6] = s.n.y; o[7] = s.n.z;
-    } else {
-        o[0] = 0.0f; o[1] = ts.t;
-        for (int k = 2; k < 8; k++) o[k] = 0.0f;
-    }
-    out_elem[i] = elem;
-}
-
-// DebugRenderer (renderer.rs:101-146): one thread per pixel, 2x2 sub-samples, pinhole rays
-__global__ void debug_render_kernel(Scene sc, RenderParams rp, int mode, float *__restrict__ accum) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= rp.width || y >= rp.height) return;
-    LaneCounters lc;
-    V3f sum = v3(0, 0, 0);
-    for (uint32_t sub = 0; sub < 4; sub++) sum = sum + debug_pixel<false>(sc, rp, x, y, sub, mode, &lc);
-    float *o = accum + ((size_t)y * rp.width + x) * 3;
-    o[0] += sum.x; o[1] += sum.y; o[2] += sum.z;
-}
-
-__global__ void tonemap_gamma_kernel(const float *__restrict__ acc, float *__restrict__ out, uint32_t n, float scale) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    tonemap_gamma(acc[i * 3], acc[i * 3 + 1], acc[i * 3 + 2], scale, &out[i * 3]);
-}
-__global__ void bilateral_quantise_kernel(const float *__restrict__ img, uint8_t *__restrict__ out, uint32_t W, uint32_t H) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H) return;
-    bilateral_quantise(img, W, H, x, y, &out[((size_t)y * W + x) * 3]);
-}
+#include "seed_kernels.h"
+#include "trace_kernel.h"
+#include "post_kernels.h"
 
 // ------------------------------------------------------------------------------------------ context
 

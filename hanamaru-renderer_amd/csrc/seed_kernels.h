@@ -1,0 +1,263 @@
+// ISAAC-64 seeding kernels: seed_pc_kernel (producer / consumer waves, default), seed_isaac64_kernel (fused),
+// seed_debug_kernel (raw outputs for the parity tests) — included by hr_api.hip only (one translation unit: the kernels and the C ABI that launches them).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_scene.h"
+#include "isaac_core.h"
+
+using namespace hr;
+
+
+// 32-bit LDS address of a generic pointer into shared memory / load from such an address (isaac_round keeps the address of
+// its next gather in a register across a scheduling fence)
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) void *)p; }
+__device__ __forceinline__ u64 lds_load64(uint32_t a) { return *(const __attribute__((address_space(3))) u64 *)(size_t)a; }
+
+// One generator per LDS bank column: mem[i][col], SEED_COLS columns per workgroup.
+static const int SEED_COLS = 80;               // 80 x 2 KiB = 160 KiB = the whole LDS of a CU
+static const int SEED_WAVES = 2, SEED_LANES = SEED_COLS / SEED_WAVES;   // 2 waves x 40 active lanes
+struct LdsMem {
+    u64 *col;  // &mem[0][col]
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_COLS]; }
+    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(SEED_COLS * 8); }
+    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_COLS] = v; }
+};
+// global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
+// (the padding lanes of the last group write into two spare slabs behind the last item: no predicate in the hot loop)
+struct GlobalTail {
+    u64 *col;  // &tail[item][0][lane]
+    __device__ __forceinline__ u64 ld(int k) const { return col[k * 64]; }
+    __device__ __forceinline__ void st(int k, u64 v) { col[k * 64] = v; }
+};
+
+static const size_t SEED_LDS_BYTES = (size_t)256 * SEED_COLS * 8;  // 160 KiB: mem[256][80 columns] u64
+
+
+// tails layout: [item = tile * num_k + k][ISAAC_TAIL][64 lanes] u64;  lens layout: [item][64 lanes] u32.
+// The LDS holds 80 generators, so a workgroup walks the flat path index (item * 64 + j) in strides of 80:
+// its two waves (40 active lanes each) run concurrently on two SIMDs — the time of one seeding pass does not
+// depend on the lane count (one wave issues at most one instruction every ~4-5 cycles), only on how many
+// generator states fit in the CU's LDS.
+__global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ tails,
+                                                                      uint32_t *__restrict__ lens, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64 *mem = reinterpret_cast<u64 *>(smem);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane >= (uint32_t)SEED_LANES) return;
+    const uint32_t col = wave * SEED_LANES + lane;
+    // latency-bound waves next to the trace kernel's waves: win issue arbitration (priority is a launch parameter)
+    switch (rp.pad[0]) {
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+    const IsaacWarm warm = isaac_warm();
+    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    for (uint64_t base = (uint64_t)blockIdx.x * SEED_COLS; base < paths; base += (uint64_t)gridDim.x * SEED_COLS) {
+        const uint64_t pid = base + col;
+        const bool in_range = pid < paths;
+        const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
+        uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        bool valid = in_range && px < rp.width && py < rp.height;
+        u64 s, t;
+        path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
+        LdsMem m{mem + col};
+        GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
+        RawLensTail<GlobalTail> lt(gt, lens_shape);
+        isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
+        lt.lens_slow();
+        bool ok = lt.in_window();
+        if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
+        if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+    }
+}
+
+// ---- producer / consumer seeding (option seed_mode = 1, the default) -----------------------------------------------------------
+// One workgroup per CU, four waves, a contiguous range of path groups (80 paths = one LDS fill) per workgroup.
+// Waves 2,3 (producers) run the scratch-free init of the paths AHEAD in registers, 64 lanes = one chunk of 64 consecutive
+// paths per pass, and scatter the states into a small ring of group buffers in global memory that belongs to this
+// workgroup (written and re-read on the same CU within ~40 us: L2 / Infinity Cache traffic, not HBM); waves 0,1
+// (consumers) fill their half of the LDS from the ring with straight global_load_lds copies and run the round on 40
+// lanes each.  A generator state then sits in LDS only for fill + round (~2/3 of the fused kernel's residency, and LDS
+// capacity is what bounds seeding), and the init runs on full waves.
+// The ring traffic is what this costs (it slows the trace kernel next door), so the producers stop after SPLIT of the 32
+// init blocks and ship those plus the 16 registers the sweep continues from; the consumer does blocks >= SPLIT itself
+// while its fill is in flight (isaac_init_front / isaac_init_back) — no mix is computed twice.
+// Group buffer, per half: [row = 0 .. RING_ROWS)[40 columns] u64; rows 0 .. 8*SPLIT are the LDS image of generator words
+// 0 .. 8*SPLIT - 1, the last 16 rows hold the registers.  One __syncthreads per group: in
+// iteration `it` the consumers work on group it-1 while the producers complete group `it` (5 chunks per 4 groups).
+template <int SPLIT>   // init blocks (of 8 words) done by the producer; even
+struct PcLayout {
+    static const int SHIP_ROWS = 8 * SPLIT;
+    static const int RING_ROWS = SHIP_ROWS + 16;
+    static const size_t HALF_WORDS = (size_t)RING_ROWS * SEED_LANES;    // u64 per half in the ring
+    static const size_t GROUP_WORDS = 2 * HALF_WORDS;
+    static_assert((SHIP_ROWS * SEED_LANES * 8) % 1024 == 0, "fill copies 1 KiB per wave instruction");
+};
+static const int SEED_RING_GROUPS = 4;                                   // group g lives in buffer g & 3
+static const size_t SEED_RING_WORDS_MAX = SEED_RING_GROUPS * PcLayout<32>::GROUP_WORDS;   // per workgroup, any SPLIT
+static const size_t SEED_LDS_HALF_BYTES = (size_t)256 * SEED_LANES * 8;  // 80 KiB
+
+// Ring stores: a lane owns one column, so its words i and i + 1 are a row (320 B) apart.  Lane pairs (l, l ^ 1) swap one
+// word each so that the even lane stores row i and the odd lane row i + 1 as 16-byte pieces {column 2k, column 2k + 1}:
+// one dwordx4 store instruction then writes whole rows.
+template <int HEAD>
+struct RingState {
+    u64 *pair;   // even lane: &row0[col]; odd lane: &row1[col - 1]
+    bool on, odd;
+    __device__ __forceinline__ RingState(u64 *col, bool on_, uint32_t lane) : on(on_), odd(lane & 1u) { pair = odd ? col + SEED_LANES - 1 : col; }
+    static __device__ __forceinline__ u64 swap_pair(u64 v) {   // value of lane ^ 1
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+        hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xf, 0xf, true);
+        return ((u64)hi << 32) | lo;
+    }
+    __device__ __forceinline__ void row2(int row, u64 v0, u64 v1) {   // rows `row` (v0) and `row + 1` (v1) of this lane's column
+        u64 got = swap_pair(odd ? v0 : v1);            // even receives the partner's v0, odd the partner's v1
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 q;
+        q.x = odd ? got : v0;
+        q.y = odd ? v1 : got;
+        if (on) *reinterpret_cast<u64x2 *>(pair + row * SEED_LANES) = q;
+    }
+    __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i, v0, v1); }
+    __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) { row2(PcLayout<HEAD>::SHIP_ROWS + j, v0, v1); }
+};
+struct LdsHalfMem {
+    u64 *col;
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_LANES]; }
+    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(SEED_LANES * 8); }
+    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_LANES] = v; }
+};
+template <int SEED_SPLIT>   // = SPLIT: init blocks done by the producers
+__global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, u64 *__restrict__ tails,
+                                                      uint32_t *__restrict__ lens, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
+    const bool consumer = wave < 2u;
+    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1];
+    switch (prio) {  // s_setprio takes an immediate
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t groups = (paths + SEED_COLS - 1) / SEED_COLS;
+    const uint64_t G0 = groups * blockIdx.x / gridDim.x, G1 = groups * (blockIdx.x + 1) / gridDim.x;   // this workgroup's groups
+    const uint64_t first_path = G0 * SEED_COLS, end_path = G1 * SEED_COLS < paths ? G1 * SEED_COLS : paths;
+    u64 *ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
+    const IsaacWarm warm = isaac_warm();
+    typedef PcLayout<SEED_SPLIT> L;
+    constexpr int SEED_SHIP_ROWS = L::SHIP_ROWS;
+    constexpr size_t SEED_HALF_WORDS = L::HALF_WORDS, SEED_GROUP_WORDS = L::GROUP_WORDS;
+    constexpr int CHUNKS = SEED_SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
+    uint64_t frontier = first_path & ~63ull;                   // first path not yet produced (chunk aligned)
+    for (uint64_t it = 0; it <= G1 - G0; it++) {
+        // ---- producers: complete group G0 + it
+        const uint64_t need = it < G1 - G0 ? (G0 + it + 1) * SEED_COLS : 0;      // paths below `need` must be in the ring
+        uint32_t n = 0;
+        while (frontier < need && frontier < end_path) {
+            if (!consumer && (n & 1u) == half) {
+                const uint64_t pid0 = frontier + lane;
+                const bool on = pid0 >= first_path && pid0 < end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
+                const uint64_t pid = pid0 >= first_path && pid0 < end_path ? pid0 : end_path - 1;
+                const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
+                uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+                uint32_t px, py, sub;
+                tile_lane_pixel(rp, tile, j, px, py, sub);
+                bool valid = px < rp.width && py < rp.height;
+                u64 s, t;
+                path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
+                const uint64_t g = pid / SEED_COLS;
+                const uint32_t c80 = (uint32_t)(pid - g * SEED_COLS);
+                RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
+                              on, lane);
+                isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+            }
+            frontier += 64;
+            n++;
+        }
+        // ---- consumers: group G0 + it - 1
+        if (consumer && it > 0) {
+            const uint64_t g = G0 + it - 1;
+            const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
+            unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+            const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+            u64 st16[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
+            if (!(rp.pad[2] & 8u)) {
+                const unsigned char *srcb = reinterpret_cast<const unsigned char *>(src);
+                // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
+                // address pair serves two 1 KiB copies
+                static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
+                const unsigned char *gsrc = srcb + lane * 16u;
+                unsigned char *ldst = lds_half;
+#pragma unroll 5
+                for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
+                    const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
+                    void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
+                }
+            }
+            const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
+            const bool in_range = pid < paths;
+            const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
+            uint32_t tile = item / rp.num_k;
+            uint32_t px, py, sub;
+            tile_lane_pixel(rp, tile, j, px, py, sub);
+            bool valid = in_range && px < rp.width && py < rp.height;
+            LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
+            if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);   // while the fill is in flight
+            __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's half has landed (no other wave touches it)
+            if (lane < (uint32_t)SEED_LANES) {
+                GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
+                RawLensTail<GlobalTail> lt(gt, lens_shape);
+                isaac_round(m, lt);
+                lt.lens_slow();
+                bool ok = lt.in_window();
+                if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
+                if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+            }
+        }
+        __syncthreads();   // group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
+    }
+}
+
+// raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
+struct RawTail {
+    u64 *out; int window;
+    __device__ __forceinline__ void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; }
+};
+struct LdsMem64 {
+    u64 *col;
+    __device__ __forceinline__ u64 ld(int i) const { return col[i * 64]; }
+    __device__ __forceinline__ uint32_t off(int i) const { return lds_addr(col) + (uint32_t)i * (uint32_t)(64 * 8); }
+    __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
+    __device__ __forceinline__ void st(int i, u64 v) { col[i * 64] = v; }
+};
+__global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
+                                                        int window, u64 *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64 *mem = reinterpret_cast<u64 *>(smem);
+    const uint32_t lane = threadIdx.x;
+    const IsaacWarm warm = isaac_warm();
+    uint32_t idx = blockIdx.x * 64 + lane;
+    bool valid = idx < num_paths;
+    uint32_t p = first_path + (valid ? idx : 0u);
+    uint32_t pix = p >> 2, sub = p & 3u;
+    u64 s, t;
+    path_seed_words(W, H, pix % W, pix / W, sub, s, t);
+    LdsMem64 m{mem + lane};
+    u64 dummy[ISAAC_TAIL];
+    RawTail rt{valid ? out + (size_t)idx * window : dummy, window};
+    isaac_seed_round(m, warm, 8700304ULL, (u64)sampling, s, t, rt);
+}

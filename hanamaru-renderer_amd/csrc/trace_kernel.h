@@ -1,0 +1,197 @@
+// The path-tracing megakernel and the two small debug kernels that share its per-lane code — included by hr_api.hip only (one translation unit: the kernels and the C ABI that launches them).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_scene.h"
+#include "isaac_core.h"
+#include "pt_core.h"
+
+using namespace hr;
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Persistent waves: a workgroup is 4 independent waves (single-wave workgroups cap residency at ~8 waves per CU);
+// every wave pulls 4x4-pixel tiles from a global counter until none are left.  A tile = 64 paths per sampling of
+// the batch; finished lanes are refilled from the tile's path queue, and when that runs dry the wave pulls the
+// next tile while its slow lanes are still working, so lanes only starve at the very end of a launch
+// (measured before: with one tile per wave the mean box-phase pass had 19.6 of 64 lanes active).
+// No barriers, no LDS.
+static const int TRACE_WAVES = 4;
+static const int NODE_UNROLL = 2;   // box tests per pass of the box-phase loop (amortises the ballot / branch overhead)
+
+template <bool CNT, int MINW>
+__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails,
+                                                                       const uint32_t *__restrict__ lens, float *__restrict__ accum,
+                                                                       Counters *cnt, uint32_t *tile_counter) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    LaneCounters lc = {0, 0, 0, 0, 0};
+    uint32_t npaths = 0;
+    uint32_t ph[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform phase statistics (counters build only)
+    unsigned long long pc[4] = {0, 0, 0, 0}, tmark = 0;   // wave-cycles per phase (counters build only)
+#define HR_PHASE_BEGIN() do { if (CNT) tmark = __builtin_readcyclecounter(); } while (0)
+#define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
+    const uint32_t total = 64u * rp.num_k;   // paths per tile in this launch: slot q = k * 64 + j
+    const size_t tile_stride = (size_t)rp.num_k * ISAAC_TAIL * 64;
+    uint32_t cur_tile = 0, next = total;      // wave-uniform: the tile being handed out and its queue head
+    bool exhausted = false;
+    Path p;
+    p.q = PATH_IDLE;
+    p.tile = 0;
+    p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0;
+    const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
+    const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
+
+    for (;;) {
+        // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
+        if (CNT) {
+            uint32_t n = (uint32_t)__popcll(__ballot(p.q != PATH_IDLE && trace_done(p.ts)));
+            ph[6]++;
+            if (n) { ph[0]++; ph[1] += n; }
+        }
+        HR_PHASE_BEGIN();
+        if (p.q != PATH_IDLE && trace_done(p.ts)) {
+            if (path_advance<CNT>(sc, p, tails + (size_t)p.tile * tile_stride, &lc)) {
+                // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
+                // path adds its radiance straight into the accumulator.  A tile belongs to exactly one wave of
+                // one launch, so only lanes of this wave ever touch these addresses: workgroup-scope atomics
+                // (executed in the XCD's L2) are sufficient.
+                uint32_t pix = (p.q & 63u) >> 2;
+                uint32_t px = (p.tile % rp.tiles_x) * 4u + (pix & 3u), py = (p.tile / rp.tiles_x) * 4u + (pix >> 2);
+                float *dst = accum + ((size_t)py * rp.width + px) * 3;
+                __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 2, p.accum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                p.q = PATH_IDLE;
+            }
+        }
+        HR_PHASE_END(0);
+        // ---- B: refill idle lanes (ballot + prefix rank = live-lane compaction); pull a new tile when the queue is dry
+        HR_PHASE_BEGIN();
+        unsigned long long idle = __ballot(p.q == PATH_IDLE);
+        if (idle) {
+            if (next >= total && !exhausted) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(tile_counter, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= tiles) exhausted = true;
+                else { cur_tile = t; next = 0; }
+            }
+            if (next < total) {
+                uint32_t q = next + lane_rank(idle);
+                if (p.q == PATH_IDLE && q < total) {
+                    uint32_t k = q >> 6, j = q & 63u, px, py, sub;
+                    tile_lane_pixel(rp, cur_tile, j, px, py, sub);
+                    if (px < rp.width && py < rp.height) {
+                        p.q = q;
+                        p.tile = cur_tile;
+                        p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
+                        p.lens_a = lens[((size_t)cur_tile * rp.num_k + k) * 64 + j];
+                        path_start(sc, rp, p, px, py, sub, tails + (size_t)cur_tile * tile_stride);
+                        npaths++;
+                    }
+                }
+                next += (uint32_t)__popcll(idle);
+            }
+        }
+        HR_PHASE_END(1);
+        const bool active = p.q != PATH_IDLE;
+        const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+        if (!n_active) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- C: traversal as two well-filled phases.  Box phase: lanes walk nodes until 1/leaf_den of the
+        //         traversing lanes have parked a leaf; leaf phase: those lanes test their primitives together.
+        //         The whole of C is left as soon as 1/adv_den of the live lanes wait for phase A.
+        for (;;) {
+            const bool trav = active && !trace_done(p.ts);
+            const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
+            if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
+            // lanes allowed to be still walking when the leaf phase starts
+            const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
+            const uint32_t walk_max = n_trav - park;
+            HR_PHASE_BEGIN();
+            for (;;) {
+                // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
+                const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
+                const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
+                if (n_go <= walk_max) break;
+                if (CNT) { ph[2]++; ph[3] += n_go; }
+                if (go) {
+                    trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (NODE_UNROLL > 1 && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                }
+            }
+            HR_PHASE_END(2);
+            HR_PHASE_BEGIN();
+            if (CNT) {
+                uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
+                if (n) { ph[4]++; ph[5] += n; }
+            }
+            if (trav && p.ts.leaf != 0) {
+                trace_leaf<CNT>(sc, p.ray, p.ts, &lc);   // clears ts.leaf
+                p.ts.leaf = p.ts.leaf2;
+                p.ts.leaf2 = 0;
+                shadow_early_out(p);
+            }
+            HR_PHASE_END(3);
+        }
+    }
+#undef HR_PHASE_BEGIN
+#undef HR_PHASE_END
+    if (CNT) {
+        // wave reduction, one atomic per counter per wave
+        unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
+        for (int i = 0; i < 6; i++) {
+            unsigned long long x = v[i];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            v[i] = x;
+        }
+        if (lane == 0) {
+            atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
+            atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
+            atomicAdd(&cnt->shade_calls, (unsigned long long)ph[0]); atomicAdd(&cnt->shade_lanes, (unsigned long long)ph[1]);
+            atomicAdd(&cnt->box_passes, (unsigned long long)ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ph[3]);
+            atomicAdd(&cnt->leaf_calls, (unsigned long long)ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ph[5]);
+            atomicAdd(&cnt->outer_iters, (unsigned long long)ph[6]);
+            for (int i = 0; i < 4; i++) atomicAdd(&cnt->phase_cycles[i], pc[i]);
+        }
+    }
+}
+
+__global__ void intersect_debug_kernel(Scene sc, uint32_t n, const float *__restrict__ rays, float *__restrict__ out, int32_t *__restrict__ out_elem) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    ray_set(r, v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
+    TraceState ts;
+    trace_begin(ts, T_INF);
+    LaneCounters lc;
+    while (ts.cur != NODE_END) trace_step<false>(sc, r, ts, &lc);
+    float *o = out + (size_t)i * 8;
+    int32_t elem = -1;
+    if (ts.prim >= 0) {
+        Surf s;
+        hit_surface(sc, r, ts, true, s);
+        elem = s.elem;
+        o[0] = 1.0f; o[1] = ts.t; o[2] = s.pos.x; o[3] = s.pos.y; o[4] = s.pos.z; o[5] = s.n.x; o[6] = s.n.y; o[7] = s.n.z;
+    } else {
+        o[0] = 0.0f; o[1] = ts.t;
+        for (int k = 2; k < 8; k++) o[k] = 0.0f;
+    }
+    out_elem[i] = elem;
+}
+
+// DebugRenderer (renderer.rs:101-146): one thread per pixel, 2x2 sub-samples, pinhole rays
+__global__ void debug_render_kernel(Scene sc, RenderParams rp, int mode, float *__restrict__ accum) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= rp.width || y >= rp.height) return;
+    LaneCounters lc;
+    V3f sum = v3(0, 0, 0);
+    for (uint32_t sub = 0; sub < 4; sub++) sum = sum + debug_pixel<false>(sc, rp, x, y, sub, mode, &lc);
+    float *o = accum + ((size_t)y * rp.width + x) * 3;
+    o[0] += sum.x; o[1] += sum.y; o[2] += sum.z;
+}
