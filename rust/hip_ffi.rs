@@ -40,4 +40,6 @@ extern "C" {
     pub fn hr_resolve(ctx: *mut HrCtx, samplings_done: u32, host_rgb8: *mut u8) -> c_int;
     pub fn hr_bind_accumulator(ctx: *mut HrCtx, device_rgb: *mut f32) -> c_int;
     pub fn hr_accumulator_device_ptr(ctx: *mut HrCtx) -> *mut c_void;
+    /// e.g. ("bvh_builder", 1.0) = build the BVH on the GPU, ("batch", 4.0) = samplings per launch; see hanamaru_hip.h
+    pub fn hr_set_option(ctx: *mut HrCtx, key: *const c_char, value: f64) -> c_int;
 }
