@@ -262,6 +262,11 @@ int emu_render_debug(const emu_scene *e, uint32_t W, uint32_t H, int mode, float
     return 0;
 }
 
+// 0 = node + leaf per visit (trace_step); 1 = the trace kernel's lane schedule: walk with up to one leaf parked, stop at the
+// second (trace_node<.., SPEC>), test the parked leaves in walk order
+static int g_walk_mode = 0;
+void emu_set_walk_mode(int mode) { g_walk_mode = mode; }
+
 int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out, int32_t *out_elem) {
     const Scene &sc = e->view;
     for (uint32_t i = 0; i < n; i++) {
@@ -270,7 +275,14 @@ int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out,
         TraceState ts;
         trace_begin(ts, T_INF);
         LaneCounters lc;
-        while (ts.cur != NODE_END) trace_step<false>(sc, r, ts, &lc);
+        if (g_walk_mode == 0) {
+            while (ts.cur != NODE_END) trace_step<false>(sc, r, ts, &lc);
+        } else {
+            while (!trace_done(ts)) {
+                while (ts.cur != NODE_END && ts.leaf2 == 0) trace_node<false, true>(sc, r, ts, &lc);
+                if (ts.leaf) { trace_leaf<false>(sc, r, ts, &lc); ts.leaf = ts.leaf2; ts.leaf2 = 0; }
+            }
+        }
         float *o = out + (size_t)i * 8;
         int32_t elem = -1;
         if (ts.prim >= 0) {

@@ -17,6 +17,7 @@ def lib():
         L.emu_scene_destroy.argtypes = [C.c_void_p]
         L.emu_set_build_options.argtypes = [C.c_int, C.c_double]
         L.emu_set_builder.argtypes = [C.c_int]
+        L.emu_set_walk_mode.argtypes = [C.c_int]
         L.emu_scene_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_path_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
@@ -75,6 +76,11 @@ def set_build_options(max_leaf=4, split_ratio=0.0, builder=0):
     """builder: 0 = host SAH, 1 = LBVH (the device builder's per-thread code, run sequentially)."""
     lib().emu_set_build_options(max_leaf, split_ratio)
     lib().emu_set_builder(builder)
+
+
+def set_walk_mode(mode):
+    """0 = node + leaf per visit, 1 = the trace kernel's postponed-leaf schedule (EmuScene.intersect)."""
+    lib().emu_set_walk_mode(mode)
 
 
 def path_draws(w, h, x, y, sub, sampling, lens_shape=1):

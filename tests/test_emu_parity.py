@@ -192,3 +192,18 @@ def test_lbvh_single_primitive(ha, emu):
     assert e.stats()["nodes"] == 1
     got, gel = e.intersect(np.array([[0, 0, 0, 0, 0, -1], [0, 0, 0, 0, 1, 0]], dtype=np.float32))
     assert got[0, 0] == 1 and abs(got[0, 1] - 2.0) < 1e-6 and gel[0] == 0 and got[1, 0] == 0
+
+
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "spheres", "cornell_mini"])
+def test_postponed_leaf_walk_gives_the_same_hits(emu, emu_scenes, name):
+    """The trace kernel lets a lane keep walking with one leaf parked (trace_node<.., SPEC>): boxes are then culled against a
+    closest hit that lags by one leaf, leaves are still tested in walk order — hits, t and elements must be identical."""
+    sc, _, e = emu_scenes(name)
+    rays = _random_rays(sc, 3000, 31)
+    ref, rel = e.intersect(rays)
+    emu.set_walk_mode(1)
+    try:
+        got, gel = e.intersect(rays)
+    finally:
+        emu.set_walk_mode(0)
+    assert np.array_equal(got, ref) and np.array_equal(gel, rel)
