@@ -225,6 +225,15 @@ def main():
             roof["traffic"] = int(tj["hbm_bytes_per_path"] * paths_per_launch)
             roof["traffic_source"] = tj["source"]
         out["roofline"] = roof
+        # The other kernel of the pair: per-path ISAAC-64 seeding, bound by LDS capacity x generator latency, not by HBM or MFMA.
+        # Ceiling = 80 generator states per CU / (rest of the init 4.25 us + round 13.05 us, measured with nothing else on the
+        # chip by tools/roundprobe.hip) x 256 CUs.
+        seed_ms = st["seed_kernel_ms"] / max(1, st["seed_launches"])
+        if seed_ms > 0:
+            seed_rate = paths_per_launch / (seed_ms * 1e-3) / 1e6
+            ceiling = 80.0 / 17.3e-6 * 256 / 1e6
+            out["seed_kernel"] = {"kernel": "seed_pc_kernel", "bound": "lds_capacity_x_latency", "avg_launch_ms": round(seed_ms, 4),
+                                  "achieved": round(seed_rate, 1), "peak": round(ceiling, 1), "unit": "Mpaths/s", "frac": round(seed_rate / ceiling, 4)}
 
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
