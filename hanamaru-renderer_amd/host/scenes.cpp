@@ -214,8 +214,7 @@ static void build_rtcamp6_v3(Builder &b) {
 }
 
 // main.rs:54-136: GGX floor with image albedo AND image roughness, two coloured NEE emitters,
-// aperture 0, skybox intensity 0 (so the cubemap's content is irrelevant — the build ships Powerlines, the
-// reference names LancellottiChapel)
+// aperture 0, LancellottiChapel skybox at intensity 0
 static void build_simple(Builder &b) {
     hh_camera_new(V3(0.0, 2.0, 9.0).c(), V3(0.0, 1.0, 0.0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8, &b.sc->desc.camera);
     double radius = 0.6;
@@ -225,18 +224,48 @@ static void build_simple(Builder &b) {
     int albedo = b.add_image_file("textures/2d/checkered_diagonal_10_0.5_1.0_512.png");
     int rough = b.add_image_file("textures/2d/checkered_diagonal_10_0.1_0.6_512.png");
     b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_GGX, 0.8, tex_image(albedo), tex_one(0), tex_image(rough)));
-    b.skybox("textures/cube/Powerlines", V3(0, 0, 0));
+    b.skybox("textures/cube/LancellottiChapel", V3(0, 0, 0));
 }
 
-// BASELINE config 2 (build-defined): sphere generator of main.rs:862-905
-static void build_spheres(Builder &b) {
+// main.rs:139-250: one sphere per surface type (Diffuse, GGX, Specular, Refraction, GGXRefraction) under
+// a spherical light, checkered diffuse floor, LancellottiChapel skybox at intensity 1
+static void build_material_examples(Builder &b) {
+    hh_camera_new(V3(0.0, 2.0, 9.0).c(), V3(0.0, 1.0, 0.0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2, 8.8, &b.sc->desc.camera);
+    const double radius = 0.4;
+    const hr_texture white = tex_one(1), black = tex_one(0), rough = tex_one(0.05);
+    b.add_sphere(V3(-2.0, radius, 0.0), radius, mat(HR_DIFFUSE, 0, white, black, rough));
+    b.add_sphere(V3(-1.0, radius, 0.0), radius, mat(HR_GGX, 0.8, white, black, rough));
+    b.add_sphere(V3(0.0, radius, 0.0), radius, mat(HR_SPECULAR, 0, white, black, rough));
+    b.add_sphere(V3(1.0, radius, 0.0), radius, mat(HR_REFRACTION, 1.5, white, black, rough));
+    b.add_sphere(V3(2.0, radius, 0.0), radius, mat(HR_GGX_REFRACTION, 1.5, white, black, rough));
+    b.add_sphere(V3(0.0, 2.0 + radius, -2.0), radius, mat(HR_DIFFUSE, 0, black, tex_one(20.0), rough));
+    int albedo = b.add_image_file("textures/2d/checkered_diagonal_10_0.5_1.0_512.png");
+    int roughness = b.add_image_file("textures/2d/checkered_diagonal_10_0.1_0.6_512.png");
+    b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_DIFFUSE, 0, tex_image(albedo), black, tex_image(roughness)));
+    b.skybox("textures/cube/LancellottiChapel", V3(1, 1, 1));
+}
+
+// main.rs:725-802: an emissive sphere inside a refractive mesh (houdini_boss.obj), checkered diffuse floor,
+// LancellottiChapel skybox at intensity 0.5, pinhole camera
+static void build_rtcamp6_v1(Builder &b) {
+    hh_camera_new(V3(0.0, 2.0, 10.0).c(), V3(0.0, 1.0, 0.0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8, &b.sc->desc.camera);
+    const double radius = 0.6;
+    b.add_sphere(V3(0.0, 3.1782 * 0.4, 0.0), radius, mat(HR_DIFFUSE, 0, tex_one(1), tex_one(10.0), tex_one(0.05)));
+    b.add_mesh("models/houdini_boss.obj", M44::scale_linear(0.4) * M44::translate(0.0, 3.1782, 2.0) * M44::rotate_y(-0.5),
+               mat(HR_REFRACTION, 1.5, tex_color(V3(0.7, 0.7, 1.0)), tex_one(0), tex_one(0.1)));
+    int albedo = b.add_image_file("textures/2d/checkered_diagonal_10_0.5_1.0_512.png");
+    int roughness = b.add_image_file("textures/2d/checkered_diagonal_10_0.1_0.6_512.png");
+    b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_DIFFUSE, 0, tex_image(albedo), tex_one(0), tex_image(roughness)));
+    b.skybox("textures/cube/LancellottiChapel", V3(0.5, 0.5, 0.5));
+}
+
+// The sphere generator of main.rs:862-905 (ISAAC-64 seed [870,2000,304,2], gen_range + AABB-collision rejection): 100 floating
+// spheres, then 5 emissive ones.  `reference_materials`: GGX f0 0.9 as in init_scene_rtcamp6_v2; otherwise BASELINE config 2's
+// alternating Diffuse / Specular.
+static void generate_spheres(Builder &b, bool reference_materials) {
     const uint64_t seed[4] = {870, 2000, 304, 2};  // main.rs:805
     Isaac64 rng;
     rng.from_seed(seed, 4);
-    hh_camera_new(V3(-5.0, -1.0, 0.0).c(), V3(0, 0, 0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8,
-                  &b.sc->desc.camera);
-    // the reference scene uses the Ryfjallet cubemap (7.5 MB); the build ships only Powerlines, same intensity 0.5
-    b.skybox("textures/cube/Powerlines", V3(0.5, 0.5, 0.5));
     int count = 0;
     while (count < 100) {
         // every attempt consumes 5 draws: px, py, pz, hue, roughness (struct-literal evaluation order)
@@ -245,8 +274,8 @@ static void build_spheres(Builder &b) {
         double hue = rng.gen_range(0.0, 1.0);
         double rough = rng.gen_range(0.0, 1.0);
         if (!b.sphere_collides(V3(px, py, pz), s)) {
-            int surface = (count % 2 == 0) ? HR_DIFFUSE : HR_SPECULAR;
-            b.add_sphere(V3(px, py, pz), s, mat(surface, 0, tex_color(hsv_to_rgb(hue, 1.0, 1.0)), tex_one(0), tex_one(rough)));
+            int surface = reference_materials ? HR_GGX : ((count % 2 == 0) ? HR_DIFFUSE : HR_SPECULAR);
+            b.add_sphere(V3(px, py, pz), s, mat(surface, reference_materials ? 0.9 : 0.0, tex_color(hsv_to_rgb(hue, 1.0, 1.0)), tex_one(0), tex_one(rough)));
             count++;
         }
     }
@@ -261,6 +290,25 @@ static void build_spheres(Builder &b) {
             count++;
         }
     }
+}
+
+// BASELINE config 2 (build-defined): the generated spheres only, Diffuse / Specular, no mesh
+static void build_spheres(Builder &b) {
+    hh_camera_new(V3(-5.0, -1.0, 0.0).c(), V3(0, 0, 0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8,
+                  &b.sc->desc.camera);
+    b.skybox("textures/cube/Ryfjallet", V3(0.5, 0.5, 0.5));
+    generate_spheres(b, false);
+}
+
+// main.rs:804-926: 100 GGX spheres + 5 emitters (five shadow rays per NEE-capable hit) around the
+// refractive fractal dodecahedron, Ryfjallet skybox at intensity 0.5
+static void build_rtcamp6_v2(Builder &b) {
+    hh_camera_new(V3(-5.0, -1.0, 0.0).c(), V3(0, 0, 0).c(), normalize(V3(0, 1, 0)).c(), 10.0, 1, 0.2 * 0.0, 8.8,
+                  &b.sc->desc.camera);
+    b.skybox("textures/cube/Ryfjallet", V3(0.5, 0.5, 0.5));
+    generate_spheres(b, true);
+    b.add_mesh("models/fractal_dodecahedron.obj", M44::scale_linear(1.0) * M44::translate(0.0, 0.0, 0.0) * M44::rotate_y(0.0),
+               mat(HR_REFRACTION, 1.5, tex_color(V3(0.7, 0.7, 1.0)), tex_one(0), tex_one(0.1)));
 }
 
 // Small build-defined scene for tests: every surface type, a textured sphere (lat-long UV), textured
@@ -351,6 +399,9 @@ int hh_scene_create(const char *name, const char *asset_root, hh_scene **out) {
     else if (n == "rtcamp6_dodeca") build_rtcamp6_v3_1(b, true);
     else if (n == "rtcamp6_v3") build_rtcamp6_v3(b);
     else if (n == "simple") build_simple(b);
+    else if (n == "material_examples") build_material_examples(b);
+    else if (n == "rtcamp6_v1") build_rtcamp6_v1(b);
+    else if (n == "rtcamp6_v2") build_rtcamp6_v2(b);
     else if (n == "spheres") build_spheres(b);
     else if (n == "cornell_mini") build_cornell_mini(b);
     else { set_error("unknown scene '%s'", name); return HR_ERR_INVALID; }

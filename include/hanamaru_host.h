@@ -22,12 +22,16 @@ const char *hh_last_error(void);
 /* Scenes (asset paths are resolved relative to `asset_root`, which must contain models/ and textures/):
  *   "rtcamp6_v3_1"  — main.rs:1020-1153, the reference's live scene (BASELINE configs 1, 3, 4)
  *   "spheres"       — BASELINE config 2: the 100+5 sphere generator of main.rs:862-905 (ISAAC-64 seed
- *                     [870,2000,304,2], gen_range + AABB-collision rejection), camera of main.rs:808-817,
+ *                     [870,2000,304,2], gen_range + AABB-collision rejection), camera and skybox of main.rs:808-858,
  *                     GGX replaced by alternating Diffuse/Specular, no mesh
+ *   "rtcamp6_v2"    — main.rs:804-926 as written: the same generator with GGX f0 0.9 spheres, five emitters, the refractive
+ *                     fractal dodecahedron, Ryfjallet skybox
+ *   "rtcamp6_v1"    — main.rs:725-802: emissive sphere inside the refractive houdini_boss mesh, checkered floor
+ *   "material_examples" — main.rs:139-250: one sphere per surface type (incl. GGXRefraction) under a spherical light
  *   "rtcamp6_dodeca"— BASELINE config 5: rtcamp6_v3_1 + models/fractal_dodecahedron.obj with the
  *                     Refraction-1.5 material of main.rs:910-915
  *   "rtcamp6_v3"    — main.rs:928-1017: two emissive spheres (one of radius 1 mm next to the camera), aperture 0.2
- *   "simple"        — main.rs:54-136: GGX floor with image albedo + image roughness, two coloured emitters, black sky
+ *   "simple"        — main.rs:54-136: GGX floor with image albedo + image roughness, two coloured emitters, skybox intensity 0
  *   "cornell_mini"  — tiny build-defined scene touching all five surface types + textured sphere (tests)
  */
 int hh_scene_create(const char *name, const char *asset_root, hh_scene **out);

@@ -20,7 +20,8 @@ def main():
     out = {"tolerance": "per channel |gpu - oracle| <= 1e-2 * max(1, |oracle|)", "cases": []}
     r = ha.Renderer(0)
     for name, w, h, s in [("rtcamp6_v3_1", 480, 270, 1), ("rtcamp6_v3_1", 480, 270, 8), ("spheres", 480, 270, 4), ("rtcamp6_dodeca", 480, 270, 4),
-                          ("rtcamp6_v3", 320, 180, 4), ("cornell_mini", 320, 200, 8)]:
+                          ("rtcamp6_v3", 320, 180, 4), ("cornell_mini", 320, 200, 8), ("material_examples", 320, 180, 4), ("rtcamp6_v1", 320, 180, 4),
+                          ("rtcamp6_v2", 320, 180, 2)]:
         sc = ha.Scene(name)
         o = orc.OracleScene(sc.desc_ptr)
         r.upload_scene(sc)
