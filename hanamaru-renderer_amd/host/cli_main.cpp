@@ -45,7 +45,7 @@ static void usage(const char *prog) {
            "    -s, --sampling SAMPLING\n                        sampling limit\n"
            "    -t, --time TIME     time limit sec\n"
            "    -i, --interval INTERVAL\n                        report interval sec\n"
-           "        --scene NAME    rtcamp6_v3_1 (default) | rtcamp6_v3 | rtcamp6_v2 | rtcamp6_v1 | material_examples | simple |\n"
+           "        --scene NAME    rtcamp6_v3_1 (default) | rtcamp6_v3 | rtcamp6_v2 | rtcamp6_v1 | rtcamp5 | tbf3 | material_examples | simple |\n"
            "                        spheres | rtcamp6_dodeca | cornell_mini\n"
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
            "        --batch N       samplings per progress report (default 32; the library launches 4 at a time)\n"

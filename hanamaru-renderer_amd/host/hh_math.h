@@ -37,6 +37,10 @@ struct M44 {
         M44 m = identity(); m.e[0][0] = sx; m.e[1][1] = sy; m.e[2][2] = sz; return m;
     }
     static M44 scale_linear(double s) { return scale(s, s, s); }
+    static M44 rotate_x(double t) {  // matrix.rs:35-44
+        double s = std::sin(t), c = std::cos(t);
+        M44 m = identity(); m.e[1][1] = c; m.e[1][2] = -s; m.e[2][1] = s; m.e[2][2] = c; return m;
+    }
     static M44 rotate_y(double t) {  // matrix.rs:47-56
         double s = std::sin(t), c = std::cos(t);
         M44 m = identity(); m.e[0][0] = c; m.e[0][2] = s; m.e[2][0] = -s; m.e[2][2] = c; return m;
@@ -60,6 +64,7 @@ inline V3 operator*(const M44 &m, V3 v) {
 
 constexpr double PI = 3.14159265358979323846;
 constexpr double PI2 = 2.0 * PI;
+inline double to_radians(double deg) { return deg * (PI / 180.0); }  // f64::to_radians
 
 void set_error(const char *fmt, ...);
 

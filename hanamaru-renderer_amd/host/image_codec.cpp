@@ -526,6 +526,147 @@ static bool decode(const std::vector<uint8_t> &d, std::vector<uint8_t> &rgba, ui
 
 }  // namespace jpg
 
+// ---------------------------------------------------------------------------------------------- TIFF
+// Baseline TIFF 6.0, what the reference's floor textures need (textures/2d/MarbleFloorTiles2/*.tiff): strips, 8-bit
+// grey / RGB / RGBA chunky, uncompressed or LZW (compression 5, MSB-first codes with the "early change" of the TIFF
+// variant), optional horizontal differencing (predictor 2).  Lossless, so the texels equal what the `image` crate's
+// `tiff` decoder hands to Texture::from_path (texture.rs:80-92).
+namespace tif {
+template <class... A>
+static bool fail(const char *fmt, A... a) { set_error(fmt, a...); return false; }
+struct Reader {
+    const std::vector<uint8_t> &d;
+    bool le;
+    uint16_t u16(size_t o) const { return o + 2 <= d.size() ? (le ? (uint16_t)(d[o] | d[o + 1] << 8) : (uint16_t)(d[o] << 8 | d[o + 1])) : 0; }
+    uint32_t u32(size_t o) const {
+        if (o + 4 > d.size()) return 0;
+        return le ? (uint32_t)d[o] | (uint32_t)d[o + 1] << 8 | (uint32_t)d[o + 2] << 16 | (uint32_t)d[o + 3] << 24
+                  : (uint32_t)d[o] << 24 | (uint32_t)d[o + 1] << 16 | (uint32_t)d[o + 2] << 8 | (uint32_t)d[o + 3];
+    }
+};
+// value k of an IFD entry (type 3 = SHORT, 4 = LONG; inline when it fits in 4 bytes)
+static uint32_t entry_value(const Reader &r, size_t entry, uint32_t k) {
+    const uint16_t type = r.u16(entry + 2);
+    const uint32_t count = r.u32(entry + 4);
+    const size_t size = type == 3 ? 2 : 4;
+    const size_t base = (size * count <= 4) ? entry + 8 : r.u32(entry + 8);
+    return type == 3 ? r.u16(base + 2 * k) : r.u32(base + 4 * k);
+}
+static bool lzw(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t expect) {
+    struct Entry { int prefix; uint8_t byte; uint16_t len; };
+    std::vector<Entry> table(4096);
+    for (int i = 0; i < 256; i++) table[i] = Entry{-1, (uint8_t)i, 1};
+    int next = 258, bits = 9, prev = -1;
+    uint32_t acc = 0;
+    int nacc = 0;
+    size_t pos = 0;
+    std::vector<uint8_t> tmp;
+    auto emit = [&](int code) {
+        tmp.resize(table[code].len);
+        for (int c = code, k = (int)table[code].len - 1; c >= 0; c = table[c].prefix, k--) tmp[k] = table[c].byte;
+        out.insert(out.end(), tmp.begin(), tmp.end());
+    };
+    while (out.size() < expect) {
+        while (nacc < bits) {
+            if (pos >= n) return out.size() >= expect;
+            acc = (acc << 8) | src[pos++];
+            nacc += 8;
+        }
+        int code = (int)((acc >> (nacc - bits)) & ((1u << bits) - 1u));
+        nacc -= bits;
+        if (code == 257) break;                         // EndOfInformation
+        if (code == 256) { next = 258; bits = 9; prev = -1; continue; }   // ClearCode
+        if (prev < 0) {
+            if (code >= 256) return false;
+            emit(code);
+        } else {
+            if (code < next) {
+                emit(code);
+                int c = code;
+                while (table[c].prefix >= 0) c = table[c].prefix;
+                if (next < 4096) table[next++] = Entry{prev, table[c].byte, (uint16_t)(table[prev].len + 1)};
+            } else if (code == next && next < 4096) {
+                int c = prev;
+                while (table[c].prefix >= 0) c = table[c].prefix;
+                table[next++] = Entry{prev, table[c].byte, (uint16_t)(table[prev].len + 1)};
+                emit(code);
+            } else {
+                return false;
+            }
+            if (next == 511 || next == 1023 || next == 2047) bits++;   // early change: one code before the table is full
+        }
+        prev = code;
+    }
+    return out.size() >= expect;
+}
+static bool decode(const std::vector<uint8_t> &d, std::vector<uint8_t> &rgba, uint32_t &W, uint32_t &H) {
+    if (d.size() < 8) return fail("tiff: truncated");
+    Reader r{d, d[0] == 'I'};
+    if (r.u16(2) != 42) return fail("tiff: bad magic");
+    size_t ifd = r.u32(4);
+    const uint16_t n = r.u16(ifd);
+    uint32_t compression = 1, photometric = 2, spp = 1, rows_per_strip = 0xffffffffu, predictor = 1, planar = 1, bits = 8;
+    size_t e_offsets = 0, e_counts = 0;
+    uint32_t n_strips = 0;
+    W = H = 0;
+    for (uint16_t i = 0; i < n; i++) {
+        const size_t e = ifd + 2 + 12 * (size_t)i;
+        const uint16_t tag = r.u16(e);
+        switch (tag) {
+            case 256: W = entry_value(r, e, 0); break;
+            case 257: H = entry_value(r, e, 0); break;
+            case 258: bits = entry_value(r, e, 0); break;
+            case 259: compression = entry_value(r, e, 0); break;
+            case 262: photometric = entry_value(r, e, 0); break;
+            case 273: e_offsets = e; n_strips = r.u32(e + 4); break;
+            case 277: spp = entry_value(r, e, 0); break;
+            case 278: rows_per_strip = entry_value(r, e, 0); break;
+            case 279: e_counts = e; break;
+            case 284: planar = entry_value(r, e, 0); break;
+            case 317: predictor = entry_value(r, e, 0); break;
+            default: break;
+        }
+    }
+    if (!W || !H || !e_offsets || !e_counts) return fail("tiff: missing dimension or strip tags");
+    if (bits != 8 || planar != 1 || spp < 1 || spp > 4 || (compression != 1 && compression != 5) || predictor > 2 || photometric > 2)
+        return fail("tiff: unsupported layout (bits %u, planar %u, samples %u, compression %u, predictor %u)", bits, planar, spp, compression, predictor);
+    if (rows_per_strip > H) rows_per_strip = H;
+    rgba.assign((size_t)W * H * 4, 255);
+    std::vector<uint8_t> strip;
+    for (uint32_t si = 0; si < n_strips; si++) {
+        const uint32_t y0 = si * rows_per_strip;
+        if (y0 >= H) break;
+        const uint32_t rows = std::min(rows_per_strip, H - y0);
+        const size_t off = entry_value(r, e_offsets, si), cnt = entry_value(r, e_counts, si);
+        if (off + cnt > d.size()) return fail("tiff: strip %u out of range", si);
+        const size_t expect = (size_t)rows * W * spp;
+        strip.clear();
+        if (compression == 1) {
+            if (cnt < expect) return fail("tiff: short strip %u", si);
+            strip.assign(d.begin() + off, d.begin() + off + expect);
+        } else if (!lzw(d.data() + off, cnt, strip, expect)) {
+            return fail("tiff: LZW error in strip %u", si);
+        }
+        for (uint32_t y = 0; y < rows; y++) {
+            uint8_t *row = &strip[(size_t)y * W * spp];
+            if (predictor == 2)
+                for (size_t x = spp; x < (size_t)W * spp; x++) row[x] = (uint8_t)(row[x] + row[x - spp]);
+            uint8_t *dst = &rgba[((size_t)(y0 + y) * W) * 4];
+            for (uint32_t x = 0; x < W; x++) {
+                const uint8_t *px = row + (size_t)x * spp;
+                if (spp >= 3) { dst[4 * x] = px[0]; dst[4 * x + 1] = px[1]; dst[4 * x + 2] = px[2]; if (spp == 4) dst[4 * x + 3] = px[3]; }
+                else {
+                    uint8_t g = photometric == 0 ? (uint8_t)(255 - px[0]) : px[0];
+                    dst[4 * x] = dst[4 * x + 1] = dst[4 * x + 2] = g;
+                    if (spp == 2) dst[4 * x + 3] = px[1];
+                }
+            }
+        }
+    }
+    return true;
+}
+}  // namespace tif
+
 }  // namespace hh
 
 extern "C" {
@@ -538,6 +679,7 @@ int hh_decode_image(const char *path, uint8_t **rgba, uint32_t *width, uint32_t 
     if (!hh::read_file(path, d)) return HR_ERR_INVALID;
     bool ok;
     if (d.size() >= 2 && d[0] == 0xff && d[1] == 0xd8) ok = hh::jpg::decode(d, px, *width, *height);
+    else if (d.size() >= 4 && ((d[0] == 'I' && d[1] == 'I') || (d[0] == 'M' && d[1] == 'M'))) ok = hh::tif::decode(d, px, *width, *height);
     else ok = hh::decode_png(d, px, *width, *height);
     if (!ok) return HR_ERR_INVALID;
     *rgba = (uint8_t *)malloc(px.size());

@@ -127,15 +127,43 @@ struct Builder {
         e.faces = sc->face_store.back().data(); e.num_faces = sc->face_store.back().size() / 3;
         sc->elements.push_back(e);
     }
-    // scene.rs:82-87 / bvh.rs:14-18 / scene.rs:366-376: strict-inequality AABB overlap test against all elements
+    // Intersectable::aabb(): sphere scene.rs:82-87, cuboid scene.rs:187, BvhMesh scene.rs:248 = bounds of the triangles
+    // (bvh.rs:51-64,91-99, INF-initialised)
+    static void element_aabb(const hr_element &e, V3 &mn, V3 &mx) {
+        if (e.kind == HR_SPHERE) { mn = V3(e.center) - V3(e.radius, e.radius, e.radius); mx = V3(e.center) + V3(e.radius, e.radius, e.radius); }
+        else if (e.kind == HR_CUBOID) { mn = V3(e.aabb_min); mx = V3(e.aabb_max); }
+        else {
+            const double INF = 1e100;   // config.rs:9
+            mn = V3(INF, INF, INF); mx = V3(-INF, -INF, -INF);
+            for (uint64_t f = 0; f < e.num_faces * 3; f++) {
+                const hr_vec3 &v = e.vertexes[e.faces[f]];
+                mn = V3(std::fmin(mn.x, v.x), std::fmin(mn.y, v.y), std::fmin(mn.z, v.z));
+                mx = V3(std::fmax(mx.x, v.x), std::fmax(mx.y, v.y), std::fmax(mx.z, v.z));
+            }
+        }
+    }
+    // Scene::add_with_check_collisions (scene.rs:366-376) with Aabb::intersect_aabb (bvh.rs:14-18, strict inequalities): the
+    // candidate is the LAST element; it is removed again when its box overlaps the box of any earlier element
+    bool keep_last_if_no_collision() {
+        V3 mn, mx;
+        element_aabb(sc->elements.back(), mn, mx);
+        for (size_t i = 0; i + 1 < sc->elements.size(); i++) {
+            V3 omn, omx;
+            element_aabb(sc->elements[i], omn, omx);
+            bool hit = omn.x < mx.x && omx.x > mn.x && omn.y < mx.y && omx.y > mn.y && omn.z < mx.z && omx.z > mn.z;
+            if (hit) {
+                if (sc->elements.back().kind == HR_MESH) { sc->vertex_store.pop_back(); sc->face_store.pop_back(); }
+                sc->elements.pop_back();
+                return false;
+            }
+        }
+        return true;
+    }
     bool sphere_collides(V3 c, double r) const {
         for (const auto &e : sc->elements) {
-            if (e.kind != HR_SPHERE) continue;
-            V3 oc(e.center);
-            double orr = e.radius;
-            bool hit = (oc.x - orr) < (c.x + r) && (oc.x + orr) > (c.x - r) && (oc.y - orr) < (c.y + r) &&
-                       (oc.y + orr) > (c.y - r) && (oc.z - orr) < (c.z + r) && (oc.z + orr) > (c.z - r);
-            if (hit) return true;
+            V3 omn, omx;
+            element_aabb(e, omn, omx);
+            if (omn.x < (c.x + r) && omx.x > (c.x - r) && omn.y < (c.y + r) && omx.y > (c.y - r) && omn.z < (c.z + r) && omx.z > (c.z - r)) return true;
         }
         return false;
     }
@@ -311,6 +339,107 @@ static void build_rtcamp6_v2(Builder &b) {
                mat(HR_REFRACTION, 1.5, tex_color(V3(0.7, 0.7, 1.0)), tex_one(0), tex_one(0.1)));
 }
 
+// main.rs:252-500 (the reference's `rtcamp5.png`): two bunnies (refraction / GGX), a sphere with a TEXTURED
+// EMISSION (earth map, an NEE emitter), a sphere with an image roughness, five coloured GGX spheres, GGX floor with the TIFF
+// marble albedo + PNG roughness, and 1 + 12 + 30 diamonds (refractive index 2.42) placed by ISAAC-64 gen_range draws with
+// AABB-collision rejection (mesh boxes included)
+static void build_rtcamp5(Builder &b) {
+    const uint64_t seed[4] = {870, 2000, 304, 2};
+    Isaac64 rng;
+    rng.from_seed(seed, 4);
+    hh_camera_new(V3(0.0, 2.5, 9.0).c(), V3(0.0, 1.0, 0.0).c(), normalize(V3(0, 1, 0)).c(), 17.0, 1, 0.15, 8.5, &b.sc->desc.camera);
+    const hr_texture white = tex_one(1), black = tex_one(0);
+    const hr_material diamond = mat(HR_REFRACTION, 2.42, white, black, black);
+    b.add_mesh("models/bunny/bunny_face1000.obj", M44::scale_linear(1.5) * M44::translate(1.2, 0.0, 0.0) * M44::rotate_y(0.2),
+               mat(HR_REFRACTION, 1.5, tex_color(V3(0.7, 0.7, 1.0)), black, tex_one(0.1)));
+    b.add_mesh("models/bunny/bunny_face1000_flip.obj", M44::scale(1.5, 1.5, 1.5) * M44::translate(-1.2, 0.0, 0.0) * M44::rotate_y(-0.2),
+               mat(HR_GGX, 0.8, tex_color(V3(1.0, 0.04, 0.04)), black, tex_one(0.1)));
+    b.add_mesh("models/dia/dia.obj", M44::translate(3.1, 0.0, 0.8) * M44::scale_linear(1.0) * M44::rotate_y(-0.5) * M44::rotate_x(to_radians(40.35)), diamond);
+    int earth = b.add_image_file("textures/2d/earth_inverse_2048.jpg");
+    b.add_sphere(V3(0.0, 0.5, -0.5), 0.5, mat(HR_GGX, 0.8, white, tex_image(earth, V3(5.0, 5.0, 2.0)), tex_one(0.05)));
+    b.add_sphere(V3(-3.5, 0.5, 0.0), 0.5, mat(HR_GGX, 0.8, tex_color(V3(1.0, 1.0, 1.0)), black, tex_image(earth)));
+    b.add_sphere(V3(0.5018854352719382, 0.3899602675366644, 1.8484239850862165), 0.3899602675366644,
+                 mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(0.2, 1.0, 1.0)), black, tex_one(0.01)));
+    b.add_sphere(V3(-0.5748933256792994, 0.2951263257801348, 2.266298272012876), 0.2951263257801348,
+                 mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(0.4, 1.0, 1.0)), black, tex_one(0.05)));
+    b.add_sphere(V3(-0.9865234498515534, 0.3386858117447873, 2.9809338871934585), 0.3386858117447873,
+                 mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(0.6, 1.0, 1.0)), black, tex_one(0.02)));
+    b.add_sphere(V3(0.6946459502665004, 0.2764689077971783, 2.7455446851003025), 0.2764689077971783,
+                 mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(0.05, 1.0, 1.0)), black, tex_one(0.0)));
+    b.add_sphere(V3(3.7027464198816952, 0.3917608374245498, -0.40505849281451556), 0.3917608374245498,
+                 mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(0.8, 1.0, 1.0)), black, tex_one(0.1)));
+    int floor_albedo = b.add_image_file("textures/2d/MarbleFloorTiles2/TexturesCom_MarbleFloorTiles2_1024_c_diffuse.tiff");
+    int floor_rough = b.add_image_file("textures/2d/MarbleFloorTiles2/TexturesCom_MarbleFloorTiles2_1024_roughness.png");
+    b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_GGX, 0.8, tex_image(floor_albedo), black, tex_image(floor_rough)));
+    b.skybox("textures/cube/LancellottiChapel", V3(1, 1, 1));
+    if (!b.ok) return;
+    // (the first generator loop of the reference, main.rs:428-449, runs `while count < 0`: no draws)
+    // diamonds lying on the floor: px, pz, s, ry per attempt (py is the literal 0.0)
+    int count = 0;
+    while (count < 12 && b.ok) {
+        double px = rng.gen_range(-4.5, 4.5), py = 0.0, pz = rng.gen_range(-2.5, 4.5);
+        double s = rng.gen_range(0.7, 1.1);
+        double ry = rng.gen_range(-to_radians(180.0), to_radians(180.0));
+        b.add_mesh("models/dia/dia.obj", M44::translate(px, py, pz) * M44::scale_linear(s) * M44::rotate_y(ry) * M44::rotate_x(to_radians(40.35)), diamond);
+        if (b.ok && b.keep_last_if_no_collision()) count++;
+    }
+    // floating diamonds: px, py, pz, s, ry, rx per attempt
+    count = 0;
+    while (count < 30 && b.ok) {
+        double px = rng.gen_range(-4.5, 4.5), py = rng.gen_range(0.0, 4.0), pz = rng.gen_range(-4.5, 3.5);
+        double s = rng.gen_range(0.6, 1.1);
+        double ry = rng.gen_range(-to_radians(180.0), to_radians(180.0));
+        double rx = rng.gen_range(-to_radians(180.0), to_radians(180.0));
+        b.add_mesh("models/dia/dia.obj", M44::translate(px, py, pz) * M44::scale_linear(s) * M44::rotate_y(ry) * M44::rotate_x(rx), diamond);
+        if (b.ok && b.keep_last_if_no_collision()) count++;
+    }
+}
+
+// main.rs:502-724: the KLab logo mesh (GGX), two fixed + 20 generated diamonds, FOUR earth-textured
+// emissive spheres (four NEE emitters), 8 generated GGX spheres, marble floor, LancellottiChapel skybox at intensity (2,2,3).
+// ISAAC-64 seed [870,2000,304,1].
+static void build_tbf3(Builder &b) {
+    const uint64_t seed[4] = {870, 2000, 304, 1};
+    Isaac64 rng;
+    rng.from_seed(seed, 4);
+    hh_camera_new(V3(0.0, 2.5, 9.0).c(), V3(0.0, 1.5, 0.0).c(), normalize(V3(0, 1, 0)).c(), 19.0, 1, 0.18, 7.0, &b.sc->desc.camera);
+    const hr_texture white = tex_one(1), black = tex_one(0);
+    const hr_material diamond = mat(HR_REFRACTION, 2.42, white, black, black);
+    b.add_mesh("models/klab_logo/klab_logo_triangle.obj", M44::scale_linear(0.4) * M44::translate(0.0, 3.1782, 2.0) * M44::rotate_y(-0.5),
+               mat(HR_GGX, 0.8, tex_color(V3(0.4, 0.4, 1.0)), black, tex_one(0.05)));
+    b.add_mesh("models/dia/dia.obj", M44::translate(1.3, 0.0, 2.2) * M44::scale_linear(1.0) * M44::rotate_y(-0.4) * M44::rotate_x(to_radians(40.35)), diamond);
+    b.add_mesh("models/dia/dia.obj", M44::translate(-0.1, 0.0, 2.4) * M44::scale_linear(1.0) * M44::rotate_y(-1.4) * M44::rotate_x(to_radians(40.35)), diamond);
+    int earth = b.add_image_file("textures/2d/earth_inverse_2048.jpg");
+    b.add_sphere(V3(-1.0, 0.4, 4.0), 0.4, mat(HR_GGX, 0.8, tex_color(V3(1, 1, 1)), tex_image(earth, V3(3.0, 3.0, 1.1)), tex_one(0.01)));
+    b.add_sphere(V3(-3.0, 0.4, -3.5), 0.4, mat(HR_GGX, 0.8, tex_color(V3(0.5, 1.0, 1.0)), tex_image(earth, V3(1.0, 3.0, 3.5)), tex_one(0.01)));
+    b.add_sphere(V3(4.0, 0.2, -4.5), 0.2, mat(HR_GGX, 0.8, tex_color(V3(0.3, 0.7, 1.0)), tex_image(earth, V3(3.0, 3.0, 1.1)), tex_one(0.01)));
+    b.add_sphere(V3(3.0, 0.2, -4.2), 0.2, mat(HR_GGX, 0.8, tex_color(V3(1.0, 0.7, 0.9)), tex_image(earth, V3(2.0, 3.0, 1.0)), tex_one(0.01)));
+    int floor_albedo = b.add_image_file("textures/2d/MarbleFloorTiles2/TexturesCom_MarbleFloorTiles2_1024_c_diffuse.tiff");
+    int floor_rough = b.add_image_file("textures/2d/MarbleFloorTiles2/TexturesCom_MarbleFloorTiles2_1024_roughness.png");
+    b.add_cuboid(V3(-5.0, -1.0, -5.0), V3(5.0, 0.0, 5.0), mat(HR_GGX, 0.8, tex_image(floor_albedo), black, tex_image(floor_rough)));
+    b.skybox("textures/cube/LancellottiChapel", V3(2.0, 2.0, 3.0));
+    if (!b.ok) return;
+    // metal spheres: px, pz, r, roughness per attempt (py is the literal 0.0; the hue depends on the running count)
+    int count = 0;
+    while (count < 8) {
+        double px = rng.gen_range(-3.0, 3.0), py = 0.0, pz = rng.gen_range(-5.0, 5.0);
+        double r = rng.gen_range(0.2, 0.4);
+        double rough = rng.gen_range(0.0, 0.2);
+        b.add_sphere(V3(px, r + py, pz), r, mat(HR_GGX, 0.8, tex_color(hsv_to_rgb(0.2 + 0.1 * (double)count, 1.0, 1.0)), black, tex_one(rough)));
+        if (b.keep_last_if_no_collision()) count++;
+    }
+    // diamonds lying on the floor: px, pz, s, ry per attempt
+    count = 0;
+    while (count < 20 && b.ok) {
+        double px = rng.gen_range(-4.0, 4.0), py = 0.0, pz = rng.gen_range(-5.0, 5.0);
+        double s = rng.gen_range(0.7, 1.1);
+        double ry = rng.gen_range(-to_radians(180.0), to_radians(180.0));
+        b.add_mesh("models/dia/dia.obj", M44::translate(px, py, pz) * M44::scale_linear(s) * M44::rotate_y(ry) * M44::rotate_x(to_radians(40.35)), diamond);
+        if (b.ok && b.keep_last_if_no_collision()) count++;
+    }
+    // (the third generator loop of the reference, main.rs:684-705, runs `while count < 0`: no draws)
+}
+
 // Small build-defined scene for tests: every surface type, a textured sphere (lat-long UV), textured
 // cuboid, a mesh, two NEE emitters, procedural cubemap.  No asset files needed except models/box.obj.
 static void build_cornell_mini(Builder &b) {
@@ -402,6 +531,8 @@ int hh_scene_create(const char *name, const char *asset_root, hh_scene **out) {
     else if (n == "material_examples") build_material_examples(b);
     else if (n == "rtcamp6_v1") build_rtcamp6_v1(b);
     else if (n == "rtcamp6_v2") build_rtcamp6_v2(b);
+    else if (n == "rtcamp5") build_rtcamp5(b);
+    else if (n == "tbf3") build_tbf3(b);
     else if (n == "spheres") build_spheres(b);
     else if (n == "cornell_mini") build_cornell_mini(b);
     else { set_error("unknown scene '%s'", name); return HR_ERR_INVALID; }

@@ -27,6 +27,9 @@ const char *hh_last_error(void);
  *   "rtcamp6_v2"    — main.rs:804-926 as written: the same generator with GGX f0 0.9 spheres, five emitters, the refractive
  *                     fractal dodecahedron, Ryfjallet skybox
  *   "rtcamp6_v1"    — main.rs:725-802: emissive sphere inside the refractive houdini_boss mesh, checkered floor
+ *   "rtcamp5"       — main.rs:252-500: bunnies, an earth-textured emissive sphere, image roughness on a sphere, TIFF marble floor,
+ *                     1 + 12 + 30 diamonds placed by gen_range draws with AABB-collision rejection (matches the reference's rtcamp5.png)
+ *   "tbf3"          — main.rs:502-724: KLab logo mesh, four earth-textured emitters, 8 + 20 generated spheres / diamonds
  *   "material_examples" — main.rs:139-250: one sphere per surface type (incl. GGXRefraction) under a spherical light
  *   "rtcamp6_dodeca"— BASELINE config 5: rtcamp6_v3_1 + models/fractal_dodecahedron.obj with the
  *                     Refraction-1.5 material of main.rs:910-915
@@ -41,7 +44,8 @@ void hh_scene_destroy(hh_scene *scene);
 /* loader.rs:12-59 semantics.  `matrix` = 16 doubles, row-major Matrix44 (matrix.rs:5-7). */
 int hh_load_obj(const char *path, const double *matrix, hr_vec3 **vertexes, uint64_t *num_vertexes,
                 uint64_t **faces, uint64_t *num_faces);
-/* PNG (8-bit, colour types 0/2/3/4/6, non-interlaced) and baseline JPEG -> RGBA8, row 0 = top. */
+/* PNG (8-bit, colour types 0/2/3/4/6, non-interlaced), baseline JPEG and baseline TIFF (8-bit strips, raw or LZW, optional
+ * horizontal predictor) -> RGBA8, row 0 = top. */
 int hh_decode_image(const char *path, uint8_t **rgba, uint32_t *width, uint32_t *height);
 int hh_write_png_rgb8(const char *path, const uint8_t *rgb, uint32_t width, uint32_t height);
 void hh_free(void *p);

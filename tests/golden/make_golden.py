@@ -33,6 +33,12 @@ def main():
     cases = [(480, 270, 0, 0, 0, 0, 1), (480, 270, 479, 269, 1, 1, 1), (1920, 1080, 960, 540, 1, 0, 1024), (3840, 2160, 17, 2000, 0, 1, 4096)]
     draws = np.stack([orc.path_draws(*c, 8) for c in cases])
     np.savez_compressed(os.path.join(OUT, "path_draws.npz"), cases=np.array(cases, dtype=np.uint32), draws=draws)
+    # the reference repository's committed render of init_scene_rtcamp5 (an OUTPUT of the reference binary), downscaled: pins the
+    # scene builder's generator draws + collision rejection (tests/test_host_layer.py)
+    src = "/root/reference/rtcamp5.png"
+    if os.path.exists(src):
+        from PIL import Image
+        Image.open(src).convert("RGB").resize((480, 270), Image.LANCZOS).save(os.path.join(OUT, "reference_rtcamp5_480x270.png"))
 
 
 if __name__ == "__main__":

@@ -64,7 +64,7 @@ def test_axis_aligned_and_degenerate_rays(emu_scenes):
 
 
 @pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 96, 54, 2), ("cornell_mini", 64, 48, 3), ("spheres", 80, 45, 1), ("rtcamp6_dodeca", 50, 29, 1), ("rtcamp6_v3", 72, 40, 2), ("simple", 80, 45, 2),
-                                         ("material_examples", 80, 45, 2), ("rtcamp6_v1", 64, 36, 2), ("rtcamp6_v2", 64, 36, 1)])
+                                         ("material_examples", 80, 45, 2), ("rtcamp6_v1", 64, 36, 2), ("rtcamp6_v2", 64, 36, 1), ("rtcamp5", 64, 36, 1), ("tbf3", 64, 36, 1)])
 def test_radiance_accumulator(emu_scenes, name, w, h, s):
     _, o, e = emu_scenes(name)
     acc, cn = e.render(w, h, 1, s + 1, threads=0)

@@ -92,7 +92,8 @@ def test_closest_hit_matches_oracle(gpu, scenes, name):
 
 @pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 160, 90, 4), ("cornell_mini", 96, 64, 4), ("cornell_mini", 320, 200, 8), ("spheres", 128, 72, 2),
                                          ("rtcamp6_dodeca", 98, 55, 2), ("rtcamp6_v3", 128, 72, 3), ("simple", 160, 90, 3),
-                                         ("material_examples", 160, 90, 3), ("rtcamp6_v1", 128, 72, 2), ("rtcamp6_v2", 128, 72, 1)])
+                                         ("material_examples", 160, 90, 3), ("rtcamp6_v1", 128, 72, 2), ("rtcamp6_v2", 128, 72, 1),
+                                         ("rtcamp5", 128, 72, 2), ("tbf3", 128, 72, 2)])
 def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
     sc, o = scenes(name)
     gpu.upload_scene(sc)

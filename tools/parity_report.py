@@ -21,7 +21,7 @@ def main():
     r = ha.Renderer(0)
     for name, w, h, s in [("rtcamp6_v3_1", 480, 270, 1), ("rtcamp6_v3_1", 480, 270, 8), ("spheres", 480, 270, 4), ("rtcamp6_dodeca", 480, 270, 4),
                           ("rtcamp6_v3", 320, 180, 4), ("cornell_mini", 320, 200, 8), ("material_examples", 320, 180, 4), ("rtcamp6_v1", 320, 180, 4),
-                          ("rtcamp6_v2", 320, 180, 2)]:
+                          ("rtcamp6_v2", 320, 180, 2), ("rtcamp5", 320, 180, 2), ("tbf3", 320, 180, 2)]:
         sc = ha.Scene(name)
         o = orc.OracleScene(sc.desc_ptr)
         r.upload_scene(sc)
