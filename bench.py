@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH")
-    ap.add_argument("--split-ratio", type=float, default=0.0)
+    ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--seed-prio", type=int, default=-1)
     ap.add_argument("--init-prio", type=int, default=-1)
@@ -95,7 +95,7 @@ def main():
         r.set_option("max_leaf", args.max_leaf)
     if args.bvh_builder:
         r.set_option("bvh_builder", args.bvh_builder)
-    if args.split_ratio:
+    if args.split_ratio is not None:
         r.set_option("split_ratio", args.split_ratio)
     r.upload_scene(scene)
     r.set_resolution(W, H)

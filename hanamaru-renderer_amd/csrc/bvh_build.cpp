@@ -192,6 +192,15 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
             out.num_leaves++;
         }
     }
+    {
+        const double root_area = std::max(b.nodes[0].box.area(), 1e-300);
+        double cost = 0;
+        for (size_t i = 0; i < N; i++) {
+            const BNode &bn = b.nodes[i];
+            cost += bn.box.area() / root_area * (1.0 + (bn.left < 0 ? 1.5 * bn.count : 0.0));
+        }
+        out.sah_cost = cost;
+    }
     out.nodes.assign(8 * N, Node{});
     for (int o = 0; o < 8; o++) {
         Node *nd = &out.nodes[(size_t)o * N];

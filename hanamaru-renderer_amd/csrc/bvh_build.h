@@ -21,6 +21,7 @@ struct BuiltBvh {
     uint32_t num_nodes = 0;
     std::vector<uint32_t> order[3];   // per type: leaf-ordered -> caller index
     uint32_t max_depth = 0, num_leaves = 0;
+    double sah_cost = 0;              // sum over nodes of area / root area (one box test each) + 1.5 x per leaf primitive
 };
 
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out);

@@ -42,14 +42,17 @@ static void clip_poly(const std::vector<P3> &in, int axis, double pos, bool keep
         }
     }
 }
-static void split_refs(const std::vector<P3> &poly, uint32_t tri_index, int depth, double ratio_max, std::vector<BuildPrim> &out) {
+// A reference is split at the middle of its longest box extent while its box is (a) much bigger than the part of the triangle
+// inside it (surface area > ratio_max x 4 x area) AND (b) not small next to the scene (surface area > min_sa): finely tessellated
+// meshes are left alone, long thin triangles are cut into up to 2^depth pieces.
+static void split_refs(const std::vector<P3> &poly, uint32_t tri_index, int depth, double ratio_max, double min_sa, std::vector<BuildPrim> &out) {
     double mn[3], mx[3];
     poly_box(poly, mn, mx);
     double d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
     double sa = 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
     double area = poly_area(poly);
     int axis = d[0] > d[1] ? (d[0] > d[2] ? 0 : 2) : (d[1] > d[2] ? 1 : 2);
-    if (depth <= 0 || poly.size() < 3 || !(sa > ratio_max * 4.0 * area) || !(d[axis] > 1e-6)) {
+    if (depth <= 0 || poly.size() < 3 || !(sa > ratio_max * 4.0 * area) || !(sa > min_sa) || !(d[axis] > 1e-6)) {
         BuildPrim p{};
         p.type = 0; p.index = tri_index;
         for (int a = 0; a < 3; a++) { p.bmin[a] = mn[a]; p.bmax[a] = mx[a]; }
@@ -60,8 +63,8 @@ static void split_refs(const std::vector<P3> &poly, uint32_t tri_index, int dept
     std::vector<P3> lo, hi;
     clip_poly(poly, axis, pos, true, lo);
     clip_poly(poly, axis, pos, false, hi);
-    if (lo.size() >= 3) split_refs(lo, tri_index, depth - 1, ratio_max, out);
-    if (hi.size() >= 3) split_refs(hi, tri_index, depth - 1, ratio_max, out);
+    if (lo.size() >= 3) split_refs(lo, tri_index, depth - 1, ratio_max, min_sa, out);
+    if (hi.size() >= 3) split_refs(hi, tri_index, depth - 1, ratio_max, min_sa, out);
 }
 
 static int ferr(std::string &err, int code, const char *fmt, ...) {
@@ -95,10 +98,31 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     std::vector<TriD> tris;
     std::vector<f4> spheres; std::vector<int32_t> sphere_elem;
     std::vector<f4> cuboids;
-    std::vector<BuildPrim> prims;
+    std::vector<BuildPrim> prims;        // one reference per primitive
+    std::vector<BuildPrim> prims_split;  // triangles cut by early split clipping (when enabled), other primitives as they are
+    // split_ratio < 0: build both trees and keep the split one only when it cuts the SAH cost by more than 30 % (measured: below
+    // that the 8 octant copies of the bigger tree cost more than the tighter boxes save)
+    const bool auto_split = split_ratio < 0.0;
+    const double ratio = auto_split ? 1.5 : split_ratio;
     out.materials.assign(sd->num_elements, Material{});
     out.emitters.clear();
     auto f3 = [](float *dst, const hr_vec3 &v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; };
+    double split_min_sa = 0.0;   // early split clipping leaves references alone whose box is below 1e-4 of the scene's
+    if (ratio > 0.0 && host_bvh) {
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        auto grow = [&](double x, double y, double z) {
+            const double p[3] = {x, y, z};
+            for (int a = 0; a < 3; a++) { mn[a] = std::fmin(mn[a], p[a]); mx[a] = std::fmax(mx[a], p[a]); }
+        };
+        for (uint32_t ei = 0; ei < sd->num_elements; ei++) {
+            const hr_element &e = sd->elements[ei];
+            if (e.kind == HR_SPHERE) { grow(e.center.x - e.radius, e.center.y - e.radius, e.center.z - e.radius); grow(e.center.x + e.radius, e.center.y + e.radius, e.center.z + e.radius); }
+            else if (e.kind == HR_CUBOID) { grow(e.aabb_min.x, e.aabb_min.y, e.aabb_min.z); grow(e.aabb_max.x, e.aabb_max.y, e.aabb_max.z); }
+            else if (e.kind == HR_MESH && e.vertexes) for (uint64_t v = 0; v < e.num_vertexes; v++) grow(e.vertexes[v].x, e.vertexes[v].y, e.vertexes[v].z);
+        }
+        const double d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        if (d[0] >= 0) split_min_sa = 1e-4 * 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
     for (uint32_t ei = 0; ei < sd->num_elements; ei++) {
         const hr_element &e = sd->elements[ei];
         Material &m = out.materials[ei];
@@ -119,6 +143,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
             double c3[3] = {e.center.x, e.center.y, e.center.z};
             for (int a = 0; a < 3; a++) { p.bmin[a] = c3[a] - e.radius; p.bmax[a] = c3[a] + e.radius; }
             prims.push_back(p);
+            prims_split.push_back(p);
             spheres.push_back(f4{(float)e.center.x, (float)e.center.y, (float)e.center.z, (float)e.radius});
             sphere_elem.push_back((int32_t)ei);
             // Scene::emissions (scene.rs:356-358): nee_available() (spheres only, scene.rs:89) && emission tint != 0
@@ -133,6 +158,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
             double mn[3] = {e.aabb_min.x, e.aabb_min.y, e.aabb_min.z}, mx[3] = {e.aabb_max.x, e.aabb_max.y, e.aabb_max.z};
             for (int a = 0; a < 3; a++) { p.bmin[a] = mn[a]; p.bmax[a] = mx[a]; }
             prims.push_back(p);
+            prims_split.push_back(p);
             union { int32_t i; float f; } cv;
             cv.i = (int32_t)ei;
             cuboids.push_back(f4{(float)mn[0], (float)mn[1], (float)mn[2], cv.f});
@@ -147,11 +173,12 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
                 const hr_vec3 &a = e.vertexes[i0], &b = e.vertexes[i1], &cc = e.vertexes[i2];
                 t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z;
                 t.v2[0] = cc.x; t.v2[1] = cc.y; t.v2[2] = cc.z; t.elem = (int32_t)ei;
-                if (split_ratio > 0.0) {
+                if (ratio > 0.0 && host_bvh) {
                     std::vector<P3> poly(3);
                     for (int k = 0; k < 3; k++) { poly[0].x[k] = t.v0[k]; poly[1].x[k] = t.v1[k]; poly[2].x[k] = t.v2[k]; }
-                    split_refs(poly, (uint32_t)tris.size(), 6, split_ratio, prims);
-                } else {
+                    split_refs(poly, (uint32_t)tris.size(), 6, ratio, split_min_sa, prims_split);
+                }
+                {
                     BuildPrim p{};
                     p.type = 0; p.index = (uint32_t)tris.size();
                     for (int k = 0; k < 3; k++) {
@@ -171,7 +198,17 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
 
     BuiltBvh bvh;
     if (host_bvh) {
-        build_bvh(prims, max_leaf, bvh);
+        const bool split_ok = ratio > 0.0 && prims_split.size() < (1u << 20);
+        if (split_ok && !auto_split) {
+            build_bvh(prims_split, max_leaf, bvh);
+        } else {
+            build_bvh(prims, max_leaf, bvh);
+            if (split_ok && auto_split && prims_split.size() > prims.size()) {
+                BuiltBvh cut;
+                build_bvh(prims_split, max_leaf, cut);
+                if (cut.sah_cost < 0.7 * bvh.sah_cost) bvh = std::move(cut);
+            }
+        }
     } else {
         // the tree is built on the device (csrc/gpu_bvh.h): primitives stay in input order, only the scene bounds are needed
         for (int a = 0; a < 3; a++) { out.scene_min[a] = 1e300; out.scene_max[a] = -1e300; }
@@ -181,7 +218,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         }
     }
     out.nodes = bvh.nodes; out.num_nodes = bvh.num_nodes;
-    out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves;
+    out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves; out.bvh_sah_cost = bvh.sah_cost;
 
     out.tris.assign(bvh.order[0].size(), Tri{});   // one record per reference (split triangles appear more than once)
     for (size_t i = 0; i < bvh.order[0].size(); i++) {

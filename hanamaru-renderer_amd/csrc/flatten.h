@@ -26,6 +26,7 @@ struct HostScene {
     float sky_intensity[3];
     CameraF cam;
     uint32_t bvh_max_depth = 0, bvh_leaves = 0;
+    double bvh_sah_cost = 0;
     double scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};   // filled when host_bvh == false
     // a Scene whose pointers refer to the vectors above (valid on the host only)
     Scene view() const;
@@ -33,8 +34,9 @@ struct HostScene {
 
 // returns HR_OK or a negative hr_status; `err` receives the message
 // split_ratio > 0 enables early split clipping of triangle references whose box surface area exceeds
-// split_ratio x 4 x (triangle area inside the box)
+// split_ratio x 4 x (triangle area inside the box) and 1e-4 of the scene's; < 0 = automatic (ratio 1.5, kept only when the
+// SAH cost drops by more than 30 %); 0 = off
 // host_bvh = false: no tree is built, primitives keep their input order (the device builds the tree, csrc/gpu_bvh.h)
-int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf = 4, double split_ratio = 0.0, bool host_bvh = true);
+int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int max_leaf = 4, double split_ratio = -1.0, bool host_bvh = true);
 
 }  // namespace hr

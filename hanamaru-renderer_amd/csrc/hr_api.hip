@@ -86,7 +86,7 @@ struct hr_ctx {
     uint32_t adv_den = 2, leaf_den = 2;      // trace-kernel phase thresholds
     int min_waves = 5;                       // occupancy variant of the trace kernel
     int max_leaf = 4;                        // BVH leaf size (next upload)
-    double split_ratio = 0.0;                // early split clipping (0 = off)
+    double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
     int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH (gpu_bvh.h); next upload
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each raw-draw buffer
@@ -616,8 +616,8 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->seed_mode = (int)value;
         return HR_OK;
     }
-    if (k == "split_ratio") {  // early split clipping of triangle references (0 = off), next hr_upload_scene
-        if (value < 0 || value > 1000) return fail(HR_ERR_INVALID, "split_ratio must be in [0,1000]");
+    if (k == "split_ratio") {  // early split clipping of triangle references (-1 = automatic, 0 = off), next hr_upload_scene
+        if ((value < 0 && value != -1) || value > 1000) return fail(HR_ERR_INVALID, "split_ratio must be -1 (automatic), 0 (off) or in (0,1000]");
         c->split_ratio = value;
         return HR_OK;
     }

@@ -168,8 +168,8 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24: how many
  * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH built on the device — replaces the reference's CPU build of
- * bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); measurement knobs: "split_ratio" (early
- * split clipping, host builder), "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
+ * bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
+ * cuts the SAH cost by more than 30 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
  * "debug_skip" (bit mask that drops parts of the pipeline for timing experiments — the image is garbage) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
 

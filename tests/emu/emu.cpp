@@ -80,7 +80,7 @@ static void raw_draws_pc(u64 s, u64 t, uint32_t sampling, int window, uint64_t *
 extern "C" {
 
 static int g_max_leaf = 4;
-static double g_split_ratio = 0.0;
+static double g_split_ratio = -1.0;   // automatic, as the library
 static int g_builder = 0;   // 0 = host SAH (bvh_build.cpp), 1 = LBVH (lbvh_core.h, the device builder's per-thread code run sequentially)
 void emu_set_build_options(int max_leaf, double split_ratio) { g_max_leaf = max_leaf; g_split_ratio = split_ratio; }
 void emu_set_builder(int builder) { g_builder = builder; }
@@ -152,6 +152,8 @@ int emu_scene_create(const hr_scene_desc *sd, emu_scene **out) {
     return 0;
 }
 void emu_scene_destroy(emu_scene *e) { delete e; }
+
+double emu_scene_sah_cost(const emu_scene *e) { return e->hs.bvh_sah_cost; }
 
 // stats: [0]=nodes [1]=leaves [2]=max depth [3]=tris [4]=spheres [5]=cuboids [6]=emitters
 void emu_scene_stats(const emu_scene *e, uint64_t *out) {

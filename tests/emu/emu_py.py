@@ -72,7 +72,7 @@ class EmuScene:
         return out, el
 
 
-def set_build_options(max_leaf=4, split_ratio=0.0, builder=0):
+def set_build_options(max_leaf=4, split_ratio=-1.0, builder=0):
     """builder: 0 = host SAH, 1 = LBVH (the device builder's per-thread code, run sequentially)."""
     lib().emu_set_build_options(max_leaf, split_ratio)
     lib().emu_set_builder(builder)
