@@ -98,6 +98,9 @@ struct hr_ctx {
     double seed_ms = 0, trace_ms = 0, post_ms = 0;
     uint64_t seed_launches = 0, trace_launches = 0;
     uint64_t paths_rendered = 0;
+    // hr_mark / hr_wait: markers on the main stream, oldest first
+    std::vector<std::pair<uint64_t, hipEvent_t>> markers;
+    uint64_t next_ticket = 1;
 };
 
 static void free_scene(hr_ctx *c) {
@@ -138,6 +141,8 @@ static int sync_all(hr_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->trace_pending[0] = c->trace_pending[1] = false;
     c->seed_pending[0] = c->seed_pending[1] = false;
+    for (auto &m : c->markers) (void)hipEventDestroy(m.second);
+    c->markers.clear();
     return drain_events(c);
 }
 
@@ -506,6 +511,30 @@ int hr_synchronize(hr_ctx *c) {
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     if (h.rng_overflow) return fail(HR_ERR_RNG_WINDOW, "%llu paths needed more than %d ISAAC-64 outputs for the lens rejection loop", h.rng_overflow, ISAAC_TAIL);
+    return HR_OK;
+}
+
+int hr_mark(hr_ctx *c, uint64_t *ticket) {
+    if (!c || !ticket) return fail(HR_ERR_INVALID, "hr_mark: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, c->stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); return fail(HR_ERR_DEVICE, "hr_mark: %s", hipGetErrorString(e)); }
+    *ticket = c->next_ticket++;
+    c->markers.emplace_back(*ticket, ev);
+    return HR_OK;
+}
+int hr_wait(hr_ctx *c, uint64_t ticket) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_wait: null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t n = 0;
+    while (n < c->markers.size() && c->markers[n].first <= ticket) n++;
+    if (!n) return HR_OK;   // already waited for (or swept by hr_synchronize)
+    hipError_t e = hipEventSynchronize(c->markers[n - 1].second);
+    for (size_t i = 0; i < n; i++) (void)hipEventDestroy(c->markers[i].second);
+    c->markers.erase(c->markers.begin(), c->markers.begin() + (long)n);
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_wait: %s", hipGetErrorString(e));
     return HR_OK;
 }
 

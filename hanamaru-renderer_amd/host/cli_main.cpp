@@ -134,33 +134,56 @@ int main(int argc, char **argv) {
         sampled = 1;
         sampling = 0;
     }
-    for (uint32_t s = first; s <= sampling;) {
-        uint32_t e = s + (uint32_t)batch;
-        if (e > sampling + 1) e = sampling + 1;
-        CHECK_HR(hr_render(ctx, s, e, 1));
-        CHECK_HR(hr_synchronize(ctx));
-        sampled = e - 1;
+    // One chunk of samplings stays in flight while the host reports on the previous one (hr_mark / hr_wait), so the GPU
+    // never drains between progress lines.  The stop prediction of report_progress (renderer.rs:222-231) therefore looks two
+    // chunks ahead instead of one.
+    struct Chunk { uint32_t begin, end; uint64_t ticket; };
+    auto issue = [&](uint32_t s, Chunk &c) -> int {
+        c.begin = s;
+        c.end = s + (uint32_t)batch;
+        if (c.end > sampling + 1) c.end = sampling + 1;
+        if (hr_render(ctx, c.begin, c.end, 1) != 0 || hr_mark(ctx, &c.ticket) != 0) { fprintf(stderr, "hr_render: %s\n", hr_last_error()); return 1; }
+        return 0;
+    };
+    Chunk cur{}, nxt{};
+    bool have_cur = false, have_next = false;
+    double chunk_sec = 0.0;   // duration of the last completed chunk (0 = not known yet)
+    if (first <= sampling) { if (issue(first, cur)) return 1; have_cur = true; }
+    while (have_cur) {
+        // keep the next chunk in flight unless the samplings run out or the time limit is already in sight
+        double pre = now_sec() - begin;
+        if (cur.end <= sampling && pre + chunk_sec * 2.2 <= time_limit) { if (issue(cur.end, nxt)) return 1; have_next = true; }
+        CHECK_HR(hr_wait(ctx, cur.ticket));
+        sampled = cur.end - 1;
         double now = now_sec();
         double used = now - begin, last = now - last_progress;
         printf("rendering: %ux4 sampled (last %.3f sec). total: %.3f sec (%.2f %%).\n", sampled, last, used, used / time_limit * 100.0);
         bool stop = false;
-        if (used + last * 1.1 > time_limit) { printf("reached time limit\n"); stop = true; }
-        else if (sampled >= sampling) { printf("reached max sampling\n"); stop = true; }
+        if (!have_next && sampled < sampling) { printf("reached time limit\n"); stop = true; }
+        else if (!have_next) { printf("reached max sampling\n"); stop = true; }
         if (stop) {
+            CHECK_HR(hr_synchronize(ctx));
             printf("output final image: %03u.png\n", counter);
             printf("remain: %.3f sec.\n", time_limit - used);
             if (save(sampled)) return 1;
             break;
         }
         if (now - last_image >= interval) {
+            // a progress image needs the accumulator of exactly `sampled` samplings: drain the chunk in flight first
+            CHECK_HR(hr_synchronize(ctx));
+            if (have_next) sampled = nxt.end - 1;
             printf("output progress image: %03u.png\n", counter);
             if (save(sampled)) return 1;
             counter++;
-            last_image = now;
+            last_image = now_sec();
         }
+        chunk_sec = last;
         last_progress = now;
-        s = e;
+        cur = nxt;
+        have_cur = have_next;
+        have_next = false;
     }
+    CHECK_HR(hr_synchronize(ctx));
     if (!ckpt_out.empty()) {
         std::vector<float> acc((size_t)width * height * 3);
         CHECK_HR(hr_read_accumulator(ctx, acc.data()));

@@ -130,6 +130,8 @@ def hip_lib():
         L.hr_clear.argtypes = [C.c_void_p]
         L.hr_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.hr_synchronize.argtypes = [C.c_void_p]
+        L.hr_mark.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.hr_wait.argtypes = [C.c_void_p, C.c_uint64]
         L.hr_render_debug.argtypes = [C.c_void_p, C.c_int]
         L.hr_read_accumulator.argtypes = [C.c_void_p, C.c_void_p]
         L.hr_write_accumulator.argtypes = [C.c_void_p, C.c_void_p]
@@ -266,6 +268,14 @@ class Renderer:
 
     def render_debug(self, mode):
         self._check(self.L.hr_render_debug(self._h, mode))
+
+    def mark(self):
+        t = C.c_uint64()
+        self._check(self.L.hr_mark(self._h, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        self._check(self.L.hr_wait(self._h, C.c_uint64(ticket)))
 
     def synchronize(self):
         self._check(self.L.hr_synchronize(self._h))

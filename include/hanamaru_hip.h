@@ -150,6 +150,12 @@ int hr_clear(hr_ctx *ctx);                 /* zero accumulator + stats */
  * Asynchronous with respect to the host; hr_synchronize() or any read waits. */
 int hr_render(hr_ctx *ctx, uint32_t sampling_begin, uint32_t sampling_end, uint32_t stride);
 int hr_synchronize(hr_ctx *ctx);
+/* hr_render only enqueues.  hr_mark records a marker behind everything enqueued so far; hr_wait blocks until that marker is
+ * reached while later work keeps running (a host loop can keep one chunk of samplings in flight while it reports on the
+ * previous one — the reference's report_progress cadence, renderer.rs:205-251, without draining the GPU).  hr_synchronize
+ * waits for everything and reports kernel-side errors. */
+int hr_mark(hr_ctx *ctx, uint64_t *ticket);
+int hr_wait(hr_ctx *ctx, uint64_t ticket);
 
 /* DebugRenderer (renderer.rs:101-146, max_sampling = 1): adds ONE sampling of the chosen visualiser to the
  * accumulator — pinhole rays, no RNG.  mode: 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane (renderer.rs:102-107;

@@ -453,3 +453,24 @@ def test_device_bvh_build_is_interchangeable(gpu, scenes, name, max_leaf):
     ref, _ = o.render(160, 90, 1, 3, threads=0, counters=True)
     frac, m1, mr = _compare(a1, ref)
     assert frac > FRAC_OK and abs(m1 - mr) <= 2e-3 * max(1e-3, abs(mr))
+
+
+def test_mark_and_wait_keep_the_pipeline_running(gpu, scenes):
+    """hr_mark / hr_wait: waiting for an earlier marker must not disturb later work, and the result equals a plain render."""
+    sc, _ = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(200, 120)
+    gpu.clear()
+    gpu.render(1, 13)
+    ref = gpu.read_accumulator().astype(np.float64)
+    gpu.clear()
+    tickets = []
+    for s in (1, 5, 9):
+        gpu.render(s, s + 4)
+        tickets.append(gpu.mark())
+        if len(tickets) >= 2:
+            gpu.wait(tickets[-2])          # one chunk stays in flight
+    gpu.wait(tickets[0])                    # waiting again for an old ticket is a no-op
+    gpu.wait(tickets[-1])
+    acc = gpu.read_accumulator().astype(np.float64)
+    assert np.abs(acc - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
