@@ -35,6 +35,9 @@ extern "C" {
     pub fn hr_render(ctx: *mut HrCtx, sampling_begin: u32, sampling_end: u32, stride: u32) -> c_int;
     pub fn hr_render_debug(ctx: *mut HrCtx, mode: c_int) -> c_int;
     pub fn hr_synchronize(ctx: *mut HrCtx) -> c_int;
+    /// marker behind everything enqueued so far / wait for it while later work keeps running
+    pub fn hr_mark(ctx: *mut HrCtx, ticket: *mut u64) -> c_int;
+    pub fn hr_wait(ctx: *mut HrCtx, ticket: u64) -> c_int;
     pub fn hr_read_accumulator(ctx: *mut HrCtx, host_rgb: *mut f32) -> c_int;
     pub fn hr_write_accumulator(ctx: *mut HrCtx, host_rgb: *const f32) -> c_int;
     pub fn hr_resolve(ctx: *mut HrCtx, samplings_done: u32, host_rgb8: *mut u8) -> c_int;
