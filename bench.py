@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--seed-prio", type=int, default=-1)
     ap.add_argument("--init-prio", type=int, default=-1)
     ap.add_argument("--seed-split", type=int, default=-1)
+    ap.add_argument("--max-tail-gib", type=float, default=0.0)
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
@@ -110,6 +111,8 @@ def main():
         r.set_option("seed_mode", args.seed_mode)
     if args.seed_prio >= 0:
         r.set_option("seed_prio", args.seed_prio)
+    if args.max_tail_gib:
+        r.set_option("max_tail_gib", args.max_tail_gib)
     if args.seed_split >= 0:
         r.set_option("seed_split", args.seed_split)
     if args.init_prio >= 0:
