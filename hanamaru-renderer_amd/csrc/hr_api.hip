@@ -201,6 +201,7 @@ int hr_destroy(hr_ctx *c) {
     free_scene(c);
     for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events})
         for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &m : c->markers) (void)hipEventDestroy(m.second);
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (int i = 0; i < 2; i++) {
         if (c->tails[i]) (void)hipFree(c->tails[i]);
@@ -380,6 +381,9 @@ int hr_clear(hr_ctx *c) {
 
 static int ensure_draws(hr_ctx *c, size_t items) {
     if (items <= c->draws_cap) return HR_OK;
+    int rc = sync_all(c);   // kernels of an earlier hr_render may still be reading the buffers that are about to be replaced
+    if (rc) return rc;
+    c->draws_cap = 0;       // stays 0 if an allocation below fails: the next call starts over
     for (int i = 0; i < 2; i++) {
         if (c->tails[i]) { HIP_TRY(hipFree(c->tails[i])); c->tails[i] = nullptr; }
         if (c->lens[i]) { HIP_TRY(hipFree(c->lens[i])); c->lens[i] = nullptr; }
