@@ -474,3 +474,27 @@ def test_mark_and_wait_keep_the_pipeline_running(gpu, scenes):
     gpu.wait(tickets[-1])
     acc = gpu.read_accumulator().astype(np.float64)
     assert np.abs(acc - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
+    """Tiny and ragged images, sampling ranges with strides, one or many groups per workgroup: the producer / consumer seed kernel
+    and the fused one must feed the trace kernel the same draws (accumulators equal up to the atomics' summation order)."""
+    sc, _ = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    rng = np.random.default_rng(12)
+    shapes = [(1, 1), (3, 2), (5, 17), (64, 1), (257, 3), (100, 100)] + [(int(rng.integers(1, 400)), int(rng.integers(1, 300))) for _ in range(4)]
+    try:
+        for (w, h) in shapes:
+            begin, stride = int(rng.integers(1, 50)), int(rng.integers(1, 4))
+            end = begin + stride * int(rng.integers(1, 9))
+            gpu.set_resolution(w, h)
+            outs = []
+            for mode in (0, 1):
+                gpu.set_option("seed_mode", mode)
+                gpu.clear()
+                gpu.render(begin, end, stride)
+                outs.append(gpu.read_accumulator().astype(np.float64))
+            assert np.isfinite(outs[1]).all()
+            assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max()), (w, h, begin, end, stride)
+    finally:
+        gpu.set_option("seed_mode", 1)
