@@ -1,7 +1,7 @@
 // hanamaru-hip — host driver with the reference binary's flag surface and outputs (main.rs:1226-1295,
 // renderer.rs:205-251): `hanamaru-hip -w W -h H -s S -t SEC -i SEC`.  Stand-in for the Rust host (no Rust
 // toolchain here): scene authoring + PNG writing stay on the host, the render loop calls the C ABI.
-// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N,
+// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N, --gpus N / --gpu-ids LIST,
 // --checkpoint FILE (write the fp32 accumulator + sampling count when the render stops) and --resume FILE
 // (continue from such a file: samplings are independent and seeded by index, so a resumed render adds exactly
 // the samplings that are missing — SURVEY.md §8f rank 3; the reference has no resumable state).
@@ -49,6 +49,9 @@ static void usage(const char *prog) {
            "                        spheres | rtcamp6_dodeca | cornell_mini\n"
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
            "        --batch N       samplings per progress report (default 32; the library launches 4 at a time)\n"
+           "        --gpus N        render on devices 0..N-1 of this node from this one process: device r takes every N-th sampling,\n"
+           "                        the accumulators are summed on the host when an image is written (default 1)\n"
+           "        --gpu-ids LIST  the same with an explicit comma-separated device list\n"
            "        --checkpoint F  write accumulator + sampling count to F when the render stops\n"
            "        --resume F      continue from a checkpoint file\n",
            prog);
@@ -57,7 +60,8 @@ static void usage(const char *prog) {
 int main(int argc, char **argv) {
     uint32_t width = 1920, height = 1080, sampling = 1000;  // main.rs:1249-1251
     double time_limit = 123.0, interval = 15.0;              // main.rs:1255-1256
-    std::string scene_name = "rtcamp6_v3_1", assets, ckpt_out, ckpt_in;
+    std::string scene_name = "rtcamp6_v3_1", assets, ckpt_out, ckpt_in, gpu_ids;
+    int gpus = 1;
     int batch = 32;  // samplings between two report_progress calls; one host sync (pipeline drain) per report
     bool debug = false;
     for (int i = 1; i < argc; i++) {
@@ -76,6 +80,8 @@ int main(int argc, char **argv) {
         else if (a == "--scene") scene_name = val("scene");
         else if (a == "--assets") assets = val("assets");
         else if (a == "--batch") batch = atoi(val("batch"));
+        else if (a == "--gpus") gpus = atoi(val("gpus"));
+        else if (a == "--gpu-ids") gpu_ids = val("gpu-ids");
         else if (a == "--checkpoint") ckpt_out = val("checkpoint");
         else if (a == "--resume") ckpt_in = val("resume");
         else { fprintf(stderr, "Unrecognized option: '%s'.\n", a.c_str()); return 1; }
@@ -95,11 +101,44 @@ int main(int argc, char **argv) {
     double init_begin = now_sec();
     hh_scene *scene = nullptr;
     if (hh_scene_create(scene_name.c_str(), assets.c_str(), &scene) != 0) { fprintf(stderr, "scene: %s\n", hh_last_error()); return 1; }
-    hr_ctx *ctx = nullptr;
-    CHECK_HR(hr_create(0, &ctx));
-    CHECK_HR(hr_upload_scene(ctx, hh_scene_desc(scene)));
-    CHECK_HR(hr_set_resolution(ctx, width, height));
+    // devices: samplings are independent and seeded by index, so device r of N renders samplings first + r, first + r + N, ...
+    // (bench.py does the same with one process per GPU and an RCCL all-reduce)
+    std::vector<int> devices;
+    if (!gpu_ids.empty()) {
+        for (size_t p = 0; p < gpu_ids.size();) {
+            size_t q = gpu_ids.find(',', p);
+            devices.push_back(atoi(gpu_ids.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+    } else {
+        for (int d = 0; d < (gpus > 0 ? gpus : 1); d++) devices.push_back(d);
+    }
+    const uint32_t ndev = (uint32_t)devices.size();
+    std::vector<hr_ctx *> ctxs(ndev, nullptr);
+    for (uint32_t r = 0; r < ndev; r++) {
+        CHECK_HR(hr_create(devices[r], &ctxs[r]));
+        CHECK_HR(hr_upload_scene(ctxs[r], hh_scene_desc(scene)));
+        CHECK_HR(hr_set_resolution(ctxs[r], width, height));
+    }
+    hr_ctx *ctx = ctxs[0];
+    if (ndev > 1) tee("devices: %u.", ndev);
     tee("init scene: %.2f sec.", now_sec() - init_begin);
+    // sum of all devices' accumulators -> device 0 (for hr_resolve / checkpoints); `own0` keeps device 0's own part
+    std::vector<float> own0, part;
+    auto combine = [&]() -> int {
+        if (ndev == 1) return 0;
+        own0.resize((size_t)width * height * 3);
+        part.resize(own0.size());
+        if (hr_read_accumulator(ctxs[0], own0.data()) != 0) return 1;
+        std::vector<float> total = own0;
+        for (uint32_t r = 1; r < ndev; r++) {
+            if (hr_read_accumulator(ctxs[r], part.data()) != 0) return 1;
+            for (size_t i = 0; i < total.size(); i++) total[i] += part[i];
+        }
+        return hr_write_accumulator(ctxs[0], total.data()) != 0;
+    };
+    auto uncombine = [&]() -> int { return ndev == 1 ? 0 : (hr_write_accumulator(ctxs[0], own0.data()) != 0); };
 
     // Renderer::render + report_progress (renderer.rs:25-46, 205-251) at batch granularity
     std::vector<uint8_t> rgb((size_t)width * height * 3);
@@ -109,7 +148,7 @@ int main(int argc, char **argv) {
         char path[32];
         snprintf(path, sizeof path, "%03u.png", counter);
         double t0 = now_sec();
-        if (hr_resolve(ctx, s, rgb.data()) != 0) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
+        if (combine() || hr_resolve(ctx, s, rgb.data()) != 0 || uncombine()) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
         printf("update_imgbuf: %.3f sec\n", now_sec() - t0);
         return hh_write_png_rgb8(path, rgb.data(), width, height);
     };
@@ -137,12 +176,14 @@ int main(int argc, char **argv) {
     // One chunk of samplings stays in flight while the host reports on the previous one (hr_mark / hr_wait), so the GPU
     // never drains between progress lines.  The stop prediction of report_progress (renderer.rs:222-231) therefore looks two
     // chunks ahead instead of one.
-    struct Chunk { uint32_t begin, end; uint64_t ticket; };
+    struct Chunk { uint32_t begin, end; std::vector<uint64_t> ticket; };
     auto issue = [&](uint32_t s, Chunk &c) -> int {
         c.begin = s;
         c.end = s + (uint32_t)batch;
         if (c.end > sampling + 1) c.end = sampling + 1;
-        if (hr_render(ctx, c.begin, c.end, 1) != 0 || hr_mark(ctx, &c.ticket) != 0) { fprintf(stderr, "hr_render: %s\n", hr_last_error()); return 1; }
+        c.ticket.assign(ndev, 0);
+        for (uint32_t r = 0; r < ndev; r++)
+            if (hr_render(ctxs[r], c.begin + r, c.end, ndev) != 0 || hr_mark(ctxs[r], &c.ticket[r]) != 0) { fprintf(stderr, "hr_render: %s\n", hr_last_error()); return 1; }
         return 0;
     };
     Chunk cur{}, nxt{};
@@ -153,7 +194,7 @@ int main(int argc, char **argv) {
         // keep the next chunk in flight unless the samplings run out or the time limit is already in sight
         double pre = now_sec() - begin;
         if (cur.end <= sampling && pre + chunk_sec * 2.2 <= time_limit) { if (issue(cur.end, nxt)) return 1; have_next = true; }
-        CHECK_HR(hr_wait(ctx, cur.ticket));
+        for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_wait(ctxs[r], cur.ticket[r]));
         sampled = cur.end - 1;
         double now = now_sec();
         double used = now - begin, last = now - last_progress;
@@ -162,7 +203,7 @@ int main(int argc, char **argv) {
         if (!have_next && sampled < sampling) { printf("reached time limit\n"); stop = true; }
         else if (!have_next) { printf("reached max sampling\n"); stop = true; }
         if (stop) {
-            CHECK_HR(hr_synchronize(ctx));
+            for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
             printf("output final image: %03u.png\n", counter);
             printf("remain: %.3f sec.\n", time_limit - used);
             if (save(sampled)) return 1;
@@ -170,7 +211,7 @@ int main(int argc, char **argv) {
         }
         if (now - last_image >= interval) {
             // a progress image needs the accumulator of exactly `sampled` samplings: drain the chunk in flight first
-            CHECK_HR(hr_synchronize(ctx));
+            for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
             if (have_next) sampled = nxt.end - 1;
             printf("output progress image: %03u.png\n", counter);
             if (save(sampled)) return 1;
@@ -183,9 +224,10 @@ int main(int argc, char **argv) {
         have_cur = have_next;
         have_next = false;
     }
-    CHECK_HR(hr_synchronize(ctx));
+    for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
     if (!ckpt_out.empty()) {
         std::vector<float> acc((size_t)width * height * 3);
+        if (combine()) { fprintf(stderr, "checkpoint: %s\n", hr_last_error()); return 1; }
         CHECK_HR(hr_read_accumulator(ctx, acc.data()));
         uint32_t hdr[4] = {0x43415248u, width, height, sampled};
         FILE *f = fopen(ckpt_out.c_str(), "wb");
@@ -198,12 +240,14 @@ int main(int argc, char **argv) {
     hr_stats st;
     if (hr_get_stats(ctx, &st) == 0) {
         double sec = st.trace_kernel_ms * 1e-3;
-        tee("gpu: %.3f Mpaths/s wall, trace kernel %.3f s, seed kernel %.3f s.", (double)st.paths / (now_sec() - begin) * 1e-6, sec, st.seed_kernel_ms * 1e-3);
+        uint64_t paths = st.paths;
+        for (uint32_t r = 1; r < ndev; r++) { hr_stats o; if (hr_get_stats(ctxs[r], &o) == 0) paths += o.paths; }
+        tee("gpu: %.3f Mpaths/s wall, trace kernel %.3f s, seed kernel %.3f s.", (double)paths / (now_sec() - begin) * 1e-6, sec, st.seed_kernel_ms * 1e-3);
     }
     double total = now_sec() - total_begin;
     double used_percent = total / time_limit * 100.0;
     tee("total %g sec. used %.2f %% (x %.2f)", total, used_percent, 100.0 / used_percent);
-    hr_destroy(ctx);
+    for (hr_ctx *c : ctxs) hr_destroy(c);
     hh_scene_destroy(scene);
     if (g_log) fclose(g_log);
     return 0;

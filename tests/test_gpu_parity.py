@@ -11,6 +11,8 @@ Tolerances (stated once, used everywhere):
     one path decorrelates completely), and the image mean agrees to 2e-3 relative.
   * 8-bit image after the post chain, fed the SAME accumulator: <= 1 LSB on every channel, > 99 % exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -498,3 +500,25 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
             assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max()), (w, h, begin, end, stride)
     finally:
         gpu.set_option("seed_mode", 1)
+
+
+def test_cli_multi_device_in_one_process(tmp_path):
+    """hanamaru-hip --gpu-ids a,b: device r renders every N-th sampling, the accumulators are summed on the host for each image.
+    With two contexts on device 0 the image must equal the single-context image (same samplings, other summation order)."""
+    import subprocess
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "hanamaru-renderer_amd", "hanamaru-hip")
+    imgs = []
+    for name, extra in [("one", []), ("two", ["--gpu-ids", "0,0"])]:
+        d = tmp_path / name
+        d.mkdir()
+        out = subprocess.run([exe, "-w", "160", "-h", "90", "-s", "21", "-t", "1000", "--batch", "4", "--scene", "cornell_mini", "--assets", os.path.join(root, "assets")] + extra,
+                             cwd=d, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "sampled: 21x4 spp." in out.stdout
+        if extra:
+            assert "devices: 2." in out.stdout
+        imgs.append(np.asarray(Image.open(d / "result.png")).astype(int))
+    diff = np.abs(imgs[0] - imgs[1])
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.999
