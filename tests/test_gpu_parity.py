@@ -522,3 +522,22 @@ def test_cli_multi_device_in_one_process(tmp_path):
         imgs.append(np.asarray(Image.open(d / "result.png")).astype(int))
     diff = np.abs(imgs[0] - imgs[1])
     assert diff.max() <= 1 and (diff == 0).mean() > 0.999
+
+
+def test_rtcamp5_gpu_render_against_the_references_committed_image(gpu, scenes):
+    """The reference repository ships a render of init_scene_rtcamp5 (rtcamp5.png; golden fixture = its 480x270 downscale).  The
+    GPU image of the same scene (textured emitter, TIFF floor, 43 collision-placed diamonds, refraction index 2.42) must show the
+    same picture; the floor texture of that older render differs, hence correlation rather than PSNR (unrelated scene: 0.64)."""
+    from PIL import Image
+    sc, _ = scenes("rtcamp5")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(960, 540)
+    gpu.clear()
+    gpu.render(1, 65)
+    img = Image.fromarray(gpu.resolve(64)).resize((240, 135), Image.BOX)
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = Image.open(os.path.join(here, "golden", "reference_rtcamp5_480x270.png")).resize((240, 135), Image.BOX)
+    a, b = np.asarray(img).astype(float), np.asarray(ref).astype(float)
+    corr = np.corrcoef(a.ravel(), b.ravel())[0, 1]
+    print("rtcamp5 vs reference image: correlation %.4f, mean abs diff %.2f" % (corr, np.abs(a - b).mean()))
+    assert corr > 0.9 and np.abs(a - b).mean() < 18.0
