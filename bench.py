@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=16)
-    ap.add_argument("--batch", type=int, default=4, help="samplings per kernel launch")
+    ap.add_argument("--batch", type=int, default=0, help="samplings per kernel launch (0 = the library's automatic choice: 4 at 1080p)")
     ap.add_argument("--scene", default="rtcamp6_v3_1")
     ap.add_argument("--adv-den", type=int, default=0, help="trace kernel early-exit denominator (0 = library default)")
     ap.add_argument("--leaf-den", type=int, default=0)
@@ -197,7 +197,7 @@ def main():
         launches = max(1, st["trace_launches"])
         avg_ms = st["trace_kernel_ms"] / launches
         # the library may cap the samplings per launch (hand-off buffer size): use what was actually launched
-        paths_per_launch = st["paths"] / launches if st["paths"] else W * H * 4 * min(args.batch, SPS)
+        paths_per_launch = st["paths"] / launches if st["paths"] else W * H * 4 * min(args.batch or 4, SPS)
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),

@@ -82,7 +82,7 @@ struct hr_ctx {
     uint32_t *d_tile_counter = nullptr;      // [2]: next tile of the trace launch in each slot
     // options (hr_set_option)
     bool counters = false;
-    uint32_t batch = 4;                      // samplings per launch
+    uint32_t batch = 0;                      // samplings per launch; 0 = automatic: about 33 M paths per launch (4 at 1080p, more for small images)
     uint32_t adv_den = 2, leaf_den = 2;      // trace-kernel phase thresholds
     int min_waves = 5;                       // occupancy variant of the trace kernel
     int max_leaf = 4;                        // BVH leaf size (next upload)
@@ -441,7 +441,11 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.pad[2] = (uint32_t)c->debug_skip;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     // the raw-draw hand-off costs 32 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
-    uint32_t batch = std::max<uint32_t>(1, c->batch);
+    uint32_t batch = c->batch;
+    if (!batch) {   // automatic: launches of the size the kernels are tuned on (4 samplings of 1920x1080), at most 64 samplings
+        const uint64_t per_sampling_paths = (uint64_t)tiles * 64u;
+        batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(4, (33177600ull + per_sampling_paths - 1) / per_sampling_paths));
+    }
     {
         uint64_t per_sampling = (uint64_t)tiles * ISAAC_TAIL * 64 * sizeof(u64);
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
@@ -468,7 +472,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(ev.a, c->stream));
         // persistent waves: enough workgroups to fill every CU (6 per CU covers every occupancy variant), never more
         // waves than tiles
-        uint32_t grid = std::min<uint32_t>((uint32_t)c->num_cus * 6u, (tiles + TRACE_WAVES - 1) / TRACE_WAVES);
+        const uint64_t units = (uint64_t)tiles * ((nk + TRACE_KCHUNK - 1) / TRACE_KCHUNK);   // work units of the trace kernel
+        uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * 6u, (units + TRACE_WAVES - 1) / TRACE_WAVES);
         HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
@@ -605,7 +610,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     std::string k = key;
     if (k == "counters") { c->counters = value != 0.0; return HR_OK; }
     if (k == "batch") {
-        if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "batch must be in [1,64]");
+        if (value < 0 || value > 64) return fail(HR_ERR_INVALID, "batch must be in [1,64], or 0 for automatic");
         int rc = sync_all(c);
         if (rc) return rc;
         c->batch = (uint32_t)value;

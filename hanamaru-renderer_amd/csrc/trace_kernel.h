@@ -13,12 +13,13 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 }
 
 // Persistent waves: a workgroup is 4 independent waves (single-wave workgroups cap residency at ~8 waves per CU);
-// every wave pulls 4x4-pixel tiles from a global counter until none are left.  A tile = 64 paths per sampling of
-// the batch; finished lanes are refilled from the tile's path queue, and when that runs dry the wave pulls the
+// every wave pulls work units from a global counter until none are left.  A unit = one 4x4-pixel tile x up to TRACE_KCHUNK
+// samplings of the batch (64 paths per sampling; small images with many samplings per launch still give every wave several units); finished lanes are refilled from the tile's path queue, and when that runs dry the wave pulls the
 // next tile while its slow lanes are still working, so lanes only starve at the very end of a launch
 // (measured before: with one tile per wave the mean box-phase pass had 19.6 of 64 lanes active).
 // No barriers, no LDS.
 static const int TRACE_WAVES = 4;
+static const uint32_t TRACE_KCHUNK = 4;   // samplings per work unit
 static const int NODE_UNROLL = 2;   // box tests per pass of the box-phase loop (amortises the ballot / branch overhead)
 
 template <bool CNT, int MINW>
@@ -33,9 +34,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     unsigned long long pc[4] = {0, 0, 0, 0}, tmark = 0;   // wave-cycles per phase (counters build only)
 #define HR_PHASE_BEGIN() do { if (CNT) tmark = __builtin_readcyclecounter(); } while (0)
 #define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
-    const uint32_t total = 64u * rp.num_k;   // paths per tile in this launch: slot q = k * 64 + j
+    const uint32_t nchunks = (rp.num_k + TRACE_KCHUNK - 1u) / TRACE_KCHUNK, units = tiles * nchunks;
+    uint32_t total = 0, cur_k0 = 0;          // wave-uniform: paths in the current unit (slot q = (k - cur_k0) * 64 + j), its first sampling
     const size_t tile_stride = (size_t)rp.num_k * ISAAC_TAIL * 64;
-    uint32_t cur_tile = 0, next = total;      // wave-uniform: the tile being handed out and its queue head
+    uint32_t cur_tile = 0, next = 0;          // wave-uniform: the tile of the unit being handed out and its queue head
     bool exhausted = false;
     Path p;
     p.q = PATH_IDLE;
@@ -76,16 +78,21 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 uint32_t t = 0;
                 if (lane == 0) t = atomicAdd(tile_counter, 1u);
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                if (t >= tiles) exhausted = true;
-                else { cur_tile = t; next = 0; }
+                if (t >= units) exhausted = true;
+                else {
+                    cur_tile = t / nchunks;
+                    cur_k0 = (t - cur_tile * nchunks) * TRACE_KCHUNK;
+                    total = 64u * (rp.num_k - cur_k0 < TRACE_KCHUNK ? rp.num_k - cur_k0 : TRACE_KCHUNK);
+                    next = 0;
+                }
             }
             if (next < total) {
                 uint32_t q = next + lane_rank(idle);
                 if (p.q == PATH_IDLE && q < total) {
-                    uint32_t k = q >> 6, j = q & 63u, px, py, sub;
+                    uint32_t k = cur_k0 + (q >> 6), j = q & 63u, px, py, sub;
                     tile_lane_pixel(rp, cur_tile, j, px, py, sub);
                     if (px < rp.width && py < rp.height) {
-                        p.q = q;
+                        p.q = (k << 6) | j;   // slot inside the tile's batch (bits 0-5: lane of the tile -> pixel, sub-sample)
                         p.tile = cur_tile;
                         p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
                         p.lens_a = lens[((size_t)cur_tile * rp.num_k + k) * 64 + j];

@@ -169,7 +169,7 @@ int hr_write_accumulator(hr_ctx *ctx, const float *host_rgb); /* resume / post-c
 int hr_resolve(hr_ctx *ctx, uint32_t samplings_done, uint8_t *host_rgb8);
 
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
-/* keys: "counters" (0/1), "batch" (samplings per launch, default 4), "adv_den" / "leaf_den" (trace-kernel phase
+/* keys: "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase
  * thresholds), "min_waves" (3..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
  * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24: how many
  * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),

@@ -103,6 +103,7 @@ def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
     gpu.set_option("batch", 3)
     gpu.render(1, s + 1)
     acc = gpu.read_accumulator()
+    gpu.set_option("batch", 0)   # back to automatic
     ref, _ = o.render(w, h, 1, s + 1, threads=0)
     assert np.isfinite(acc).all()
     frac, m_gpu, m_ref = _compare(acc, ref)
@@ -142,7 +143,7 @@ def test_sharding_and_batching_are_exact_partitions(gpu, scenes):
     gpu.render(1, 9)
     again = gpu.read_accumulator().astype(np.float64)
     assert np.abs(whole - again).max() <= 1e-5 * max(1.0, np.abs(whole).max())
-    gpu.set_option("batch", 4)
+    gpu.set_option("batch", 0)   # back to automatic
 
 
 def test_full_size_properties(gpu, scenes):
@@ -195,7 +196,7 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 0), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_split", 10), ("bvh_builder", 2), ("rng_window", 32)]:
+    for key, bad in [("batch", 65), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_split", 10), ("bvh_builder", 2), ("rng_window", 32)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
     with pytest.raises(ha.HipError):
@@ -241,7 +242,7 @@ def test_no_systematic_bias_at_many_samplings(gpu, scenes):
     gpu.set_option("batch", 8)
     gpu.render(1, s + 1)
     acc = gpu.read_accumulator().astype(np.float64) / (4 * s)
-    gpu.set_option("batch", 4)
+    gpu.set_option("batch", 0)   # back to automatic
     ref, _ = o.render(w, h, 1, s + 1, threads=0)
     ref /= 4 * s
     assert abs(acc.mean() - ref.mean()) <= 5e-4 * ref.mean()
@@ -359,7 +360,7 @@ def test_4k_and_sphere_scene_properties(gpu, scenes):
     gpu.upload_scene(sc)
     gpu.set_resolution(3840, 2160)
     gpu.set_option("counters", 1)
-    gpu.set_option("batch", 4)
+    gpu.set_option("batch", 0)
     gpu.clear()
     gpu.render(1, 3)
     acc = gpu.read_accumulator()
@@ -396,7 +397,7 @@ def test_matches_the_reference_binarys_committed_render(gpu, scenes):
     sc, _ = scenes("rtcamp6_v3_1")
     gpu.upload_scene(sc)
     gpu.set_resolution(1920, 1080)
-    gpu.set_option("batch", 4)
+    gpu.set_option("batch", 0)
     gpu.clear()
     gpu.render(1, 1001)
     img = gpu.resolve(1000).astype(np.float64)
