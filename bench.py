@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--init-prio", type=int, default=-1)
     ap.add_argument("--seed-split", type=int, default=-1)
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
+    ap.add_argument("--trace-wgs", type=int, default=0, help="trace-kernel workgroups per CU (0 = library default)")
+    ap.add_argument("--ring-policy", type=int, default=-1)
+    ap.add_argument("--node-unroll", type=int, default=0)
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
@@ -107,6 +110,12 @@ def main():
         r.set_option("leaf_den", args.leaf_den)
     if args.min_waves:
         r.set_option("min_waves", args.min_waves)
+    if args.trace_wgs:
+        r.set_option("trace_wgs", args.trace_wgs)
+    if args.ring_policy >= 0:
+        r.set_option("ring_policy", args.ring_policy)
+    if args.node_unroll:
+        r.set_option("node_unroll", args.node_unroll)
     if args.seed_mode >= 0:
         r.set_option("seed_mode", args.seed_mode)
     if args.seed_prio >= 0:

@@ -172,7 +172,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
         const float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
         node_set_box(n, mn, mx, 0);   // near > far on every axis: nothing hits it in any octant
         n.a = NODE_END; n.b = NODE_END;
-        out.nodes.assign(8, n);
+        out.nodes.assign(8 + 1, n);
         out.num_nodes = 1;
         return;
     }
@@ -201,30 +201,54 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
         }
         out.sah_cost = cost;
     }
-    out.nodes.assign(8 * N, Node{});
+    // Every octant's copy is stored in ITS OWN traversal order (preorder, near child first): the near child of an inner node
+    // is then the next record in memory, and the trace kernel fetches a node together with its successor in one go — the
+    // dependent load that follows an inner hit is contiguous with its parent (a paired fetch of node + successor was measured: the extra loads cost more than the saved round trips).  One spare record at the very
+    // end keeps that paired fetch in bounds.
+    out.nodes.assign(8 * N + 1, Node{});
+    std::vector<uint32_t> newid(N);
     for (int o = 0; o < 8; o++) {
         Node *nd = &out.nodes[(size_t)o * N];
-        for (size_t i = 0; i < N; i++) {
-            const BNode &bn = b.nodes[i];
-            float mn[3], mx[3];
-            for (int a = 0; a < 3; a++) { mn[a] = round_down(bn.box.mn[a], 2); mx[a] = round_up(bn.box.mx[a], 2); }
-            node_set_box(nd[i], mn, mx, o);
-        }
-        // iterative assignment of the successors with an explicit stack of (node, next_after_subtree)
-        std::vector<std::pair<int, uint32_t>> st;
-        st.emplace_back(0, NODE_END);
+        // pass 1: number the nodes in this octant's order
+        std::vector<int> st;
+        st.push_back(0);
+        uint32_t next = 0;
         while (!st.empty()) {
-            auto [id, after] = st.back();
+            int id = st.back();
             st.pop_back();
+            newid[id] = next++;
             const BNode &bn = b.nodes[id];
-            nd[id].b = after;
-            if (bn.left < 0) { nd[id].a = leaf_word[id]; continue; }
+            if (bn.left < 0) continue;
             bool neg = (o >> bn.axis) & 1;  // ray travels toward -axis: the higher-coordinate child is nearer
             int nearc = neg ? bn.right : bn.left, farc = neg ? bn.left : bn.right;
-            nd[id].a = (uint32_t)nearc;
-            st.emplace_back(nearc, (uint32_t)farc);
-            st.emplace_back(farc, after);
+            st.push_back(farc);
+            st.push_back(nearc);
         }
+        // pass 2: boxes and successors, with an explicit stack of (node, next_after_subtree)
+        std::vector<std::pair<int, uint32_t>> st2;
+        st2.emplace_back(0, NODE_END);
+        while (!st2.empty()) {
+            auto [id, after] = st2.back();
+            st2.pop_back();
+            const BNode &bn = b.nodes[id];
+            Node &n = nd[newid[id]];
+            float mn[3], mx[3];
+            for (int a = 0; a < 3; a++) { mn[a] = round_down(bn.box.mn[a], 2); mx[a] = round_up(bn.box.mx[a], 2); }
+            node_set_box(n, mn, mx, o);
+            n.b = after;
+            if (bn.left < 0) { n.a = leaf_word[id]; continue; }
+            bool neg = (o >> bn.axis) & 1;
+            int nearc = neg ? bn.right : bn.left, farc = neg ? bn.left : bn.right;
+            n.a = newid[nearc];   // == newid[id] + 1
+            st2.emplace_back(nearc, newid[farc]);
+            st2.emplace_back(farc, after);
+        }
+    }
+    {
+        Node &pad = out.nodes[8 * N];
+        const float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+        node_set_box(pad, mn, mx, 0);
+        pad.a = NODE_END; pad.b = NODE_END;
     }
 }
 

@@ -17,7 +17,7 @@ struct BuildPrim {
 };
 
 struct BuiltBvh {
-    std::vector<Node> nodes;          // 8 * num_nodes, octant-major: box + (hit | leaf word, miss)
+    std::vector<Node> nodes;          // 8 * num_nodes (+ 1 spare), octant-major, each octant in its own near-first preorder: box + (hit | leaf word, miss)
     uint32_t num_nodes = 0;
     std::vector<uint32_t> order[3];   // per type: leaf-ordered -> caller index
     uint32_t max_depth = 0, num_leaves = 0;

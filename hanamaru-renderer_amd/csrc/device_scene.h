@@ -88,7 +88,9 @@ struct RenderParams {
     uint32_t sampling_begin, stride, num_k;
     uint32_t adv_den;                 // trace kernel: leave the traversal loop when 1/adv_den of the live lanes are done
     uint32_t leaf_den;                // trace kernel: run the leaf phase when 1/leaf_den of the traversing lanes parked a leaf
-    uint32_t pad[3];
+    uint32_t pad[3];                  // seed kernel: [0] s_setprio of the consumer waves, [1] of the producer waves, [2] debug_skip bits
+    uint32_t ring_policy;             // seed kernel: cache policy of the ring stores (bits 0-1) and of the fill (bits 2-3), see seed_kernels.h
+    uint32_t node_unroll;             // trace kernel: node fetches per pass of the box-phase loop (1 or 2)
 };
 
 // lane j of tile `tile` -> pixel and sub-sample (tile = 4x4 pixels x 4 sub-samples = 64 paths per sampling)
@@ -100,11 +102,24 @@ HD void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint3
     py = ty * 4u + (pix >> 2);
 }
 
-// Hand-off from the seed kernel to the trace kernel, per path: the last ISAAC_TAIL raw generator outputs
-// (draw k = k-th next_u64) as [item][k][64 lanes] u64, plus the index of the accepted lens attempt.
-// A path consumes draws 2*a, 2*a+1 (lens) and 2*(a+i), 2*(a+i)+1 for iteration i = 1..9.
-static const int ISAAC_TAIL = 64;
+// Hand-off from the seed kernel to the trace kernel: a 128-byte record of REC_FLOATS fp32 slots per path,
+//   slots 0 .. REC_DRAWS-1   the path's first draws as the fp32 values the trace kernel computes with (draw k = k-th next_f64, rounded once)
+//   slot  REC_HEAD           index a of the accepted lens attempt (uint bits), then lens x, lens y (2 u - 1, camera.rs:69-70), spare
+// stored per item (= tile x sampling: the 64 paths of one wave-sized tile) as [quad = slot / 4][64 lanes][4 floats]: the seed kernel's
+// lanes (consecutive paths) write 16 bytes each into one contiguous row per store instruction, the trace kernel's lanes read their
+// two draws of an iteration with one 8-byte load and the head with one 16-byte load, both coalesced across the lanes of a tile.
+// A path consumes draws 2*a, 2*a+1 (lens, taken from the head) and 2*(a+i), 2*(a+i)+1 for iteration i = 1..9, so a record covers
+// a <= LENS_FAST-1 rejections; the rare path that needs more (probability (1 - pi/4)^LENS_FAST = 4.6e-4 for the round lens) is
+// queued for the fix-up kernel, which re-derives it with a window of ISAAC_TAIL outputs and rewrites the record rebased to a = 0.
+static const int ISAAC_TAIL = 64;     // raw-output window of the debug and fix-up kernels
+static const int REC_FLOATS = 32;
+static const int REC_DRAWS = 28;
+static const int REC_HEAD = 28;
+static const int LENS_FAST = 5;       // 2 * (LENS_FAST - 1 + 9) + 1 < REC_DRAWS
 static const int DRAWS_PER_PATH = 20; // what a path can consume at most (debug API)
+static const uint32_t REC_ITEM_FLOATS = 64u * REC_FLOATS;   // one item = 8 KiB
+// float index of `slot` of the path whose lane base is item * REC_ITEM_FLOATS + lane * 4
+HD uint32_t rec_slot(uint32_t lane_base, uint32_t slot) { return lane_base + (slot >> 2) * 256u + (slot & 3u); }
 
 struct Counters {
     unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, pad;
@@ -112,6 +127,8 @@ struct Counters {
     unsigned long long shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters, pad2;
     // wave-cycles (s_memtime deltas, summed over the waves) spent in: A shade, B refill, C box phase, C leaf phase
     unsigned long long phase_cycles[4];
+    // seed kernel, option seed_prof: cycles of the consumer waves per phase (seed_kernels.h), [7] = groups processed
+    unsigned long long seed_phase[8];
 };
 
 }  // namespace hr

@@ -69,11 +69,12 @@ struct hr_ctx {
     float *post_tmp = nullptr;
     uint8_t *d_rgb8 = nullptr;
     // seed -> trace hand-off, double buffered (slot = batch & 1)
-    u64 *tails[2] = {nullptr, nullptr};
-    uint32_t *lens[2] = {nullptr, nullptr};
+    float *recs[2] = {nullptr, nullptr};     // 128-byte record per path (device_scene.h)
+    uint32_t *ovf = nullptr;                 // per consumer wave: list of the paths it re-derives at the end of a launch (seed_fixup_wave)
+    u64 *ovf_win = nullptr;                  // per consumer wave: raw-output window of that fix-up
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
     u64 *ring = nullptr;                     // producer / consumer seeding: ring of group buffers, <= 640 KiB per CU
-    int seed_split = 16;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24)
+    int seed_split = 16;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24, 28)
     uint32_t init_prio = 1;                  // s_setprio of the producer waves
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
     bool seed_pending[2] = {false, false}, trace_pending[2] = {false, false};
@@ -85,12 +86,16 @@ struct hr_ctx {
     uint32_t batch = 0;                      // samplings per launch; 0 = automatic: about 33 M paths per launch (4 at 1080p, more for small images)
     uint32_t adv_den = 2, leaf_den = 2;      // trace-kernel phase thresholds
     int min_waves = 5;                       // occupancy variant of the trace kernel
+    uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
+    uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
+    uint32_t ring_policy = 1;                // cache policy of the seed kernel's ring stores / fill (seed_kernels.h)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
     int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH (gpu_bvh.h); next upload
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
-    uint64_t max_tail_bytes = 20ull << 30;   // cap of each raw-draw buffer
+    uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
     int seed_mode = 1;                       // 1 = producer / consumer seed kernel, 0 = fused seed kernel
+    bool seed_prof = false;                  // phase timing build of the producer / consumer seed kernel (splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
@@ -190,7 +195,12 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<28>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
+    HIP_TRY(hipMalloc((void **)&c->ovf, (size_t)c->num_cus * 2 * SEED_OVF_CAP * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&c->ovf_win, (size_t)c->num_cus * 2 * SEED_WIN_WORDS * sizeof(u64)));
     return HR_OK;
 }
 
@@ -204,12 +214,13 @@ int hr_destroy(hr_ctx *c) {
     for (auto &m : c->markers) (void)hipEventDestroy(m.second);
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (int i = 0; i < 2; i++) {
-        if (c->tails[i]) (void)hipFree(c->tails[i]);
-        if (c->lens[i]) (void)hipFree(c->lens[i]);
+        if (c->recs[i]) (void)hipFree(c->recs[i]);
         if (c->seed_done[i]) (void)hipEventDestroy(c->seed_done[i]);
         if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
     }
     if (c->ring) (void)hipFree(c->ring);
+    if (c->ovf) (void)hipFree(c->ovf);
+    if (c->ovf_win) (void)hipFree(c->ovf_win);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->post_tmp) (void)hipFree(c->post_tmp);
@@ -254,7 +265,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     LBVH_ALLOC(word, uint32_t, N, false) LBVH_ALLOC(axis_low, uint32_t, n, false)
     w.parent = parent; w.left = left; w.right = right; w.first = first; w.last = last; w.flags = flags;
     w.bmin = bmin; w.bmax = bmax; w.word = word; w.axis_low = axis_low;
-    LBVH_ALLOC(nodes, Node, 8 * (size_t)N, true)
+    LBVH_ALLOC(nodes, Node, 8 * (size_t)N + 1, true)   // + 1: the trace kernel fetches a record together with the one behind it
     LBVH_ALLOC(tris, Tri, d.num_tris, true)
     LBVH_ALLOC(spheres, f4, d.num_spheres, true)
     LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
@@ -385,10 +396,8 @@ static int ensure_draws(hr_ctx *c, size_t items) {
     if (rc) return rc;
     c->draws_cap = 0;       // stays 0 if an allocation below fails: the next call starts over
     for (int i = 0; i < 2; i++) {
-        if (c->tails[i]) { HIP_TRY(hipFree(c->tails[i])); c->tails[i] = nullptr; }
-        if (c->lens[i]) { HIP_TRY(hipFree(c->lens[i])); c->lens[i] = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->tails[i], (items + 2) * ISAAC_TAIL * 64 * sizeof(u64)));   // + 2 slabs for the padding lanes of the last group
-        HIP_TRY(hipMalloc((void **)&c->lens[i], items * 64 * sizeof(uint32_t)));
+        if (c->recs[i]) { HIP_TRY(hipFree(c->recs[i])); c->recs[i] = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->recs[i], (items + SEED_SPARE_ITEMS) * REC_ITEM_FLOATS * sizeof(float)));   // + spare items for the padding lanes of the last group
     }
     c->draws_cap = items;
     return HR_OK;
@@ -404,18 +413,21 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     if (c->debug_skip & 2) {
     } else if (c->seed_mode == 1) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
-#define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->tails[slot], c->lens[slot], c->d_counters)
-        switch (c->seed_split) {
+#define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
+        if (c->seed_prof && c->seed_split == 20) hipLaunchKernelGGL((seed_pc_kernel<20, true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+        else if (c->seed_prof) hipLaunchKernelGGL((seed_pc_kernel<16, true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+        else switch (c->seed_split) {
             case 8: HR_LAUNCH_PC(8); break;
             case 12: HR_LAUNCH_PC(12); break;
             case 20: HR_LAUNCH_PC(20); break;
             case 24: HR_LAUNCH_PC(24); break;
+            case 28: HR_LAUNCH_PC(28); break;
             default: HR_LAUNCH_PC(16); break;
         }
 #undef HR_LAUNCH_PC
     } else
-        hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->tails[slot],
-                           c->lens[slot], c->d_counters);
+        hipLaunchKernelGGL(seed_isaac64_kernel, dim3(grid), dim3(64 * SEED_WAVES), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->recs[slot], c->ovf, c->ovf_win,
+                           c->d_counters);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, st));
     c->seed_events.push_back(ev);
@@ -436,18 +448,19 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.stride = stride;
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
+    rp.node_unroll = c->node_unroll; rp.ring_policy = c->ring_policy;
     rp.pad[0] = c->seed_prio;
     rp.pad[1] = c->init_prio;
     rp.pad[2] = (uint32_t)c->debug_skip;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
-    // the raw-draw hand-off costs 32 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
+    // the hand-off costs 8 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
     uint32_t batch = c->batch;
     if (!batch) {   // automatic: launches of the size the kernels are tuned on (4 samplings of 1920x1080), at most 64 samplings
         const uint64_t per_sampling_paths = (uint64_t)tiles * 64u;
         batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(4, (33177600ull + per_sampling_paths - 1) / per_sampling_paths));
     }
     {
-        uint64_t per_sampling = (uint64_t)tiles * ISAAC_TAIL * 64 * sizeof(u64);
+        uint64_t per_sampling = (uint64_t)tiles * REC_ITEM_FLOATS * sizeof(float);
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
         batch = (uint32_t)std::min<uint64_t>(batch, fit);
     }
@@ -473,11 +486,11 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         // persistent waves: enough workgroups to fill every CU (6 per CU covers every occupancy variant), never more
         // waves than tiles
         const uint64_t units = (uint64_t)tiles * ((nk + TRACE_KCHUNK - 1) / TRACE_KCHUNK);   // work units of the trace kernel
-        uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * 6u, (units + TRACE_WAVES - 1) / TRACE_WAVES);
+        uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
         HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
-#define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->tails[slot], c->lens[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
+#define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
             if (c->debug_skip & 16) {
             } else if (c->counters) HR_LAUNCH_TRACE(true, 3);
             else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4);
@@ -519,7 +532,7 @@ int hr_synchronize(hr_ctx *c) {
     if (rc) return rc;
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-    if (h.rng_overflow) return fail(HR_ERR_RNG_WINDOW, "%llu paths needed more than %d ISAAC-64 outputs for the lens rejection loop", h.rng_overflow, ISAAC_TAIL);
+    if (h.rng_overflow) return fail(HR_ERR_RNG_WINDOW, "%llu paths needed more than %d ISAAC-64 outputs for the lens rejection loop (or the fix-up queue overflowed)", h.rng_overflow, ISAAC_TAIL);
     return HR_OK;
 }
 
@@ -601,6 +614,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
     for (int i = 0; i < 4; i++) out->phase_cycles[i] = h.phase_cycles[i];
+    for (int i = 0; i < 8; i++) out->seed_phase_cycles[i] = h.seed_phase[i];
     out->bvh_nodes = c->st_nodes; out->triangles = c->st_tris; out->spheres = c->st_spheres; out->cuboids = c->st_cuboids;
     return HR_OK;
 }
@@ -626,6 +640,21 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->min_waves = (int)value;
         return HR_OK;
     }
+    if (k == "ring_policy") {
+        if (value < 0 || value > 15) return fail(HR_ERR_INVALID, "ring_policy must be in [0,15]");
+        c->ring_policy = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "node_unroll") {
+        if (value != 1 && value != 2) return fail(HR_ERR_INVALID, "node_unroll must be 1 or 2");
+        c->node_unroll = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "trace_wgs") {
+        if (value < 1 || value > 8) return fail(HR_ERR_INVALID, "trace_wgs must be in [1,8]");
+        c->trace_wgs = (uint32_t)value;
+        return HR_OK;
+    }
     if (k == "max_tail_gib") {
         if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
         c->max_tail_bytes = (uint64_t)value << 30;
@@ -637,7 +666,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "seed_split") {
-        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24) return fail(HR_ERR_INVALID, "seed_split must be 8, 12, 16, 20 or 24");
+        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24 && value != 28) return fail(HR_ERR_INVALID, "seed_split must be 8, 12, 16, 20, 24 or 28");
         c->seed_split = (int)value;
         return HR_OK;
     }
@@ -647,6 +676,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
+    if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
     if (k == "seed_mode") {
         if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "seed_mode must be 1 (producer / consumer waves, default) or 0 (fused kernel)");
         int rc = sync_all(c);
@@ -714,22 +744,21 @@ int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, tiles))) return rc;
     if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
-    std::vector<u64> h((size_t)tiles * ISAAC_TAIL * 64);
-    std::vector<uint32_t> hl((size_t)tiles * 64);
+    std::vector<float> h((size_t)tiles * REC_ITEM_FLOATS);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(h.data(), c->tails[0], h.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hl.data(), c->lens[0], hl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), c->recs[0], h.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (uint32_t t = 0; t < tiles; t++)
         for (uint32_t j = 0; j < 64; j++) {
             uint32_t tx = t % rp.tiles_x, ty = t / rp.tiles_x, pix = j >> 2, sub = j & 3;
             uint32_t px = tx * 4 + (pix & 3), py = ty * 4 + (pix >> 2);
             if (px >= c->W || py >= c->H) continue;
-            const u64 *col = &h[(size_t)t * ISAAC_TAIL * 64 + j];
-            uint32_t a = hl[(size_t)t * 64 + j];
+            const float *rec = &h[(size_t)t * REC_ITEM_FLOATS];
+            const uint32_t lb = j * 4u;
+            uint32_t a = float_as_uint(rec[rec_slot(lb, REC_HEAD)]);
             float *o = &host_out[(((size_t)py * c->W + px) * 4 + sub) * DRAWS_PER_PATH];
-            o[0] = draw_lens_f32(col[(2 * a) * 64]);
-            o[1] = draw_lens_f32(col[(2 * a + 1) * 64]);
-            for (uint32_t d = 2; d < (uint32_t)DRAWS_PER_PATH; d++) o[d] = draw_f32(col[(2 * a + d) * 64]);
+            o[0] = rec[rec_slot(lb, REC_HEAD + 1)];
+            o[1] = rec[rec_slot(lb, REC_HEAD + 2)];
+            for (uint32_t d = 2; d < (uint32_t)DRAWS_PER_PATH; d++) o[d] = rec[rec_slot(lb, 2 * a + d)];
         }
     return drain_events(c);
 }

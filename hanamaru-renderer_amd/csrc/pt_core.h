@@ -146,31 +146,36 @@ HD void cuboid_test(const f4 &mn, const f4 &mx, const Ray &r, TraceState &ts, in
 // SPEC (trace kernel): a lane whose first leaf is still parked keeps walking until it finds a second one ("postponed
 // leaf": fuller box AND leaf phases); the box it tests meanwhile is culled against a closest hit that does not yet include
 // the parked leaf's primitives, which can only add node visits, never lose a hit.  Leaves are still tested in walk order.
-template <bool CNT, bool SPEC = false>
-HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
-    const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
-    if (CNT) cn->node_tests++;
-    float tmin, tmax;
-    // slab test of bvh.rs:20-39 with the planes already sorted along the ray (near / far per octant, device_scene.h): entry
-    // distance = max of the near terms, exit distance = min of the far terms.  A NaN term (origin exactly on a plane the ray
-    // runs parallel to) is ignored by max3 / min3, which keeps the test conservative.  Packed pairs: three subtracts, three
-    // multiplies.
+// slab test of bvh.rs:20-39 with the planes already sorted along the ray (near / far per octant, device_scene.h): entry
+// distance = max of the near terms, exit distance = min of the far terms.  A NaN term (origin exactly on a plane the ray
+// runs parallel to) is ignored by max3 / min3, which keeps the test conservative.  Packed pairs: three subtracts, three
+// multiplies.
+HD bool node_hit(const Node &nd, const Ray &r, float tbest) {
     const f2v oxy = {r.o.x, r.o.y}, ozz = {r.o.z, r.o.z}, ixy = {r.inv.x, r.inv.y}, izz = {r.inv.z, r.inv.z};
     const f2v nxy = {nd.nearx, nd.neary}, fxy = {nd.farx, nd.fary}, zz = {nd.nearz, nd.farz};
     const f2v tn = (nxy - oxy) * ixy, tf = (fxy - oxy) * ixy, tz = (zz - ozz) * izz;
-    tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
-    tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
-    const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
-    const bool leaf = node_word_is_leaf(nd.a);
-    ts.cur = (hit && !leaf) ? nd.a : nd.b;
+    const float tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
+    const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
+    return tmin <= tmax && !signbit(tmax) && tmin <= tbest;
+}
+template <bool SPEC>
+HD void node_advance(TraceState &ts, bool hit, uint32_t a, uint32_t b) {
+    const bool leaf = node_word_is_leaf(a);
+    ts.cur = (hit && !leaf) ? a : b;
     if (SPEC) {
-        const uint32_t found = (hit && leaf) ? nd.a : 0u;
+        const uint32_t found = (hit && leaf) ? a : 0u;
         const bool first = ts.leaf == 0u;
         ts.leaf2 = first ? 0u : found;
         ts.leaf = first ? found : ts.leaf;
     } else {
-        ts.leaf = (hit && leaf) ? nd.a : 0u;
+        ts.leaf = (hit && leaf) ? a : 0u;
     }
+}
+template <bool CNT, bool SPEC = false>
+HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
+    if (CNT) cn->node_tests++;
+    node_advance<SPEC>(ts, node_hit(nd, r, ts.t), nd.a, nd.b);
 }
 template <bool CNT>
 HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
@@ -383,8 +388,8 @@ HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3
 struct Path {
     uint32_t q;           // path slot inside the tile batch, 0xffffffff = lane idle
     uint32_t tile;        // the 4x4-pixel tile the path belongs to (a wave works on several tiles over its life)
-    uint32_t draw_base;   // index of raw draw 0 of this path in the tile's tail buffer (stride 64 between draws)
-    uint32_t lens_a;      // accepted lens attempt: the path's draws start at 2 * lens_a
+    uint32_t draw_base;   // lane base of this path's hand-off record inside the tile's block of records (device_scene.h rec_slot)
+    uint32_t draw0;       // 2 * a (a = accepted lens attempt): iteration i reads draws draw0 + 2 i, draw0 + 2 i + 1
     int32_t iter;         // 1..9 (renderer.rs:174)
     int32_t phase;        // 0 = main ray in flight, 1 = shadow ray in flight
     Ray ray;
@@ -401,15 +406,17 @@ struct Path {
 };
 static const uint32_t PATH_IDLE = 0xffffffffu;
 
-// camera.rs:83-96 with the lens rejection loop already resolved by the seed kernel (attempt p.lens_a)
-HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const u64 *draws) {
+// camera.rs:83-96 with the lens rejection loop already resolved by the seed kernel (record head: attempt a, lens x, lens y).
+// In: p.draw_base = lane base of the path's record inside `recs` (the tile's block of records).
+HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const float *recs) {
     float fx = (float)px, fy = (float)(rp.height - py);
     float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
     float m = (float)(rp.width < rp.height ? rp.width : rp.height);
     float ncx = ((fx + ox) * 2.0f - (float)rp.width) * HR_RCP(m), ncy = ((fy + oy) * 2.0f - (float)rp.height) * HR_RCP(m);
     const CameraF &c = sc.cam;
-    float lx = draw_lens_f32(draws[p.draw_base + 64u * (2u * p.lens_a)]) * c.lens_radius;
-    float ly = draw_lens_f32(draws[p.draw_base + 64u * (2u * p.lens_a + 1u)]) * c.lens_radius;
+    const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(p.draw_base, REC_HEAD));
+    float lx = head.y * c.lens_radius, ly = head.z * c.lens_radius;
+    p.draw0 = 2u * float_as_uint(head.x);
     V3f lens_pos = v3(c.right) * lx + v3(c.up) * ly;
     V3f dir = normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward) - lens_pos);
     ray_set(p.ray, v3(c.eye) + lens_pos, dir);
@@ -450,12 +457,12 @@ HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
 
 // returns true when the path is finished (accum final)
 template <bool CNT>
-HD bool path_advance(const Scene &sc, Path &p, const u64 *draws, LaneCounters *cn) {
+HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *cn) {
     if (CNT) cn->rays++;
     const bool hit = p.ts.prim >= 0;
     if (p.phase == 0) {
-        p.r0 = draw_f32(draws[p.draw_base + 64u * (2u * (p.lens_a + (uint32_t)p.iter))]);        // renderer.rs:175
-        p.r1 = draw_f32(draws[p.draw_base + 64u * (2u * (p.lens_a + (uint32_t)p.iter) + 1u)]);
+        const f2v r01 = *reinterpret_cast<const f2v *>(recs + rec_slot(p.draw_base, p.draw0 + 2u * (uint32_t)p.iter));   // renderer.rs:175
+        p.r0 = r01[0]; p.r1 = r01[1];
         if (!hit) {  // scene.rs:398 + renderer.rs:196,199
             p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
             return true;

@@ -1,5 +1,6 @@
 // ISAAC-64 seeding kernels: seed_pc_kernel (producer / consumer waves, default), seed_isaac64_kernel (fused),
-// seed_debug_kernel (raw outputs for the parity tests) — included by hr_api.hip only (one translation unit: the kernels and the C ABI that launches them).
+// seed_debug_kernel (raw outputs for the parity tests); the rare paths whose lens rejection loop runs past the hand-off record are
+// re-derived by the consumer waves themselves at the end of a launch (seed_fixup_wave) — included by hr_api.hip only (one translation unit: the kernels and the C ABI that launches them).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,29 +25,88 @@ struct LdsMem {
     __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
     __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_COLS] = v; }
 };
-// global-memory tail of one path: [k][64 lanes] u64 inside the item's slab
-// (the padding lanes of the last group write into two spare slabs behind the last item: no predicate in the hot loop)
-struct GlobalTail {
-    u64 *col;  // &tail[item][0][lane]
-    __device__ __forceinline__ u64 ld(int k) const { return col[k * 64]; }
-    __device__ __forceinline__ void st(int k, u64 v) { col[k * 64] = v; }
+// the path's hand-off record in global memory (device_scene.h: [item][quad][lane][4]); four slots = one quad per store
+// (the padding lanes of the last group write into spare items behind the last one: no predicate in the hot loop)
+struct RecStore {
+    float *rec;   // &recs[item * REC_ITEM_FLOATS + lane * 4]
+    __device__ __forceinline__ RecStore(float *recs, uint64_t pid) : rec(recs + (size_t)(pid >> 6) * REC_ITEM_FLOATS + (size_t)(pid & 63u) * 4u) {}
+    __device__ __forceinline__ void st4(int slot, float a, float b, float c, float d) {
+        f4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+        *reinterpret_cast<f4 *>(rec + (slot >> 2) * 256) = v;
+    }
 };
+static const uint32_t SEED_SPARE_ITEMS = 3;
+
+// ---- fix-up of the paths whose lens rejection loop runs past the hand-off record ----------------------------------------------
+// A consumer wave notes such paths (all LENS_FAST first attempts rejected: 4.6e-4 of the paths of a round-lens camera) in its own
+// list and, when its share of the launch is done, re-derives them in its own LDS columns with the fused init + round, keeping
+// the last ISAAC_TAIL raw outputs in a per-wave scratch window; the reference's rejection loop is replayed over that window and
+// the record rewritten rebased to a = 0 (record_from_window).  All bookkeeping is per wave: no atomics, no extra kernel, nothing
+// between the seed kernels on their stream.  A path that would need more than ISAAC_TAIL outputs (probability 4e-16), or a list
+// that overflows, is counted in rng_overflow and reported by hr_synchronize as HR_ERR_RNG_WINDOW instead of producing a wrong image.
+static const uint32_t SEED_OVF_CAP = 2048;                 // entries per consumer wave
+static const uint32_t SEED_WIN_WORDS = ISAAC_TAIL * 40;   // u64 per consumer wave: [ISAAC_TAIL][40 lanes]
+__device__ __forceinline__ uint32_t wave_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ void ovf_note(bool ov, uint64_t pid, uint32_t *list, uint32_t &count) {   // whole wave
+    const unsigned long long m = __ballot(ov);
+    if (!m) return;
+    const uint32_t slot = count + wave_rank(m);
+    if (ov && slot < SEED_OVF_CAP) list[slot] = (uint32_t)pid;
+    count += (uint32_t)__popcll(m);
+}
+struct GlobalWindow {
+    u64 *col;   // &win[0][lane]
+    __device__ __forceinline__ void put(int step, u64 v) { col[(255 - step) * 40] = v; }
+    __device__ __forceinline__ u64 ld(int k) const { return __hip_atomic_load(col + k * 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+template <class Mem>
+__device__ __forceinline__ void seed_fixup_wave(const RenderParams &rp, int lens_shape, Mem m, uint32_t lane40, bool lane_on, const uint32_t *list, uint32_t count,
+                                                u64 *win, float *recs, Counters *cnt) {
+    if (count > SEED_OVF_CAP) {
+        if (lane40 == 0 && lane_on) atomicAdd(&cnt->rng_overflow, (unsigned long long)(count - SEED_OVF_CAP));
+        count = SEED_OVF_CAP;
+    }
+    const IsaacWarm warm = isaac_warm();
+    for (uint32_t base = 0; base < count; base += 40u) {
+        const bool valid = lane_on && base + lane40 < count;
+        const uint32_t pid = __hip_atomic_load(list + (valid ? base + lane40 : base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t item = pid >> 6, j = pid & 63u;
+        const uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        u64 s, t;
+        path_seed_words(rp.width, rp.height, px, py, sub, s, t);
+        if (lane_on) {
+            GlobalWindow w{win + lane40};
+            isaac_seed_round<ISAAC_TAIL>(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, w);
+            __builtin_amdgcn_s_waitcnt(0);   // the window stores have left the wave before it is read back (L1-bypassing loads)
+            if (valid) {
+                RecStore rs(recs, pid);
+                if (!record_from_window(w, ISAAC_TAIL, lens_shape, rs)) atomicAdd(&cnt->rng_overflow, 1ULL);
+            }
+        }
+    }
+}
 
 static const size_t SEED_LDS_BYTES = (size_t)256 * SEED_COLS * 8;  // 160 KiB: mem[256][80 columns] u64
 
 
-// tails layout: [item = tile * num_k + k][ISAAC_TAIL][64 lanes] u64;  lens layout: [item][64 lanes] u32.
+// recs layout: [item = tile * num_k + k][8 quads][64 lanes][4] f32 (flat path index pid = item * 64 + lane).
 // The LDS holds 80 generators, so a workgroup walks the flat path index (item * 64 + j) in strides of 80:
 // its two waves (40 active lanes each) run concurrently on two SIMDs — the time of one seeding pass does not
 // depend on the lane count (one wave issues at most one instruction every ~4-5 cycles), only on how many
 // generator states fit in the CU's LDS.
-__global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ tails,
-                                                                      uint32_t *__restrict__ lens, Counters *cnt) {
+__global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderParams rp, int lens_shape, float *__restrict__ recs,
+                                                                      uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64 *mem = reinterpret_cast<u64 *>(smem);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane >= (uint32_t)SEED_LANES) return;
-    const uint32_t col = wave * SEED_LANES + lane;
+    const bool lane_on = lane < (uint32_t)SEED_LANES;
+    const uint32_t col = wave * SEED_LANES + (lane_on ? lane : 0u);
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + wave) * SEED_OVF_CAP;
+    uint32_t ovf_count = 0;
     // latency-bound waves next to the trace kernel's waves: win issue arbitration (priority is a launch parameter)
     switch (rp.pad[0]) {
         case 0: break;
@@ -67,14 +127,15 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
         u64 s, t;
         path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
         LdsMem m{mem + col};
-        GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
-        RawLensTail<GlobalTail> lt(gt, lens_shape);
-        isaac_seed_round(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
-        lt.lens_slow();
-        bool ok = lt.in_window();
-        if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
-        if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+        RecStore rs(recs, pid);
+        RecordTail<RecStore> lt(rs, lens_shape);
+        if (lane_on) {
+            isaac_seed_round<REC_DRAWS>(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
+            lt.finish();
+        }
+        ovf_note(lane_on && valid && lt.overflow(), pid, ovf_list, ovf_count);
     }
+    seed_fixup_wave(rp, lens_shape, LdsMem{mem + col}, lane_on ? lane : 0u, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + wave) * SEED_WIN_WORDS, recs, cnt);
 }
 
 // ---- producer / consumer seeding (option seed_mode = 1, the default) -----------------------------------------------------------
@@ -110,7 +171,8 @@ template <int HEAD>
 struct RingState {
     u64 *pair;   // even lane: &row0[col]; odd lane: &row1[col - 1]
     bool on, odd;
-    __device__ __forceinline__ RingState(u64 *col, bool on_, uint32_t lane) : on(on_), odd(lane & 1u) { pair = odd ? col + SEED_LANES - 1 : col; }
+    uint32_t policy;   // cache policy of the ring stores: 0 plain, 1 sc1 (write-through, not kept in the XCD's L2), 2 nt, 3 sc0 sc1
+    __device__ __forceinline__ RingState(u64 *col, bool on_, uint32_t lane, uint32_t policy_) : on(on_), odd(lane & 1u), policy(policy_) { pair = odd ? col + SEED_LANES - 1 : col; }
     static __device__ __forceinline__ u64 swap_pair(u64 v) {   // value of lane ^ 1
         uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
         lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
@@ -123,7 +185,15 @@ struct RingState {
         u64x2 q;
         q.x = odd ? got : v0;
         q.y = odd ? v1 : got;
-        if (on) *reinterpret_cast<u64x2 *>(pair + row * SEED_LANES) = q;
+        if (on) {
+            u64x2 *dst = reinterpret_cast<u64x2 *>(pair + row * SEED_LANES);
+            switch (policy) {   // wave-uniform
+                case 1: asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(q) : "memory"); break;
+                case 2: asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(q) : "memory"); break;
+                case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(q) : "memory"); break;
+                default: *dst = q; break;
+            }
+        }
     }
     __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i, v0, v1); }
     __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) { row2(PcLayout<HEAD>::SHIP_ROWS + j, v0, v1); }
@@ -135,9 +205,12 @@ struct LdsHalfMem {
     __device__ __forceinline__ u64 ldo(uint32_t o) const { return lds_load64(o); }
     __device__ __forceinline__ void st(int i, u64 v) { col[i * SEED_LANES] = v; }
 };
-template <int SEED_SPLIT>   // = SPLIT: init blocks done by the producers
-__global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, u64 *__restrict__ tails,
-                                                      uint32_t *__restrict__ lens, Counters *cnt) {
+// PROF (option seed_prof): s_memtime stamps around the consumer's phases, summed per wave into Counters::seed_phase
+//   0 issue of the register loads + bookkeeping   1 wait for the 16 registers   2 isaac_init_back   3 barrier B (fill landed)
+//   4 isaac_round + record head   5 overflow note   6 barrier A (waiting for the producers / the other half)   7 groups
+template <int SEED_SPLIT, bool PROF = false>   // SPLIT: init blocks done by the producers
+__global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
+                                                      uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
     const bool consumer = wave < 2u;
@@ -159,76 +232,113 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     constexpr size_t SEED_HALF_WORDS = L::HALF_WORDS, SEED_GROUP_WORDS = L::GROUP_WORDS;
     constexpr int CHUNKS = SEED_SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
     uint64_t frontier = first_path & ~63ull;                   // first path not yet produced (chunk aligned)
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * SEED_OVF_CAP;   // consumer waves only
+    uint32_t ovf_count = 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
+#define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
     for (uint64_t it = 0; it <= G1 - G0; it++) {
-        // ---- producers: complete group G0 + it
+        // ---- group G0 + it - 1 (complete in the ring since the barrier that ended the last iteration) enters the LDS:
+        //      the PRODUCER wave of each half issues the fill (straight 1 KiB global_load_lds copies, no VGPR round trip; ~60
+        //      cycles of issue each, which the consumer's critical path does not pay) and waits for it to land; the CONSUMER
+        //      wave fetches the 16 registers and finishes init blocks >= SPLIT straight into LDS meanwhile (isaac_init_back,
+        //      no mix is computed twice).  Barrier B: the half is complete.
+        LdsHalfMem m{nullptr};
+        uint64_t pid = 0;
+        bool valid = false;
+        if (it > 0) {
+            if (PROF) tm = __builtin_readcyclecounter();
+            const uint64_t g = G0 + it - 1;
+            const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
+            unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+            if (!consumer) {
+                if (!(rp.pad[2] & 8u)) {
+                    // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
+                    // address pair serves two 1 KiB copies
+                    static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
+                    const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(src) + lane * 16u;
+                    unsigned char *ldst = lds_half;
+#pragma unroll 5
+                    for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
+                        const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
+                        void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
+                        switch (rp.ring_policy >> 2) {   // cache policy of the fill: 0 nt, 1 sc1, 2 sc1 nt, 3 default
+                            case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 16); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 16); break;
+                            case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 18); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 18); break;
+                            case 3: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
+                            default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2); break;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): landed
+                }
+            } else {
+                const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+                u64 st16[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
+                pid = g * SEED_COLS + half * SEED_LANES + colr;
+                const bool in_range = pid < paths;
+                const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
+                uint32_t tile = item / rp.num_k;
+                uint32_t px, py, sub;
+                tile_lane_pixel(rp, tile, j, px, py, sub);
+                valid = in_range && px < rp.width && py < rp.height;
+                m.col = reinterpret_cast<u64 *>(lds_half) + colr;
+                HR_STAMP(0);
+                if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
+                if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);
+                HR_STAMP(2);
+            }
+            __syncthreads();   // B
+            if (consumer) HR_STAMP(3);
+        }
+        // ---- producers: complete group G0 + it in the ring
         const uint64_t need = it < G1 - G0 ? (G0 + it + 1) * SEED_COLS : 0;      // paths below `need` must be in the ring
         uint32_t n = 0;
         while (frontier < need && frontier < end_path) {
             if (!consumer && (n & 1u) == half) {
                 const uint64_t pid0 = frontier + lane;
                 const bool on = pid0 >= first_path && pid0 < end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
-                const uint64_t pid = pid0 >= first_path && pid0 < end_path ? pid0 : end_path - 1;
-                const uint32_t item = (uint32_t)(pid >> 6), j = (uint32_t)(pid & 63u);
+                const uint64_t ppid = pid0 >= first_path && pid0 < end_path ? pid0 : end_path - 1;
+                const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
                 uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
                 uint32_t px, py, sub;
                 tile_lane_pixel(rp, tile, j, px, py, sub);
-                bool valid = px < rp.width && py < rp.height;
+                bool pvalid = px < rp.width && py < rp.height;
                 u64 s, t;
-                path_seed_words(rp.width, rp.height, valid ? px : 0u, valid ? py : 0u, sub, s, t);
-                const uint64_t g = pid / SEED_COLS;
-                const uint32_t c80 = (uint32_t)(pid - g * SEED_COLS);
+                path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
+                const uint64_t g = ppid / SEED_COLS;
+                const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS);
                 RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
-                              on, lane);
+                              on, lane, rp.ring_policy & 3u);
                 isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
             }
             frontier += 64;
             n++;
         }
-        // ---- consumers: group G0 + it - 1
+        // ---- consumers: the round of group G0 + it - 1
         if (consumer && it > 0) {
-            const uint64_t g = G0 + it - 1;
-            const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
-            unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
-            const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
-            u64 st16[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
-            if (!(rp.pad[2] & 8u)) {
-                const unsigned char *srcb = reinterpret_cast<const unsigned char *>(src);
-                // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
-                // address pair serves two 1 KiB copies
-                static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
-                const unsigned char *gsrc = srcb + lane * 16u;
-                unsigned char *ldst = lds_half;
-#pragma unroll 5
-                for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
-                    const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
-                    void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
-                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
-                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
-                }
-            }
-            const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
-            const bool in_range = pid < paths;
-            const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
-            uint32_t tile = item / rp.num_k;
-            uint32_t px, py, sub;
-            tile_lane_pixel(rp, tile, j, px, py, sub);
-            bool valid = in_range && px < rp.width && py < rp.height;
-            LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
-            if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);   // while the fill is in flight
-            __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's half has landed (no other wave touches it)
+            RecStore rs(recs, pid);
+            RecordTail<RecStore> lt(rs, lens_shape);
             if (lane < (uint32_t)SEED_LANES) {
-                GlobalTail gt{tails + (size_t)(pid >> 6) * ISAAC_TAIL * 64 + (pid & 63u)};
-                RawLensTail<GlobalTail> lt(gt, lens_shape);
-                isaac_round(m, lt);
-                lt.lens_slow();
-                bool ok = lt.in_window();
-                if (in_range) lens[(size_t)item * 64 + j] = ok ? (uint32_t)lt.accepted : 0u;
-                if (valid && !ok) atomicAdd(&cnt->rng_overflow, 1ULL);
+                isaac_round<REC_DRAWS>(m, lt);
+                lt.finish();
             }
+            HR_STAMP(4);
+            ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count);
+            HR_STAMP(5);
+            if (PROF) pc[7]++;
         }
-        __syncthreads();   // group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
+        __syncthreads();   // A: group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
+        if (consumer && it > 0) HR_STAMP(6);
+    }
+#undef HR_STAMP
+    if (PROF && consumer && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
+    if (consumer) {
+        const bool lane_on = lane < (uint32_t)SEED_LANES;
+        const uint32_t l40 = lane_on ? lane : 0u;
+        seed_fixup_wave(rp, lens_shape, LdsHalfMem{reinterpret_cast<u64 *>(smem + (size_t)half * SEED_LDS_HALF_BYTES) + l40}, l40, lane_on, ovf_list, ovf_count,
+                        win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
     }
 }
 
@@ -259,5 +369,5 @@ __global__ __launch_bounds__(64) void seed_debug_kernel(uint32_t W, uint32_t H, 
     LdsMem64 m{mem + lane};
     u64 dummy[ISAAC_TAIL];
     RawTail rt{valid ? out + (size_t)idx * window : dummy, window};
-    isaac_seed_round(m, warm, 8700304ULL, (u64)sampling, s, t, rt);
+    isaac_seed_round<ISAAC_TAIL>(m, warm, 8700304ULL, (u64)sampling, s, t, rt);
 }

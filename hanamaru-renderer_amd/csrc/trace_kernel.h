@@ -20,12 +20,10 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // No barriers, no LDS.
 static const int TRACE_WAVES = 4;
 static const uint32_t TRACE_KCHUNK = 4;   // samplings per work unit
-static const int NODE_UNROLL = 2;   // box tests per pass of the box-phase loop (amortises the ballot / branch overhead)
 
 template <bool CNT, int MINW>
-__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const u64 *__restrict__ tails,
-                                                                       const uint32_t *__restrict__ lens, float *__restrict__ accum,
-                                                                       Counters *cnt, uint32_t *tile_counter) {
+__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ recs,
+                                                                       float *__restrict__ accum, Counters *cnt, uint32_t *tile_counter) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     LaneCounters lc = {0, 0, 0, 0, 0};
@@ -36,7 +34,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
 #define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
     const uint32_t nchunks = (rp.num_k + TRACE_KCHUNK - 1u) / TRACE_KCHUNK, units = tiles * nchunks;
     uint32_t total = 0, cur_k0 = 0;          // wave-uniform: paths in the current unit (slot q = (k - cur_k0) * 64 + j), its first sampling
-    const size_t tile_stride = (size_t)rp.num_k * ISAAC_TAIL * 64;
+    const size_t tile_stride = (size_t)rp.num_k * REC_ITEM_FLOATS;   // floats of hand-off records per tile
     uint32_t cur_tile = 0, next = 0;          // wave-uniform: the tile of the unit being handed out and its queue head
     bool exhausted = false;
     Path p;
@@ -55,17 +53,19 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         }
         HR_PHASE_BEGIN();
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
-            if (path_advance<CNT>(sc, p, tails + (size_t)p.tile * tile_stride, &lc)) {
+            if (path_advance<CNT>(sc, p, recs + (size_t)p.tile * tile_stride, &lc)) {
                 // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
-                // path adds its radiance straight into the accumulator.  A tile belongs to exactly one wave of
-                // one launch, so only lanes of this wave ever touch these addresses: workgroup-scope atomics
-                // (executed in the XCD's L2) are sufficient.
+                // path adds its radiance straight into the accumulator.  A work unit is one tile x up to TRACE_KCHUNK
+                // samplings, so with more than TRACE_KCHUNK samplings per launch several waves — in other workgroups,
+                // on other XCDs — add to the same pixels concurrently: the adds are AGENT-scope atomics (device-wide
+                // at the memory side; the same global_atomic_add_f32 instruction on gfx950, so no cost).  Only the
+                // fp32 summation order per pixel varies between runs.
                 uint32_t pix = (p.q & 63u) >> 2;
                 uint32_t px = (p.tile % rp.tiles_x) * 4u + (pix & 3u), py = (p.tile / rp.tiles_x) * 4u + (pix >> 2);
                 float *dst = accum + ((size_t)py * rp.width + px) * 3;
-                __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(dst + 2, p.accum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dst + 2, p.accum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 p.q = PATH_IDLE;
             }
         }
@@ -94,9 +94,8 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                     if (px < rp.width && py < rp.height) {
                         p.q = (k << 6) | j;   // slot inside the tile's batch (bits 0-5: lane of the tile -> pixel, sub-sample)
                         p.tile = cur_tile;
-                        p.draw_base = (uint32_t)(k * ISAAC_TAIL * 64 + j);
-                        p.lens_a = lens[((size_t)cur_tile * rp.num_k + k) * 64 + j];
-                        path_start(sc, rp, p, px, py, sub, tails + (size_t)cur_tile * tile_stride);
+                        p.draw_base = k * REC_ITEM_FLOATS + j * 4u;
+                        path_start(sc, rp, p, px, py, sub, recs + (size_t)cur_tile * tile_stride);
                         npaths++;
                     }
                 }
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 if (CNT) { ph[2]++; ph[3] += n_go; }
                 if (go) {
                     trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                    if (NODE_UNROLL > 1 && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
                 }
             }
             HR_PHASE_END(2);

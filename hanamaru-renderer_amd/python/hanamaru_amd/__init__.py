@@ -78,7 +78,7 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("triangles", C.c_uint64), ("spheres", C.c_uint64), ("cuboids", C.c_uint64),
                 ("shade_calls", C.c_uint64), ("shade_lanes", C.c_uint64), ("box_passes", C.c_uint64), ("box_lanes", C.c_uint64),
                 ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
-                ("bvh_build_ms", C.c_double)]
+                ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}

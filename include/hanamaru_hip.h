@@ -121,6 +121,7 @@ typedef struct hr_stats {
     uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
     uint64_t phase_cycles[4];  /* counters build: wave-cycles in A shade, B refill, C box phase, C leaf phase */
     double bvh_build_ms;       /* device BVH build of the last hr_upload_scene (option bvh_builder = 1), else 0 */
+    uint64_t seed_phase_cycles[8]; /* option seed_prof: consumer-wave cycles per phase of the seed kernel, [7] = groups */
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;

@@ -31,28 +31,39 @@ struct ArrMem {
     void st(int i, u64 v) { m[i] = v; }
     void st2(int i, u64 v0, u64 v1) { m[i] = v0; m[i + 1] = v1; }
 };
-struct ArrStore { u64 t[ISAAC_TAIL]; u64 ld(int k) const { return t[k]; } void st(int k, u64 v) { t[k] = v; } };
+// one hand-off record (device_scene.h) and a window of raw outputs for the fix-up path
+struct ArrRec {   // lane 0 of a one-item block in the device layout [quad][64 lanes][4]
+    float f[REC_ITEM_FLOATS];
+    void st4(int slot, float a, float b, float c, float d) { float *q = f + rec_slot(0, (uint32_t)slot); q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+    float at(int slot) const { return f[rec_slot(0, (uint32_t)slot)]; }
+};
+struct ArrWindow { u64 t[ISAAC_TAIL]; void put(int step, u64 v) { t[255 - step] = v; } u64 ld(int k) const { return t[k]; } };
 
-// what the seed kernel produces for one path: raw tail + accepted lens attempt
-static bool path_tail(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, ArrStore &st, uint32_t &lens_a) {
+// what the seed kernel (+ the fix-up kernel for the paths it queues) produces for one path: the record
+static bool path_record(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, ArrRec &rec, bool *fixed = nullptr) {
     static const IsaacWarm warm = isaac_warm();
-    ArrMem mem;
-    RawLensTail<ArrStore> lt(st, lens_shape);
     u64 s, t;
     path_seed_words(W, H, px, py, sub, s, t);
-    isaac_seed_round(mem, warm, 8700304ULL, (u64)sampling, s, t, lt);
-    lt.lens_slow();
-    bool ok = lt.in_window();
-    lens_a = ok ? (uint32_t)lt.accepted : 0u;
-    return ok;
+    {
+        ArrMem mem;
+        RecordTail<ArrRec> lt(rec, lens_shape);
+        isaac_seed_round<REC_DRAWS>(mem, warm, 8700304ULL, (u64)sampling, s, t, lt);
+        lt.finish();
+        if (fixed) *fixed = lt.overflow();
+        if (!lt.overflow()) return true;
+    }
+    ArrMem mem;
+    ArrWindow win;
+    isaac_seed_round<ISAAC_TAIL>(mem, warm, 8700304ULL, (u64)sampling, s, t, win);
+    return record_from_window(win, ISAAC_TAIL, lens_shape, rec);
 }
 static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
-    ArrStore st;
-    uint32_t a;
-    bool ok = path_tail(W, H, px, py, sub, sampling, lens_shape, st, a);
-    out20[0] = draw_lens_f32(st.t[2 * a]);
-    out20[1] = draw_lens_f32(st.t[2 * a + 1]);
-    for (int d = 2; d < DRAWS_PER_PATH; d++) out20[d] = draw_f32(st.t[2 * a + d]);
+    ArrRec rec;
+    bool ok = path_record(W, H, px, py, sub, sampling, lens_shape, rec);
+    uint32_t a = float_as_uint(rec.at(REC_HEAD));
+    out20[0] = rec.at(REC_HEAD + 1);
+    out20[1] = rec.at(REC_HEAD + 2);
+    for (int d = 2; d < DRAWS_PER_PATH; d++) out20[d] = rec.at(2 * (int)a + d);
     return ok;
 }
 
@@ -74,7 +85,7 @@ static void raw_draws_pc(u64 s, u64 t, uint32_t sampling, int window, uint64_t *
     for (int i = 0; i < 256; i++) mem.st(i, sink.m[i]);
     isaac_init_back<HEAD>(mem, sink.end);
     RawTailPc rt{out, window};
-    isaac_round(mem, rt);
+    isaac_round<ISAAC_TAIL>(mem, rt);
 }
 
 extern "C" {
@@ -115,7 +126,7 @@ static void lbvh_build_host(HostScene &hs, int max_leaf) {
             cur = parent[cur];
         }
     }
-    hs.nodes.resize(8 * (size_t)N);
+    hs.nodes.resize(8 * (size_t)N + 1);
     for (int o = 0; o < 8; o++)
         for (int i = 0; i < N; i++) hs.nodes[(size_t)o * N + i] = emit_node(n, i, o, w);
     hs.num_nodes = (uint32_t)N;
@@ -173,7 +184,7 @@ int emu_raw_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub
     RawTail rt{out, window};
     u64 s, t;
     path_seed_words(W, H, px, py, sub, s, t);
-    isaac_seed_round(mem, warm, 8700304ULL, (u64)sampling, s, t, rt);
+    isaac_seed_round<ISAAC_TAIL>(mem, warm, 8700304ULL, (u64)sampling, s, t, rt);
     return 0;
 }
 
@@ -186,7 +197,7 @@ int emu_raw_draws_split(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     isaac_init_final(stage, warm, 8700304ULL, (u64)sampling, s, t);
     for (int i = 0; i < 256; i++) mem.st(i, stage.ld(i));
     RawTail rt{out, window};
-    isaac_round(mem, rt);
+    isaac_round<ISAAC_TAIL>(mem, rt);
     return 0;
 }
 
@@ -214,23 +225,21 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
     for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
         std::atomic<uint32_t> next{0};
         auto work = [&](int tid) {
-            std::vector<u64> draws((size_t)ISAAC_TAIL * 64);
             for (;;) {
                 uint32_t y = next.fetch_add(1);
                 if (y >= H) break;
                 for (uint32_t x = 0; x < W; x++) {
                     float sum[3] = {0, 0, 0};
                     for (uint32_t sub = 0; sub < 4; sub++) {
-                        ArrStore st;
+                        ArrRec rec;
                         Path p;
                         p.q = 0; p.draw_base = 0;
-                        path_tail(W, H, x, y, sub, sampling, sc.cam.lens_shape, st, p.lens_a);
-                        for (int d = 0; d < ISAAC_TAIL; d++) draws[(size_t)d * 64] = st.t[d];
-                        path_start(sc, rp, p, x, y, sub, draws.data());
+                        path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
+                        path_start(sc, rp, p, x, y, sub, rec.f);
                         LaneCounters lc = {0, 0, 0, 0, 0};
                         for (;;) {
                             while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
-                            if (path_advance<true>(sc, p, draws.data(), &lc)) break;
+                            if (path_advance<true>(sc, p, rec.f, &lc)) break;
                         }
                         sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
                         cn[tid][0]++; cn[tid][1] += lc.rays; cn[tid][2] += lc.node_tests; cn[tid][3] += lc.tri_tests;

@@ -89,6 +89,23 @@ def test_kernel_lens_rejection_matches_oracle(emu, orc):
         exp = np.asarray([2 * f[2 * j] - 1, 2 * f[2 * j + 1] - 1] + f[2 * j + 2:2 * j + 20], dtype=np.float64).astype(np.float32)
         assert np.array_equal(got, exp)
     assert deep >= 2                       # the sample exercised repeated rejections
+    # paths that reject the first LENS_FAST = 5 attempts leave the 28-draw hand-off record and go through the fix-up
+    # path (record_from_window, isaac_core.h): probability 4.6e-4 each, so search for some
+    fixed = 0
+    for i in range(30000):
+        w, h = 640, 360
+        x, y, sub, s = i % w, (i // w) % h, i % 4, 7 + i // (w * h)
+        f = [orc.u64_to_f64(v) for v in orc.path_draws(w, h, x, y, sub & 1, sub >> 1, s, 64)]
+        j = 0
+        while not ((2 * f[2 * j] - 1) ** 2 + (2 * f[2 * j + 1] - 1) ** 2 < 1.0):
+            j += 1
+        if j < 5:
+            continue
+        fixed += 1
+        got, ok = emu.path_draws(w, h, x, y, sub, s, 1)
+        exp = np.asarray([2 * f[2 * j] - 1, 2 * f[2 * j + 1] - 1] + f[2 * j + 2:2 * j + 20], dtype=np.float64).astype(np.float32)
+        assert ok and np.array_equal(got, exp)
+    assert fixed >= 3
     sq, ok = emu.path_draws(64, 64, 1, 2, 3, 4, 0)   # square lens: first pair always accepted
     f = [orc.u64_to_f64(v) for v in orc.path_draws(64, 64, 1, 2, 1, 1, 4, 4)]
     assert ok and sq[0] == np.float32(2 * f[0] - 1) and sq[2] == np.float32(f[2])
