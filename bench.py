@@ -28,6 +28,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0  # same guide: aggregate L2 bandwidth
+
+
+def usable_cpus():
+    """Host threads this process can really run at once: hardware threads, clipped by the scheduler affinity and by the cgroup CPU
+    quota (a container on a 256-thread host with cpu.max = 16 CPUs runs 256 threads no faster than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, (os.cpu_count() or 1), quota
+
+
+def latest_pmc_traffic():
+    """profiles/rNN_pmc_traffic.json of the newest round (written by tools/prof_pmc.sh), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+            if "kernels" in j:
+                return j
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def main():
@@ -92,6 +133,10 @@ def main():
         else:
             dist.all_reduce(t, op=op)
 
+    # The accumulators are summed by the LIBRARY (hr_allreduce_accumulator: ncclAllReduce on the device accumulator, RCCL loaded
+    # by libhanamaru_hip.so); torch.distributed only carries the ncclUniqueId to the ranks, the barriers and the max over ranks.
+    lib_rccl = dist is not None and not one_device
+
     W, H, SPS = args.width, args.height, args.spp_per_step
     scene = ha.Scene(args.scene)
     r = ha.Renderer(local_rank)
@@ -128,6 +173,12 @@ def main():
         r.set_option("init_prio", args.init_prio)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     r.bind_accumulator(acc.data_ptr())
+    if lib_rccl:
+        uid = [ha.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        r.comm_init_rank(uid[0], world, rank)
+        r.allreduce_accumulator()      # warm-up: the first collective sets up the rings
+        r.synchronize()
     paths_per_step_gpu = W * H * 4 * SPS
 
     def run_step(i):
@@ -163,8 +214,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(i)
+    if lib_rccl:
+        r.allreduce_accumulator()      # enqueued on the render stream behind the last step
     r.synchronize()
-    if dist is not None:
+    if dist is not None and not lib_rccl:
         all_reduce_(acc, dist.ReduceOp.SUM)
     barrier()
     t1 = time.perf_counter()
@@ -174,12 +227,13 @@ def main():
         all_reduce_(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = r.stats()
+    acc_mean = float(r.read_accumulator().mean()) if lib_rccl else float(acc.mean().item())   # after the all-reduce: the total
     # ---- the trace kernel with the chip to itself (seed kernel skipped: the hand-off buffers still hold the previous
     #      batches' draws, so the workload is the same) — outside the timed region, reported next to the concurrent figure
     alone_ms = None
     if rank == 0 and not args.debug_skip and not args.no_counters:
         if os.environ.get("HR_BENCH_CHECKSUM") == "1":
-            sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % float(acc.mean().item()))
+            sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % acc_mean)
         r.set_option("debug_skip", 2)
         r.render(*step_range(0, SPS, world, rank))
         r.synchronize()
@@ -188,7 +242,7 @@ def main():
         alone_ms = (st2["trace_kernel_ms"] - st["trace_kernel_ms"]) / max(1, st2["trace_launches"] - st["trace_launches"])
 
     if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0 and alone_ms is None:
-        sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % float(acc.mean().item()))
+        sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % acc_mean)
     if rank == 0:
         total_paths = paths_per_step_gpu * world * args.steps
         value = total_paths / elapsed / 1e6
@@ -200,7 +254,8 @@ def main():
             "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
             "config": {"workload": "%s %dx%d, %d samplings (x4 sub-samples) per step per GPU; K=64 steps = 1024 samplings" % (args.scene, W, H, SPS),
                        "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": paths_per_step_gpu * world,
-                       "parallelism": "spp-sharded x%d, one all-reduce" % world},
+                       "parallelism": "spp-sharded x%d, one all-reduce (%s)" % (world, "ncclAllReduce inside libhanamaru_hip.so" if lib_rccl else
+                                                                                  ("gloo on a host copy: HR_BENCH_ONE_DEVICE debugging aid" if dist is not None else "single rank"))},
             "rays_per_s_M": None,
         }
         launches = max(1, st["trace_launches"])
@@ -230,40 +285,66 @@ def main():
                 roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs_alone, 1), "frac_alone": round(gbs_alone / HBM_PEAK_GBS, 4),
                              "note": "achieved / frac: trace kernel running concurrently with the seed kernel of the next batch (the production schedule); "
                                      "*_alone: the same kernel on the same workload with the chip to itself"})
-        # HBM traffic is a PMC measurement (separate rocprofv3 --pmc pass, see profiles/); scaled per launch
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and (W, H, args.scene) == (1920, 1080, "rtcamp6_v3_1"):
-            tj = json.load(open(tfile))
-            roof["traffic"] = int(tj["hbm_bytes_per_path"] * paths_per_launch)
-            roof["traffic_source"] = tj["source"]
+        # L2: the BVH working set is L2-resident, so the same algorithmic bytes are also quoted against the aggregate L2 bandwidth
+        if roof.get("achieved"):
+            roof["l2"] = {"achieved": roof["achieved"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(roof["achieved"] / L2_PEAK_GBS, 4),
+                          "note": "algorithmic traversal bytes per second vs the aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s)"}
+        # HBM / fabric traffic and instruction counts are PMC measurements (separate rocprofv3 --pmc passes of this same command,
+        # tools/prof_pmc.sh, which also writes the JSON read here); per launch like `achieved`
+        pmc = latest_pmc_traffic()
+        if pmc and (W, H, args.scene) == (1920, 1080, "rtcamp6_v3_1"):
+            tk = pmc["kernels"].get("trace_kernel", {})
+            if "fetch_bytes_per_path" in tk:
+                roof["traffic"] = int(tk["fetch_bytes_per_path"] * paths_per_launch)
+                roof["traffic_source"] = pmc["source"]
+                roof["traffic_write"] = int(tk.get("write_bytes_per_path", 0) * paths_per_launch)
+            # issue: wave-level instructions per path of BOTH kernels vs what the chip can issue (one instruction per wave per
+            # ~4.5 cycles is the per-wave rate; the per-SIMD VALU rate is one wave64 instruction per 2 cycles)
+            per_path = {k: {f: v[f] for f in ("valu_per_path", "salu_per_path", "vmem_per_path", "lds_per_path") if f in v} for k, v in pmc["kernels"].items()}
+            valu = sum(v.get("valu_per_path", 0.0) for v in per_path.values())
+            if valu > 0:
+                chip_valu_per_s = 256 * 4 * 2.4e9 / 2.0     # 1024 SIMD-32 units, a wave64 VALU instruction every 2 cycles
+                roof["issue"] = {"wave_instructions_per_path": per_path, "valu_wave_instructions_per_path_both_kernels": round(valu, 1),
+                                 "valu_ceiling_Mpaths_per_s": round(chip_valu_per_s / valu / 1e6, 1), "frac": round(value * 1e6 * valu / chip_valu_per_s, 4),
+                                 "source": pmc["source"]}
         out["roofline"] = roof
-        # The other kernel of the pair: per-path ISAAC-64 seeding, bound by LDS capacity x generator latency, not by HBM or MFMA.
-        # Ceiling = 80 generator states per CU / (rest of the init 4.25 us + round 13.05 us, measured with nothing else on the
-        # chip by tools/roundprobe.hip) x 256 CUs.
+        # The other kernel of the pair: per-path ISAAC-64 seeding.  Bound neither by HBM nor by MFMA but by how fast ONE wave can
+        # issue: the LDS holds 80 generator states per CU (2 KiB each), two consumer waves of 40 lanes run their rounds, and a
+        # lone wave issues one instruction per ~4.5 cycles (LDS reads ~8, LDS writes ~16: tools/issueprobe.hip).  Ceiling =
+        # 80 states / (256 round steps x ~110 cycles + 16 init blocks x ~656 cycles at 2.4 GHz = 16.1 us) x 256 CUs.
         seed_ms = st["seed_kernel_ms"] / max(1, st["seed_launches"])
         if seed_ms > 0:
             seed_rate = paths_per_launch / (seed_ms * 1e-3) / 1e6
-            ceiling = 80.0 / 17.3e-6 * 256 / 1e6
-            out["seed_kernel"] = {"kernel": "seed_pc_kernel", "bound": "lds_capacity_x_latency", "avg_launch_ms": round(seed_ms, 4),
+            ceiling = 80.0 / 16.1e-6 * 256 / 1e6
+            out["seed_kernel"] = {"kernel": "seed_pc_kernel", "bound": "lds_capacity_x_single_wave_issue_rate", "avg_launch_ms": round(seed_ms, 4),
                                   "achieved": round(seed_rate, 1), "peak": round(ceiling, 1), "unit": "Mpaths/s", "frac": round(seed_rate / ceiling, 4)}
 
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py as orc
             o = orc.OracleScene(scene.desc_ptr)
-            cores = os.cpu_count() or 1
-            cw, ch, cs = 480, 270, 1
+            cores, hw_threads, quota = usable_cpus()
+            # one thread first (bounded: a 240x135 image), then every host core at BASELINE's 1920x1080: a
+            # 480x270 probe sizes the sample to roughly 12 s of CPU work (at least one full 1080p sampling)
             tc0 = time.perf_counter()
-            o.render(cw, ch, 1, 2, threads=cores)
-            probe = time.perf_counter() - tc0
-            # scale the sample to roughly 10-20 s of CPU work
-            mult = int(max(1, min(64, 12.0 / max(probe, 1e-3))))
+            o.render(240, 135, 1, 2, threads=1)
+            one_rate = 240 * 135 * 4 / (time.perf_counter() - tc0) / 1e6
+            tc0 = time.perf_counter()
+            o.render(480, 270, 1, 2, threads=cores)
+            probe_rate = 480 * 270 * 4 / max(time.perf_counter() - tc0, 1e-4) / 1e6
+            cw, ch = 1920, 1080
+            mult = int(max(1, min(64, 12.0 * probe_rate * 1e6 / (cw * ch * 4))))
             tc0 = time.perf_counter()
             o.render(cw, ch, 2, 2 + mult, threads=cores)
             dt = time.perf_counter() - tc0
-            out["cpu_baseline"] = {"value": round(cw * ch * 4 * mult / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
-                                   "sample": "%s %dx%d x %d samplings (%d paths), all host cores, f64 oracle with reference-order BVH" %
-                                             (args.scene, cw, ch, mult, cw * ch * 4 * mult)}
+            rate = cw * ch * 4 * mult / dt / 1e6
+            out["cpu_baseline"] = {"value": round(rate, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+                                   "one_thread_value": round(one_rate, 4), "parallel_efficiency": round(rate / (one_rate * cores), 3),
+                                   "host_hardware_threads": hw_threads, "cgroup_cpu_quota": quota,
+                                   "sample": "%s %dx%d x %d samplings (%d paths) on %d threads = every CPU this container may use (%d hardware threads, cgroup quota %s; "
+                                             "persistent pool, 16-pixel chunks, one barrier per sampling like renderer.rs:32-43); f64 oracle with the reference-order "
+                                             "BVHs; one thread: 240x135 x 1 sampling" %
+                                             (args.scene, cw, ch, mult, cw * ch * 4 * mult, cores, hw_threads, ("%.0f CPUs" % quota) if quota else "none")}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

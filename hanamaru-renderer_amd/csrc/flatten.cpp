@@ -100,10 +100,11 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     std::vector<f4> cuboids;
     std::vector<BuildPrim> prims;        // one reference per primitive
     std::vector<BuildPrim> prims_split;  // triangles cut by early split clipping (when enabled), other primitives as they are
-    // split_ratio < 0: build both trees and keep the split one only when it cuts the SAH cost by more than 30 % (measured: below
-    // that the 8 octant copies of the bigger tree cost more than the tighter boxes save)
+    // split_ratio < 0: build both trees and keep the split one only when it cuts the SAH cost by more than 7 % (the 8 octant
+    // copies of the bigger tree have to pay for themselves: rtcamp6_v3_1 -10 % SAH, +28 % nodes, measured +2.6 % Mpaths/s;
+    // rtcamp5 -2.5 % SAH for 2.5x the nodes: left alone)
     const bool auto_split = split_ratio < 0.0;
-    const double ratio = auto_split ? 1.5 : split_ratio;
+    const double ratio = auto_split ? 2.0 : split_ratio;
     out.materials.assign(sd->num_elements, Material{});
     out.emitters.clear();
     auto f3 = [](float *dst, const hr_vec3 &v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; };
@@ -206,7 +207,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
             if (split_ok && auto_split && prims_split.size() > prims.size()) {
                 BuiltBvh cut;
                 build_bvh(prims_split, max_leaf, cut);
-                if (cut.sah_cost < 0.7 * bvh.sah_cost) bvh = std::move(cut);
+                if (cut.sah_cost < 0.93 * bvh.sah_cost) bvh = std::move(cut);
             }
         }
     } else {

@@ -21,6 +21,7 @@
 #include "flatten.h"
 #include "gpu_bvh.h"
 #include "hanamaru_hip.h"
+#include "hr_comm.h"
 #include "isaac_core.h"
 #include "post_core.h"
 #include "pt_core.h"
@@ -68,6 +69,12 @@ struct hr_ctx {
     float *accum_own = nullptr, *accum = nullptr;
     float *post_tmp = nullptr;
     uint8_t *d_rgb8 = nullptr;
+    // multi-GPU: RCCL communicator of this rank, and the all-reduced accumulator (valid until the next render / clear / write)
+    hrcomm::Comm comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    std::vector<hr_ctx *> same_device_peers;   // hr_comm_init_local over contexts that share ONE device: summed by a kernel, not by RCCL
+    float *accum_total = nullptr;
+    bool total_valid = false;
     // seed -> trace hand-off, double buffered (slot = batch & 1)
     float *recs[2] = {nullptr, nullptr};     // 128-byte record per path (device_scene.h)
     uint32_t *ovf = nullptr;                 // per consumer wave: list of the paths it re-derives at the end of a launch (seed_fixup_wave)
@@ -225,6 +232,9 @@ int hr_destroy(hr_ctx *c) {
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->post_tmp) (void)hipFree(c->post_tmp);
     if (c->d_rgb8) (void)hipFree(c->d_rgb8);
+    if (c->accum_total) (void)hipFree(c->accum_total);
+    if (c->comm && hrcomm::api().CommDestroy) (void)hrcomm::api().CommDestroy(c->comm);
+    for (hr_ctx *p : c->same_device_peers) if (p != c) { p->same_device_peers.clear(); p->comm_world = 0; p->total_valid = false; }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->seed_stream) (void)hipStreamDestroy(c->seed_stream);
     delete c;
@@ -344,31 +354,38 @@ int hr_set_resolution(hr_ctx *c, uint32_t w, uint32_t h) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
-    bool external = c->accum && c->accum != c->accum_own;
+    // no target while the buffers are being replaced (a failed allocation leaves the context without one, not with dangling
+    // pointers); a caller-bound accumulator was sized for the old resolution: it is unbound, the caller rebinds
+    c->accum = nullptr; c->W = c->H = 0; c->total_valid = false;
     if (c->accum_own) { HIP_TRY(hipFree(c->accum_own)); c->accum_own = nullptr; }
     if (c->post_tmp) { HIP_TRY(hipFree(c->post_tmp)); c->post_tmp = nullptr; }
     if (c->d_rgb8) { HIP_TRY(hipFree(c->d_rgb8)); c->d_rgb8 = nullptr; }
-    c->W = w; c->H = h;
+    if (c->accum_total) { HIP_TRY(hipFree(c->accum_total)); c->accum_total = nullptr; }
     size_t n = (size_t)w * h * 3;
     HIP_TRY(hipMalloc((void **)&c->accum_own, n * sizeof(float)));
     HIP_TRY(hipMemset(c->accum_own, 0, n * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&c->post_tmp, n * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&c->d_rgb8, n));
-    if (!external) c->accum = c->accum_own;
+    c->W = w; c->H = h;
+    c->accum = c->accum_own;
     return HR_OK;
 }
 
 int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
     if (!c) return fail(HR_ERR_INVALID, "hr_bind_accumulator: null ctx");
+    if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_bind_accumulator: hr_set_resolution not called");
+    HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
     c->accum = device_rgb ? device_rgb : c->accum_own;
+    c->total_valid = false;
     return HR_OK;
 }
 void *hr_accumulator_device_ptr(hr_ctx *c) { return c ? c->accum : nullptr; }
 
 int hr_set_stream(hr_ctx *c, void *s) {
     if (!c) return fail(HR_ERR_INVALID, "hr_set_stream: null ctx");
+    HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
     c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -381,6 +398,7 @@ int hr_clear(hr_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
+    c->total_valid = false;
     HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -441,6 +459,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_render: hr_set_resolution not called");
     if (s_end <= s_begin) return HR_OK;
     HIP_TRY(hipSetDevice(c->device));
+    c->total_valid = false;
     uint32_t total_k = (s_end - s_begin + stride - 1) / stride;
     RenderParams rp{};
     rp.width = c->W; rp.height = c->H;
@@ -518,6 +537,7 @@ int hr_render_debug(hr_ctx *c, int mode) {
     if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_render_debug: no scene uploaded");
     if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_render_debug: hr_set_resolution not called");
     HIP_TRY(hipSetDevice(c->device));
+    c->total_valid = false;
     RenderParams rp{};
     rp.width = c->W; rp.height = c->H;
     hipLaunchKernelGGL(debug_render_kernel, dim3((c->W + 15) / 16, (c->H + 15) / 16), dim3(16, 16), 0, c->stream, c->dsc, rp, mode, c->accum);
@@ -565,14 +585,16 @@ int hr_read_accumulator(hr_ctx *c, float *host) {
     if (!c->accum) return fail(HR_ERR_NO_TARGET, "hr_read_accumulator: no accumulator");
     int rc = hr_synchronize(c);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(host, c->accum, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host, c->total_valid ? c->accum_total : c->accum, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return HR_OK;
 }
 int hr_write_accumulator(hr_ctx *c, const float *host) {
     if (!c || !host) return fail(HR_ERR_INVALID, "hr_write_accumulator: null argument");
     if (!c->accum) return fail(HR_ERR_NO_TARGET, "hr_write_accumulator: no accumulator");
+    HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
+    c->total_valid = false;
     HIP_TRY(hipMemcpy(c->accum, host, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyHostToDevice));
     return HR_OK;
 }
@@ -588,7 +610,7 @@ int hr_resolve(hr_ctx *c, uint32_t samplings, uint8_t *host_rgb8) {
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, c->stream));
-    hipLaunchKernelGGL(tonemap_gamma_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->post_tmp, n, scale);
+    hipLaunchKernelGGL(tonemap_gamma_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->total_valid ? c->accum_total : c->accum, c->post_tmp, n, scale);
     hipLaunchKernelGGL(bilateral_quantise_kernel, dim3((c->W + 31) / 32, (c->H + 7) / 8), dim3(32, 8), 0, c->stream, c->post_tmp, c->d_rgb8, c->W, c->H);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, c->stream));
@@ -598,8 +620,129 @@ int hr_resolve(hr_ctx *c, uint32_t samplings, uint8_t *host_rgb8) {
     return drain_events(c);
 }
 
+// ---- multi-GPU: one all-reduce of the accumulators over RCCL (hr_comm.h) ------------------------------------------------------
+#define NCCL_TRY(expr)                                                                                                    \
+    do {                                                                                                                  \
+        int r_ = (expr);                                                                                                  \
+        if (r_ != 0) return fail(HR_ERR_DEVICE, "%s failed: %s", #expr, hrcomm::api().GetErrorString ? hrcomm::api().GetErrorString(r_) : "?"); \
+    } while (0)
+
+int hr_comm_get_unique_id(void *id_out) {
+    if (!id_out) return fail(HR_ERR_INVALID, "hr_comm_get_unique_id: null argument");
+    if (!hrcomm::load()) return fail(HR_ERR_UNSUPPORTED, "%s", hrcomm::api().error.c_str());
+    hrcomm::UniqueId id;
+    NCCL_TRY(hrcomm::api().GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return HR_OK;
+}
+__global__ void add_accumulator_kernel(float *__restrict__ total, const float *__restrict__ part, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) total[i] += part[i];
+}
+static int comm_release(hr_ctx *c) {
+    if (c->comm) { NCCL_TRY(hrcomm::api().CommDestroy(c->comm)); c->comm = nullptr; }
+    for (hr_ctx *p : c->same_device_peers) if (p != c) { p->same_device_peers.clear(); p->comm_world = 0; p->total_valid = false; }
+    c->same_device_peers.clear();
+    c->comm_world = 0; c->comm_rank = 0; c->total_valid = false;
+    return HR_OK;
+}
+int hr_comm_init_rank(hr_ctx *c, const void *id, int world_size, int rank) {
+    if (!c || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(HR_ERR_INVALID, "hr_comm_init_rank: bad argument");
+    if (!hrcomm::load()) return fail(HR_ERR_UNSUPPORTED, "%s", hrcomm::api().error.c_str());
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = comm_release(c);
+    if (rc) return rc;
+    hrcomm::UniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCL_TRY(hrcomm::api().CommInitRank(&c->comm, world_size, uid, rank));
+    c->comm_world = world_size; c->comm_rank = rank;
+    return HR_OK;
+}
+int hr_comm_init_local(hr_ctx **ctxs, int n) {
+    if (!ctxs || n < 1) return fail(HR_ERR_INVALID, "hr_comm_init_local: bad argument");
+    for (int i = 0; i < n; i++) if (!ctxs[i]) return fail(HR_ERR_INVALID, "hr_comm_init_local: null context");
+    {
+        // all contexts on ONE device (RCCL wants one rank per device): the "collective" is a sum kernel on that device
+        bool same = n > 1;
+        for (int i = 1; i < n; i++) same = same && ctxs[i]->device == ctxs[0]->device;
+        if (same) {
+            for (int i = 0; i < n; i++) { int rc = comm_release(ctxs[i]); if (rc) return rc; }
+            for (int i = 0; i < n; i++) { ctxs[i]->same_device_peers.assign(ctxs, ctxs + n); ctxs[i]->comm_world = n; ctxs[i]->comm_rank = i; }
+            return HR_OK;
+        }
+    }
+    if (!hrcomm::load()) return fail(HR_ERR_UNSUPPORTED, "%s", hrcomm::api().error.c_str());
+    std::vector<int> devs(n);
+    std::vector<hrcomm::Comm> comms(n, nullptr);
+    for (int i = 0; i < n; i++) {
+        int rc = comm_release(ctxs[i]);
+        if (rc) return rc;
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return fail(HR_ERR_INVALID, "hr_comm_init_local: device %d appears twice (RCCL needs one rank per device)", devs[i]);
+    }
+    NCCL_TRY(hrcomm::api().CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_world = n; ctxs[i]->comm_rank = i; }
+    return HR_OK;
+}
+int hr_comm_destroy(hr_ctx *c) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_comm_destroy: null ctx");
+    if (!c->comm && c->same_device_peers.empty()) return HR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    return comm_release(c);
+}
+// enqueue this rank's part of the collective behind its render work (caller: inside a group when it drives several ranks)
+static int allreduce_enqueue(hr_ctx *c) {
+    if (!c->comm && c->same_device_peers.empty()) return fail(HR_ERR_INVALID, "hr_allreduce_accumulator: no communicator (hr_comm_init_rank / hr_comm_init_local)");
+    if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_allreduce_accumulator: no accumulator");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H * 3;
+    if (!c->accum_total) HIP_TRY(hipMalloc((void **)&c->accum_total, n * sizeof(float)));
+    if (!c->same_device_peers.empty()) {
+        for (hr_ctx *p : c->same_device_peers) {
+            if (p->W != c->W || p->H != c->H || !p->accum) return fail(HR_ERR_INVALID, "hr_allreduce_accumulator: the contexts of the group differ in resolution");
+            if (p != c) { int rc = sync_all(p); if (rc) return rc; }   // the peers' render work (their own streams)
+        }
+        // rank order, so that every context of the group gets bit-identical totals (as an all-reduce delivers them)
+        int rc = sync_all(c);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->accum_total, c->same_device_peers[0]->accum, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        for (size_t k = 1; k < c->same_device_peers.size(); k++)
+            hipLaunchKernelGGL(add_accumulator_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->accum_total, c->same_device_peers[k]->accum, n);
+        HIP_TRY(hipGetLastError());
+        c->total_valid = true;
+        return HR_OK;
+    }
+    NCCL_TRY(hrcomm::api().AllReduce(c->accum, c->accum_total, n, hrcomm::kFloat, hrcomm::kSum, c->comm, c->stream));
+    c->total_valid = true;
+    return HR_OK;
+}
+int hr_allreduce_accumulator(hr_ctx *c) {
+    if (!c) return fail(HR_ERR_INVALID, "hr_allreduce_accumulator: null ctx");
+    return allreduce_enqueue(c);
+}
+int hr_allreduce_accumulators(hr_ctx **ctxs, int n) {
+    if (!ctxs || n < 1) return fail(HR_ERR_INVALID, "hr_allreduce_accumulators: bad argument");
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i] || (!ctxs[i]->comm && ctxs[i]->same_device_peers.empty())) return fail(HR_ERR_INVALID, "hr_allreduce_accumulators: context %d has no communicator", i);
+    if (!ctxs[0]->same_device_peers.empty()) {
+        for (int i = 0; i < n; i++) { int rc = allreduce_enqueue(ctxs[i]); if (rc) return rc; }
+        return HR_OK;
+    }
+    NCCL_TRY(hrcomm::api().GroupStart());
+    int rc = HR_OK;
+    for (int i = 0; i < n && rc == HR_OK; i++) rc = allreduce_enqueue(ctxs[i]);
+    int r_ = hrcomm::api().GroupEnd();
+    if (rc) return rc;
+    if (r_ != 0) return fail(HR_ERR_DEVICE, "ncclGroupEnd failed: %s", hrcomm::api().GetErrorString(r_));
+    return HR_OK;
+}
+void *hr_total_device_ptr(hr_ctx *c) { return c && c->total_valid ? c->accum_total : nullptr; }
+
 int hr_get_stats(hr_ctx *c, hr_stats *out) {
     if (!c || !out) return fail(HR_ERR_INVALID, "hr_get_stats: null argument");
+    HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
     Counters h;
@@ -621,6 +764,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
 
 int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (!c || !key) return fail(HR_ERR_INVALID, "hr_set_option: null argument");
+    HIP_TRY(hipSetDevice(c->device));
     std::string k = key;
     if (k == "counters") { c->counters = value != 0.0; return HR_OK; }
     if (k == "batch") {

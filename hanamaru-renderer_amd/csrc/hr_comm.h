@@ -1,0 +1,61 @@
+// Multi-GPU exchange of the render path: the samplings of renderer.rs:32-43 are sharded by index over the
+// ranks, every rank accumulates its share, and ONE all-reduce (sum) of the fp32 accumulators over RCCL precedes the resolve
+// of renderer.rs:64-90.  RCCL (librccl.so, the ROCm build of the NCCL API) is loaded on first use: a single-GPU host never
+// pays for it, and a box without it gets HR_ERR_UNSUPPORTED with the loader's message — there is no host-side fallback sum.
+// Included by hr_api.hip only.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+namespace hrcomm {
+
+typedef struct { char internal[128]; } UniqueId;   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef void *Comm;                                // ncclComm_t
+enum { kFloat = 7, kSum = 0 };                     // ncclFloat32, ncclSum
+
+struct Api {
+    void *lib = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    int (*CommInitAll)(Comm *, int, const int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+
+inline Api &api() {
+    static Api a;
+    return a;
+}
+// false (and api().error set) when RCCL cannot be loaded
+inline bool load() {
+    Api &a = api();
+    if (a.lib) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (a.lib) break;
+    }
+    if (!a.lib) { a.error = std::string("cannot load RCCL: ") + dlerror(); return false; }
+    bool ok = true;
+    auto sym = [&](const char *name) -> void * {
+        void *p = dlsym(a.lib, name);
+        if (!p) { ok = false; a.error = std::string("RCCL symbol missing: ") + name; }
+        return p;
+    };
+    a.GetUniqueId = (int (*)(UniqueId *))sym("ncclGetUniqueId");
+    a.CommInitRank = (int (*)(Comm *, int, UniqueId, int))sym("ncclCommInitRank");
+    a.CommInitAll = (int (*)(Comm *, int, const int *))sym("ncclCommInitAll");
+    a.AllReduce = (int (*)(const void *, void *, size_t, int, int, Comm, hipStream_t))sym("ncclAllReduce");
+    a.GroupStart = (int (*)())sym("ncclGroupStart");
+    a.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    a.CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
+    a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    if (!ok) { dlclose(a.lib); a.lib = nullptr; }
+    return ok;
+}
+
+}  // namespace hrcomm

@@ -149,9 +149,10 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
 // The ring traffic is what this costs (it slows the trace kernel next door), so the producers stop after SPLIT of the 32
 // init blocks and ship those plus the 16 registers the sweep continues from; the consumer does blocks >= SPLIT itself
 // while its fill is in flight (isaac_init_front / isaac_init_back) — no mix is computed twice.
-// Group buffer, per half: [row = 0 .. RING_ROWS)[40 columns] u64; rows 0 .. 8*SPLIT are the LDS image of generator words
-// 0 .. 8*SPLIT - 1, the last 16 rows hold the registers.  One __syncthreads per group: in
-// iteration `it` the consumers work on group it-1 while the producers complete group `it` (5 chunks per 4 groups).
+// Group buffer, per half: [row = 0 .. 8*SPLIT)[40 columns] u64 = the LDS image of generator words 0 .. 8*SPLIT - 1, then the
+// registers as [8 pairs][40 columns][2] u64 (16 bytes per lane, contiguous across the lanes: eight coalesced 16-byte loads for the consumer).  Two barriers per
+// group: in iteration `it` the consumers work on group it-1 while the producers complete group it+1 (5 chunks per 4 groups) —
+// one group of slack, so that the consumer can fetch the registers of group `it` while it runs the round of group it-1.
 template <int SPLIT>   // init blocks (of 8 words) done by the producer; even
 struct PcLayout {
     static const int SHIP_ROWS = 8 * SPLIT;
@@ -172,7 +173,11 @@ struct RingState {
     u64 *pair;   // even lane: &row0[col]; odd lane: &row1[col - 1]
     bool on, odd;
     uint32_t policy;   // cache policy of the ring stores: 0 plain, 1 sc1 (write-through, not kept in the XCD's L2), 2 nt, 3 sc0 sc1
-    __device__ __forceinline__ RingState(u64 *col, bool on_, uint32_t lane, uint32_t policy_) : on(on_), odd(lane & 1u), policy(policy_) { pair = odd ? col + SEED_LANES - 1 : col; }
+    __device__ __forceinline__ RingState(u64 *half_base, uint32_t column, bool on_, uint32_t lane, uint32_t policy_) : on(on_), odd(lane & 1u), policy(policy_) {
+        u64 *col = half_base + column;
+        pair = odd ? col + SEED_LANES - 1 : col;
+        regs = half_base + (size_t)PcLayout<HEAD>::SHIP_ROWS * SEED_LANES + (size_t)column * 2u;
+    }
     static __device__ __forceinline__ u64 swap_pair(u64 v) {   // value of lane ^ 1
         uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
         lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
@@ -196,7 +201,14 @@ struct RingState {
         }
     }
     __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i, v0, v1); }
-    __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) { row2(PcLayout<HEAD>::SHIP_ROWS + j, v0, v1); }
+    // registers j, j + 1 (j even) of this lane's column: [j / 2][column][2] behind the shipped rows, no lane swap needed
+    __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 q;
+        q.x = v0; q.y = v1;
+        if (on) *reinterpret_cast<u64x2 *>(regs + (j >> 1) * (2 * SEED_LANES)) = q;
+    }
+    u64 *regs;   // &half[SHIP_ROWS * 40 + column * 2]
 };
 struct LdsHalfMem {
     u64 *col;
@@ -236,6 +248,14 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     uint32_t ovf_count = 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
 #define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
+    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t st16v[8];   // consumer: the 16 registers of the group whose init_back comes next (fetched one round ahead)
+    auto load_regs = [&](uint64_t g) {
+        const u64 *regs = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS + (size_t)SEED_SHIP_ROWS * SEED_LANES +
+                          (size_t)(lane < (uint32_t)SEED_LANES ? lane : 0u) * 2u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) st16v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
+    };
     for (uint64_t it = 0; it <= G1 - G0; it++) {
         // ---- group G0 + it - 1 (complete in the ring since the barrier that ended the last iteration) enters the LDS:
         //      the PRODUCER wave of each half issues the fill (straight 1 KiB global_load_lds copies, no VGPR round trip; ~60
@@ -272,9 +292,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
                 }
             } else {
                 const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
-                u64 st16[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) st16[q] = __builtin_nontemporal_load(src + (size_t)(SEED_SHIP_ROWS + q) * SEED_LANES + colr);
+                if (it == 1) load_regs(g);   // later groups: fetched during the previous round
                 pid = g * SEED_COLS + half * SEED_LANES + colr;
                 const bool in_range = pid < paths;
                 const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
@@ -285,14 +303,20 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
                 m.col = reinterpret_cast<u64 *>(lds_half) + colr;
                 HR_STAMP(0);
                 if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
+                u64 st16[16];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { st16[2 * q] = st16v[q].x; st16[2 * q + 1] = st16v[q].y; }
                 if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);
                 HR_STAMP(2);
             }
             __syncthreads();   // B
-            if (consumer) HR_STAMP(3);
+            if (consumer) {
+                HR_STAMP(3);
+                if (it < G1 - G0) load_regs(G0 + it);   // group G0 + it has been complete since barrier A; used after this round
+            }
         }
-        // ---- producers: complete group G0 + it in the ring
-        const uint64_t need = it < G1 - G0 ? (G0 + it + 1) * SEED_COLS : 0;      // paths below `need` must be in the ring
+        // ---- producers: complete group G0 + it + 1 in the ring (one group of slack: see load_regs above)
+        const uint64_t need = (G0 + it + 2) * SEED_COLS;      // paths below `need` (clipped to this workgroup's range) must be in the ring
         uint32_t n = 0;
         while (frontier < need && frontier < end_path) {
             if (!consumer && (n & 1u) == half) {
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
                 path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
                 const uint64_t g = ppid / SEED_COLS;
                 const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS);
-                RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0) + (c80 % SEED_LANES),
+                RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0), c80 % SEED_LANES,
                               on, lane, rp.ring_policy & 3u);
                 isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
             }

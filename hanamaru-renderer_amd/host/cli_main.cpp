@@ -50,7 +50,7 @@ static void usage(const char *prog) {
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
            "        --batch N       samplings per progress report (default 32; the library launches 4 at a time)\n"
            "        --gpus N        render on devices 0..N-1 of this node from this one process: device r takes every N-th sampling,\n"
-           "                        the accumulators are summed on the host when an image is written (default 1)\n"
+           "                        the accumulators are summed with one RCCL all-reduce when an image is written (default 1)\n"
            "        --gpu-ids LIST  the same with an explicit comma-separated device list\n"
            "        --checkpoint F  write accumulator + sampling count to F when the render stops\n"
            "        --resume F      continue from a checkpoint file\n",
@@ -86,6 +86,9 @@ int main(int argc, char **argv) {
         else if (a == "--resume") ckpt_in = val("resume");
         else { fprintf(stderr, "Unrecognized option: '%s'.\n", a.c_str()); return 1; }
     }
+    if (batch < 1) { fprintf(stderr, "--batch must be at least 1.\n"); return 1; }
+    if (width == 0 || height == 0) { fprintf(stderr, "width and height must be positive.\n"); return 1; }
+    if (gpus < 1) { fprintf(stderr, "--gpus must be at least 1.\n"); return 1; }
     if (assets.empty()) {
         FILE *probe = fopen("assets/models/box.obj", "rb");
         if (probe) { fclose(probe); assets = "assets"; } else assets = ".";
@@ -124,21 +127,11 @@ int main(int argc, char **argv) {
     hr_ctx *ctx = ctxs[0];
     if (ndev > 1) tee("devices: %u.", ndev);
     tee("init scene: %.2f sec.", now_sec() - init_begin);
-    // sum of all devices' accumulators -> device 0 (for hr_resolve / checkpoints); `own0` keeps device 0's own part
-    std::vector<float> own0, part;
-    auto combine = [&]() -> int {
-        if (ndev == 1) return 0;
-        own0.resize((size_t)width * height * 3);
-        part.resize(own0.size());
-        if (hr_read_accumulator(ctxs[0], own0.data()) != 0) return 1;
-        std::vector<float> total = own0;
-        for (uint32_t r = 1; r < ndev; r++) {
-            if (hr_read_accumulator(ctxs[r], part.data()) != 0) return 1;
-            for (size_t i = 0; i < total.size(); i++) total[i] += part[i];
-        }
-        return hr_write_accumulator(ctxs[0], total.data()) != 0;
-    };
-    auto uncombine = [&]() -> int { return ndev == 1 ? 0 : (hr_write_accumulator(ctxs[0], own0.data()) != 0); };
+    // The image needs the sum of all devices' accumulators: ONE all-reduce over RCCL (hr_allreduce_accumulators — the sum lands
+    // in a separate buffer per device, so every device keeps accumulating its own samplings afterwards); hr_resolve /
+    // hr_read_accumulator on device 0 then see the total (renderer.rs:64-90 runs after the sum).
+    if (ndev > 1) CHECK_HR(hr_comm_init_local(ctxs.data(), (int)ndev));
+    auto combine = [&]() -> int { return ndev == 1 ? 0 : (hr_allreduce_accumulators(ctxs.data(), (int)ndev) != 0); };
 
     // Renderer::render + report_progress (renderer.rs:25-46, 205-251) at batch granularity
     std::vector<uint8_t> rgb((size_t)width * height * 3);
@@ -148,19 +141,23 @@ int main(int argc, char **argv) {
         char path[32];
         snprintf(path, sizeof path, "%03u.png", counter);
         double t0 = now_sec();
-        if (combine() || hr_resolve(ctx, s, rgb.data()) != 0 || uncombine()) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
+        if (combine() || hr_resolve(ctx, s, rgb.data()) != 0) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
         printf("update_imgbuf: %.3f sec\n", now_sec() - t0);
         return hh_write_png_rgb8(path, rgb.data(), width, height);
     };
     uint32_t first = 1;
+    // checkpoint = {magic, width, height, samplings done, FNV-1a of the scene name} + the fp32 accumulator
+    const uint32_t CKPT_MAGIC = 0x32415248u;   // "HRA2"
+    uint32_t scene_hash = 2166136261u;
+    for (char ch : scene_name) scene_hash = (scene_hash ^ (uint8_t)ch) * 16777619u;
     if (!ckpt_in.empty()) {
         FILE *f = fopen(ckpt_in.c_str(), "rb");
-        uint32_t hdr[4] = {0, 0, 0, 0};
+        uint32_t hdr[5] = {0, 0, 0, 0, 0};
         std::vector<float> acc((size_t)width * height * 3);
-        bool ok = f && fread(hdr, 4, 4, f) == 4 && hdr[0] == 0x43415248u /* "HRAC" */ && hdr[1] == width && hdr[2] == height &&
+        bool ok = f && fread(hdr, 4, 5, f) == 5 && hdr[0] == CKPT_MAGIC && hdr[1] == width && hdr[2] == height && hdr[4] == scene_hash &&
                   fread(acc.data(), sizeof(float), acc.size(), f) == acc.size();
         if (f) fclose(f);
-        if (!ok) { fprintf(stderr, "cannot resume from %s (missing, wrong magic or resolution)\n", ckpt_in.c_str()); return 1; }
+        if (!ok) { fprintf(stderr, "cannot resume from %s (missing, wrong magic, resolution or scene)\n", ckpt_in.c_str()); return 1; }
         CHECK_HR(hr_write_accumulator(ctx, acc.data()));
         first = hdr[3] + 1;
         sampled = hdr[3];
@@ -190,6 +187,10 @@ int main(int argc, char **argv) {
     bool have_cur = false, have_next = false;
     double chunk_sec = 0.0;   // duration of the last completed chunk (0 = not known yet)
     if (first <= sampling) { if (issue(first, cur)) return 1; have_cur = true; }
+    else if (!debug && sampled > 0) {   // resumed from a checkpoint that already holds every requested sampling: just resolve it
+        printf("reached max sampling\n");
+        if (save(sampled)) return 1;
+    }
     while (have_cur) {
         // keep the next chunk in flight unless the samplings run out or the time limit is already in sight
         double pre = now_sec() - begin;
@@ -229,9 +230,9 @@ int main(int argc, char **argv) {
         std::vector<float> acc((size_t)width * height * 3);
         if (combine()) { fprintf(stderr, "checkpoint: %s\n", hr_last_error()); return 1; }
         CHECK_HR(hr_read_accumulator(ctx, acc.data()));
-        uint32_t hdr[4] = {0x43415248u, width, height, sampled};
+        uint32_t hdr[5] = {CKPT_MAGIC, width, height, sampled, scene_hash};
         FILE *f = fopen(ckpt_out.c_str(), "wb");
-        bool ok = f && fwrite(hdr, 4, 4, f) == 4 && fwrite(acc.data(), sizeof(float), acc.size(), f) == acc.size();
+        bool ok = f && fwrite(hdr, 4, 5, f) == 5 && fwrite(acc.data(), sizeof(float), acc.size(), f) == acc.size();
         if (f) fclose(f);
         if (!ok) { fprintf(stderr, "cannot write checkpoint %s\n", ckpt_out.c_str()); return 1; }
     }

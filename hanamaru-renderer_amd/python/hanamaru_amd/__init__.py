@@ -140,8 +140,46 @@ def hip_lib():
         L.hr_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.hr_debug_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.hr_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hr_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.hr_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.hr_comm_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.hr_comm_destroy.argtypes = [C.c_void_p]
+        L.hr_allreduce_accumulator.argtypes = [C.c_void_p]
+        L.hr_allreduce_accumulators.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.hr_total_device_ptr.argtypes = [C.c_void_p]
+        L.hr_total_device_ptr.restype = C.c_void_p
         _hip = L
     return _hip
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library: bytes to hand to every rank's Renderer.comm_init_rank."""
+    L = hip_lib()
+    buf = (C.c_char * COMM_ID_BYTES)()
+    rc = L.hr_comm_get_unique_id(buf)
+    if rc != 0:
+        raise HipError(rc, L.hr_last_error().decode())
+    return bytes(buf)
+
+
+def comm_init_local(renderers):
+    """One process driving several GPUs: ncclCommInitAll over the renderers' devices."""
+    L = hip_lib()
+    arr = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+    rc = L.hr_comm_init_local(arr, len(renderers))
+    if rc != 0:
+        raise HipError(rc, L.hr_last_error().decode())
+
+
+def allreduce_accumulators(renderers):
+    L = hip_lib()
+    arr = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+    rc = L.hr_allreduce_accumulators(arr, len(renderers))
+    if rc != 0:
+        raise HipError(rc, L.hr_last_error().decode())
 
 
 class HostError(RuntimeError):
@@ -299,6 +337,20 @@ class Renderer:
         s = Stats()
         self._check(self.L.hr_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    # ---- multi-GPU: one all-reduce of the accumulators over RCCL (include/hanamaru_hip.h)
+    def comm_init_rank(self, unique_id, world_size, rank):
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self.L.hr_comm_init_rank(self._h, buf, world_size, rank))
+
+    def comm_destroy(self):
+        self._check(self.L.hr_comm_destroy(self._h))
+
+    def allreduce_accumulator(self):
+        self._check(self.L.hr_allreduce_accumulator(self._h))
+
+    def total_device_ptr(self):
+        return self.L.hr_total_device_ptr(self._h)
 
     def debug_draws(self, sampling, first_path, num_paths, window):
         out = np.empty((num_paths, window), dtype=np.uint64)

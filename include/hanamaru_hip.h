@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 1
+#define HR_ABI_VERSION 2
 
 typedef enum hr_status {
     HR_OK = 0,
@@ -168,6 +168,28 @@ int hr_write_accumulator(hr_ctx *ctx, const float *host_rgb); /* resume / post-c
 
 /* renderer.rs:64-90: scale by 1/(samplings*4) -> Reinhard -> gamma -> bilateral 3x3 -> u8 RGB. */
 int hr_resolve(hr_ctx *ctx, uint32_t samplings_done, uint8_t *host_rgb8);
+
+/* ---- multi-GPU (one node, RCCL over xGMI) --------------------------------------------------------------------------
+ * The loop being sharded is renderer.rs:32-43: samplings are independent and seeded by index, so rank r of N renders
+ * s = begin + r, begin + r + N, ... (hr_render's stride) into its own accumulator.  Before the resolve of renderer.rs:64-90
+ * the accumulators are summed with ONE ncclAllReduce (fp32, W*H*3 values: 24.9 MB at 1080p).  The sum goes to a separate
+ * buffer: the rank's own accumulator is untouched, so rendering can continue after a progress image.  After the call
+ * hr_resolve / hr_read_accumulator return the TOTAL, until the next hr_render / hr_render_debug / hr_clear /
+ * hr_write_accumulator on that context.  The collective is enqueued on the context's stream behind its render work.
+ *   one process per GPU:   rank 0: hr_comm_get_unique_id -> share the HR_COMM_ID_BYTES with the other ranks (any transport)
+ *                          every rank: hr_comm_init_rank, ..., hr_allreduce_accumulator
+ *   one process, N GPUs:   hr_comm_init_local(ctxs, N), ..., hr_allreduce_accumulators(ctxs, N)   (one RCCL group call)
+ * RCCL is loaded on first use; without it these return HR_ERR_UNSUPPORTED (there is no host-side fallback sum).  RCCL wants one
+ * rank per device: hr_comm_init_local over contexts that all share ONE device (a single-GPU box) sums them with a kernel on
+ * that device instead; a mix of shared and distinct devices is rejected. */
+#define HR_COMM_ID_BYTES 128
+int hr_comm_get_unique_id(void *id_out);
+int hr_comm_init_rank(hr_ctx *ctx, const void *id, int world_size, int rank);
+int hr_comm_init_local(hr_ctx **ctxs, int n);
+int hr_comm_destroy(hr_ctx *ctx);
+int hr_allreduce_accumulator(hr_ctx *ctx);
+int hr_allreduce_accumulators(hr_ctx **ctxs, int n);
+void *hr_total_device_ptr(hr_ctx *ctx);   /* device pointer of the all-reduced accumulator, NULL when not valid */
 
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* keys: "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase

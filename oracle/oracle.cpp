@@ -29,6 +29,8 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <vector>
 
 #include "hanamaru_hip.h"  // only the POD scene description (hr_scene_desc) — no product code is linked
@@ -848,26 +850,47 @@ ORC_API int orc_render(const orc_scene *os, uint32_t W, uint32_t H, uint32_t s_b
     const Scene &s = os->s;
     std::vector<Counters> cns(nthreads);
     for (auto &c : cns) memset(&c, 0, sizeof c);
-    for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
-        std::atomic<uint32_t> next_row{0};
-        auto worker = [&](int tid) {
-            Counters *cn = counters_out ? &cns[tid] : nullptr;
+    // renderer.rs:32-43: one parallel pass over the pixels per sampling (rayon work stealing), one barrier between samplings.
+    // Here: a persistent pool, chunks of 16 pixels handed out by an atomic counter (row-sized units would leave most of a
+    // 256-thread host idle on small images), a barrier per sampling.
+    const uint32_t CHUNK = 16;
+    const uint64_t pixels = (uint64_t)W * H;
+    const uint32_t chunks = (uint32_t)((pixels + CHUNK - 1) / CHUNK);
+    std::vector<uint32_t> samplings;
+    for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) samplings.push_back(sampling);
+    std::vector<std::atomic<uint32_t>> next(samplings.size());
+    for (auto &n : next) n.store(0);
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t arrived = 0, generation = 0;
+    auto barrier = [&]() {
+        std::unique_lock<std::mutex> lk(mu);
+        uint32_t gen = generation;
+        if (++arrived == (uint32_t)nthreads) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    };
+    auto worker = [&](int tid) {
+        Counters *cn = counters_out ? &cns[tid] : nullptr;
+        for (size_t k = 0; k < samplings.size(); k++) {
             for (;;) {
-                uint32_t y = next_row.fetch_add(1);
-                if (y >= H) break;
-                for (uint32_t x = 0; x < W; x++) {
-                    V3 c = supersampling(s, W, H, x, y, sampling, cn);
-                    double *p = &acc[((size_t)y * W + x) * 3];
-                    p[0] += c.x; p[1] += c.y; p[2] += c.z;
+                uint32_t c = next[k].fetch_add(1);
+                if (c >= chunks) break;
+                uint64_t p0 = (uint64_t)c * CHUNK, p1 = std::min<uint64_t>(p0 + CHUNK, pixels);
+                for (uint64_t i = p0; i < p1; i++) {
+                    uint32_t x = (uint32_t)(i % W), y = (uint32_t)(i / W);
+                    V3 col = supersampling(s, W, H, x, y, samplings[k], cn);
+                    double *p = &acc[i * 3];
+                    p[0] += col.x; p[1] += col.y; p[2] += col.z;
                 }
             }
-        };
-        if (nthreads == 1) worker(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
-            for (auto &t : th) t.join();
+            if (nthreads > 1) barrier();
         }
+    };
+    if (nthreads == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+        for (auto &t : th) t.join();
     }
     if (counters_out) {
         Counters total;

@@ -22,7 +22,9 @@ def emu_scenes(scenes, emu):
 def test_device_bvh_shape(emu_scenes):
     _, _, e = emu_scenes("rtcamp6_v3_1")
     st = e.stats()
-    assert st["tris"] == 12294 and st["spheres"] == 1 and st["cuboids"] == 1 and st["emitters"] == 1
+    # 12,294 triangles in the scene; early split clipping of long thin ones (kept here: it cuts the SAH cost by 10 %) stores
+    # some of them as several references
+    assert 12294 <= st["tris"] < 2 * 12294 and st["spheres"] == 1 and st["cuboids"] == 1 and st["emitters"] == 1
     assert st["leaves"] * 2 - 1 == st["nodes"] and st["max_depth"] < 40
     _, _, e2 = emu_scenes("spheres")
     assert e2.stats()["spheres"] == 105 and e2.stats()["emitters"] == 5 and e2.stats()["tris"] == 0
@@ -144,7 +146,8 @@ def test_lbvh_closest_hit_is_tree_independent(scenes, emu, emu_scenes, name, max
         emu.set_build_options()
     st, st0 = e.stats(), e_sah.stats()
     n = st["tris"] + st["spheres"] + st["cuboids"]
-    assert (st["tris"], st["spheres"], st["cuboids"]) == (st0["tris"], st0["spheres"], st0["cuboids"])
+    # (the host tree may hold long thin triangles as several split references; the device LBVH holds every triangle once)
+    assert st["tris"] <= st0["tris"] and (st["spheres"], st["cuboids"]) == (st0["spheres"], st0["cuboids"])
     assert st["nodes"] == 2 * n - 1 and st["leaves"] >= (n + max_leaf - 1) // max_leaf and st["max_depth"] < 64
     rays = _random_rays(sc, 4000, 23)
     got, gel = e.intersect(rays)

@@ -506,7 +506,8 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
 
 
 def test_cli_multi_device_in_one_process(tmp_path):
-    """hanamaru-hip --gpu-ids a,b: device r renders every N-th sampling, the accumulators are summed on the host for each image.
+    """hanamaru-hip --gpu-ids a,b: device r renders every N-th sampling, hr_allreduce_accumulators sums them for each image (RCCL
+    between distinct devices; contexts that share one device — all a single-GPU box can offer — are summed by a kernel on it).
     With two contexts on device 0 the image must equal the single-context image (same samplings, other summation order)."""
     import subprocess
     from PIL import Image
@@ -525,6 +526,69 @@ def test_cli_multi_device_in_one_process(tmp_path):
         imgs.append(np.asarray(Image.open(d / "result.png")).astype(int))
     diff = np.abs(imgs[0] - imgs[1])
     assert diff.max() <= 1 and (diff == 0).mean() > 0.999
+
+
+def test_rccl_allreduce_of_the_accumulator(gpu, scenes, ha):
+    """The multi-GPU exchange of the boundary (hr_comm_* / hr_allreduce_accumulator): RCCL is loaded, a communicator of world
+    size 1 is created on this GPU from an ncclUniqueId and ncclAllReduce runs on the accumulator.  With one rank the total must
+    equal the rank's own accumulator bit for bit; the total is what hr_read_accumulator / hr_resolve see until the next render,
+    and the rank's own accumulator is left untouched (it keeps accumulating)."""
+    sc, _ = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(96, 54)
+    gpu.clear()
+    gpu.render(1, 4)
+    own = gpu.read_accumulator()
+    uid = ha.comm_unique_id()
+    assert len(uid) == ha.COMM_ID_BYTES and any(uid)
+    gpu.comm_init_rank(uid, 1, 0)
+    try:
+        assert not gpu.total_device_ptr()
+        gpu.allreduce_accumulator()
+        assert gpu.total_device_ptr() and gpu.total_device_ptr() != gpu.L.hr_accumulator_device_ptr(gpu._h)
+        tot = gpu.read_accumulator()
+        assert np.array_equal(tot, own) and own.sum() > 0
+        img = gpu.resolve(3)
+        assert img.std() > 1
+        gpu.render(4, 5)                       # a new sampling invalidates the total ...
+        assert not gpu.total_device_ptr()
+        own2 = gpu.read_accumulator()          # ... and lands on top of the rank's own part
+        assert (own2 >= own).all() and own2.sum() > own.sum()
+        gpu.allreduce_accumulator()
+        assert np.array_equal(gpu.read_accumulator(), own2)
+        with pytest.raises(ha.HipError):
+            gpu.comm_init_rank(uid, 1, 1)      # rank outside the world
+    finally:
+        gpu.comm_destroy()
+    with pytest.raises(ha.HipError):
+        gpu.allreduce_accumulator()            # no communicator any more
+
+
+def test_same_device_group_sum(scenes, ha):
+    """hr_comm_init_local over contexts on ONE device + hr_allreduce_accumulators: every context ends up with the same total =
+    the sum of the parts, i.e. (sharded by sampling index) the accumulator of one context that rendered all samplings."""
+    sc, _ = scenes("cornell_mini")
+    rs = [ha.Renderer(0) for _ in range(3)]
+    try:
+        for r in rs:
+            r.upload_scene(sc)
+            r.set_resolution(80, 45)
+        ha.comm_init_local(rs)
+        for k, r in enumerate(rs):
+            r.render(1 + k, 10, 3)
+        ha.allreduce_accumulators(rs)
+        tots = [r.read_accumulator().astype(np.float64) for r in rs]
+        assert np.array_equal(tots[0], tots[1]) and np.array_equal(tots[0], tots[2])
+        one = ha.Renderer(0)
+        one.upload_scene(sc)
+        one.set_resolution(80, 45)
+        one.render(1, 10)
+        ref = one.read_accumulator().astype(np.float64)
+        one.close()
+        assert np.abs(tots[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    finally:
+        for r in rs:
+            r.close()
 
 
 def test_rtcamp5_gpu_render_against_the_references_committed_image(gpu, scenes):

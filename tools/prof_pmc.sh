@@ -1,17 +1,19 @@
 #!/bin/bash
-# PMC passes for the trace / seed kernels (run on the GPU box through gpurun).  Each pass is its own
-# rocprofv3 run with --pmc only (never combined with tracing options).
+# PMC passes for the trace / seed kernels (run on the GPU box through gpurun).  Each pass is its own rocprofv3 run with --pmc
+# only (never combined with tracing options).  Writes $OUT/summary.txt and $OUT/pmc_traffic.json; copy the latter to
+# profiles/rNN_pmc_traffic.json — bench.py reads the newest one for roofline.traffic and roofline.issue.
+#   usage: tools/prof_pmc.sh [outdir] [round-tag]      e.g. tools/prof_pmc.sh gpurun_out/pmc_r02 r02
 set -u
 OUT=${1:-gpurun_out/pmc}
+TAG=${2:-r02}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CMD="python bench.py --steps 1 --warmup 0 --spp-per-step 4 --no-counters --no-cpu-baseline ${BENCH_ARGS:-}"
 PASSES=${PASSES:-7}
-rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 i=0
 for pass in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+  "SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
   "FETCH_SIZE" \
@@ -22,24 +24,42 @@ for pass in \
   timeout 600 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pass$i" -o p -- $CMD > "$OUT/pass$i.log" 2>&1
   echo "pass $i rc=$?" >> "$OUT/status.log"
 done
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(int)
+disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        if row["Counter_Name"] in ("SQ_WAVES", "FETCH_SIZE", "TCC_HIT_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_ACTIVE_INST_VALU", "WRITE_SIZE", "TA_BUSY_avr"):
-            cnt[(k, row["Counter_Name"])] += 1
+        disp[k][row["Counter_Name"]].add(row.get("Dispatch_Id", "?"))
+PATHS = 1920 * 1080 * 4 * 4   # one launch of either kernel under this command
+kernels = {}
 with open(out + "/summary.txt", "w") as o:
     for k, d in agg.items():
-        if "trace" not in k and "seed" not in k:
+        if "trace_kernel" not in k and "seed_" not in k:
             continue
         o.write(k + "\n")
+        per = {}
         for c, v in sorted(d.items()):
-            o.write("   %-36s %.6g\n" % (c, v))
-        o.write("   dispatch counts: %s\n" % {c: n for (kk, c), n in cnt.items() if kk == k})
+            n = max(1, len(disp[k][c]))
+            o.write("   %-36s %.6g   (%d dispatches)\n" % (c, v, n))
+            per[c] = v / n
+        name = "trace_kernel" if "trace_kernel" in k else ("seed_pc_kernel" if "seed_pc" in k else k.replace("void ", "").strip())
+        e = {}
+        # FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (x2)
+        if "FETCH_SIZE" in per: e["fetch_bytes_per_path"] = per["FETCH_SIZE"] * 1024 * 2.0 / PATHS
+        if "WRITE_SIZE" in per: e["write_bytes_per_path"] = per["WRITE_SIZE"] * 1024 / PATHS
+        for c, key in (("SQ_INSTS_VALU", "valu_per_path"), ("SQ_INSTS_SALU", "salu_per_path"), ("SQ_INSTS_VMEM_RD", "vmem_per_path"), ("SQ_INSTS_LDS", "lds_per_path")):
+            if c in per: e[key] = per[c] / PATHS
+        if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per: e["l2_hit_rate"] = per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
+        if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per: e["valu_lane_utilisation"] = per["SQ_THREAD_CYCLES_VALU"] / max(1.0, per["SQ_ACTIVE_INST_VALU"] * 64)
+        if name in kernels: continue
+        kernels[name] = e
+json.dump({"paths_per_launch": PATHS, "kernels": kernels,
+           "source": "profiles/%s_pmc_summary.txt (tools/prof_pmc.sh: separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction; kernels run serialised under PMC)" % tag},
+          open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())
+print(open(out + "/pmc_traffic.json").read())
 PY
