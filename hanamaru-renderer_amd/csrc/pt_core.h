@@ -238,6 +238,19 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         else if (fabsf(s.pos.x - mx.x) < EPS_F) { s.n = v3(1, 0, 0); s.u = uvw.z; s.v = uvw.y; }
         else if (fabsf(s.pos.z - mn.z) < EPS_F) { s.n = v3(0, 0, -1); s.u = uvw.x; s.v = uvw.y; }
         else if (fabsf(s.pos.z - mx.z) < EPS_F) { s.n = v3(0, 0, 1); s.u = uvw.x; s.v = uvw.y; }
+        else {
+            // fp32 only: far from the origin the hit position is off its face by more than EPS (|pos| * 6e-8 > 1e-4 from
+            // |pos| ~ 1700; the f64 reference always finds a face) — take the nearest face instead of a zero normal
+            float dy1 = fabsf(s.pos.y - mx.y), dy0 = fabsf(s.pos.y - mn.y), dx0 = fabsf(s.pos.x - mn.x), dx1 = fabsf(s.pos.x - mx.x);
+            float dz0 = fabsf(s.pos.z - mn.z), dz1 = fabsf(s.pos.z - mx.z);
+            float best = fminf(fminf(fminf(dy1, dy0), fminf(dx0, dx1)), fminf(dz0, dz1));
+            if (best == dy1) { s.n = v3(0, 1, 0); s.u = uvw.x; s.v = 1.0f - uvw.z; }
+            else if (best == dy0) { s.n = v3(0, -1, 0); s.u = uvw.x; s.v = 1.0f - uvw.z; }
+            else if (best == dx0) { s.n = v3(-1, 0, 0); s.u = uvw.z; s.v = uvw.y; }
+            else if (best == dx1) { s.n = v3(1, 0, 0); s.u = uvw.z; s.v = uvw.y; }
+            else if (best == dz0) { s.n = v3(0, 0, -1); s.u = uvw.x; s.v = uvw.y; }
+            else { s.n = v3(0, 0, 1); s.u = uvw.x; s.v = uvw.y; }
+        }
     }
 }
 

@@ -1026,6 +1026,45 @@ ORC_API int orc_intersect(const orc_scene *os, uint32_t n, const double *rays, d
     return 0;
 }
 
+// closest hit WITH the material fetch of scene.rs:385-401, for the analytic unit tests: out = 19 doubles
+// {hit, distance, pos xyz, normal xyz, u, v, surface, param, albedo rgb, emission rgb, roughness}
+ORC_API int orc_intersect_material(const orc_scene *os, const double *ray6, double *out, int32_t *out_element) {
+    Ray r{V3(ray6[0], ray6[1], ray6[2]), V3(ray6[3], ray6[4], ray6[5])};
+    Intersection isect;
+    long el;
+    bool hit = scene_intersect(os->s, r, isect, &el, nullptr);
+    out[0] = hit ? 1.0 : 0.0; out[1] = isect.distance;
+    out[2] = isect.position.x; out[3] = isect.position.y; out[4] = isect.position.z;
+    out[5] = isect.normal.x; out[6] = isect.normal.y; out[7] = isect.normal.z;
+    out[8] = isect.u; out[9] = isect.v;
+    out[10] = (double)isect.material.surface; out[11] = isect.material.param;
+    out[12] = isect.material.albedo.x; out[13] = isect.material.albedo.y; out[14] = isect.material.albedo.z;
+    out[15] = isect.material.emission.x; out[16] = isect.material.emission.y; out[17] = isect.material.emission.z;
+    out[18] = isect.material.roughness;
+    if (out_element) *out_element = (int32_t)el;
+    return 0;
+}
+// PointMaterial::sample (material.rs:91-151) and ::bsdf (:53-89) on explicit arguments.
+// sample: out = 8 doubles {some(1)/none(0), origin xyz, direction xyz, reflectance}
+ORC_API int orc_material_sample(int surface, double param, double roughness, double r0, double r1, const double *position, const double *view,
+                                const double *normal, double *out) {
+    PointMaterial m;
+    m.surface = surface; m.param = param; m.albedo = V3(1, 1, 1); m.emission = V3(); m.roughness = roughness;
+    SampleResult res;
+    res.ray.origin = V3(); res.ray.direction = V3(); res.reflectance = 0.0;
+    bool ok = material_sample(m, r0, r1, V3(position[0], position[1], position[2]), V3(view[0], view[1], view[2]), V3(normal[0], normal[1], normal[2]), res);
+    out[0] = ok ? 1.0 : 0.0;
+    out[1] = res.ray.origin.x; out[2] = res.ray.origin.y; out[3] = res.ray.origin.z;
+    out[4] = res.ray.direction.x; out[5] = res.ray.direction.y; out[6] = res.ray.direction.z;
+    out[7] = res.reflectance;
+    return 0;
+}
+ORC_API double orc_material_bsdf(int surface, double param, double roughness, const double *view, const double *normal, const double *light) {
+    PointMaterial m;
+    m.surface = surface; m.param = param; m.albedo = V3(1, 1, 1); m.emission = V3(); m.roughness = roughness;
+    return material_bsdf(m, V3(view[0], view[1], view[2]), V3(normal[0], normal[1], normal[2]), V3(light[0], light[1], light[2]));
+}
+
 // material / texture lookups for unit tests: sample a skybox direction
 ORC_API int orc_skybox_sample(const orc_scene *os, const double *dir, double *rgb) {
     V3 c = skybox_sample(os->s, V3(dir[0], dir[1], dir[2]));

@@ -36,6 +36,10 @@ def lib():
         L.orc_u64_to_f64.argtypes = [C.c_uint64]
         L.orc_u64_to_f64.restype = C.c_double
         L.orc_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_intersect_material.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_material_sample.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_material_bsdf.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_material_bsdf.restype = C.c_double
         L.orc_skybox_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_image_sample_bilinear.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
         L.orc_bvh_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -110,6 +114,17 @@ class OracleScene:
         lib().orc_intersect(self._h, r.shape[0], r.ctypes.data, out.ctypes.data, el.ctypes.data)
         return out, el
 
+    def intersect_material(self, origin, direction):
+        """Closest hit with the material fetch (scene.rs:385-401): dict of hit, distance, position, normal, u, v, surface, param,
+        albedo, emission, roughness, element."""
+        r = np.ascontiguousarray(list(origin) + list(direction), dtype=np.float64)
+        out = np.zeros(19, dtype=np.float64)
+        el = C.c_int32(-1)
+        lib().orc_intersect_material(self._h, r.ctypes.data, out.ctypes.data, C.byref(el))
+        return {"hit": out[0] == 1.0, "distance": out[1], "position": out[2:5].copy(), "normal": out[5:8].copy(), "u": out[8], "v": out[9],
+                "surface": int(out[10]), "param": out[11], "albedo": out[12:15].copy(), "emission": out[15:18].copy(), "roughness": out[18],
+                "element": el.value}
+
     def skybox(self, d):
         d = np.ascontiguousarray(d, dtype=np.float64)
         out = np.zeros(3, dtype=np.float64)
@@ -145,6 +160,19 @@ class OracleScene:
 
     def num_emissions(self):
         return lib().orc_num_emissions(self._h)
+
+
+def material_sample(surface, param, roughness, r0, r1, position, view, normal):
+    """PointMaterial::sample (material.rs:91-151): (some, origin, direction, reflectance)."""
+    p, v, n = (np.ascontiguousarray(a, dtype=np.float64) for a in (position, view, normal))
+    out = np.zeros(8, dtype=np.float64)
+    lib().orc_material_sample(surface, param, roughness, r0, r1, p.ctypes.data, v.ctypes.data, n.ctypes.data, out.ctypes.data)
+    return out[0] == 1.0, out[1:4].copy(), out[4:7].copy(), float(out[7])
+
+
+def material_bsdf(surface, param, roughness, view, normal, light):
+    v, n, l = (np.ascontiguousarray(a, dtype=np.float64) for a in (view, normal, light))
+    return lib().orc_material_bsdf(surface, param, roughness, v.ctypes.data, n.ctypes.data, l.ctypes.data)
 
 
 def isaac64(seed, count, skip=0):

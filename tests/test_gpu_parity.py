@@ -6,9 +6,11 @@ Tolerances (stated once, used everywhere):
   * fp32 draws handed to the trace kernel: equal to the oracle's f64 draws rounded once to fp32.
   * closest-hit queries: same element; |t_gpu - t_ref| <= 2e-5 * max(1, t_ref) for 99 % (max 1e-3: grazing spheres); normals: median error < 1e-5 (meshes) /
     1e-4 (r = 0.1 spheres five units away: fp32 position error over the radius), 99.9 % < 2e-3.
-  * radiance accumulator, per channel: |gpu - oracle| <= 1e-2 * max(1, |oracle|) for >= 99.5 % of channels
-    (an fp32 rounding difference can flip a branch — Fresnel coin, hit/miss at a silhouette — and then that
-    one path decorrelates completely), and the image mean agrees to 2e-3 relative.
+  * radiance accumulator, per channel: |gpu - oracle| <= 1e-2 * max(1, |oracle|) and <= 1e-3 * max(1, |oracle|) for the
+    fractions of GATES below — per scene, set just under what is measured (an fp32 rounding difference can flip a
+    branch — Fresnel coin, hit/miss at a silhouette, a grazing sphere hit — and then that one path decorrelates
+    completely, SURVEY.md §7.5-3: scenes full of small spheres or refracting diamonds have more such paths than the
+    headline scene), and the image mean agrees to 2e-3 relative (5e-3 at full size against full-size oracle crops).
   * 8-bit image after the post chain, fed the SAME accumulator: <= 1 LSB on every channel, > 99 % exact.
 """
 import os
@@ -19,12 +21,32 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ATOL_REL = 1e-2
-FRAC_OK = 0.995
+# scene -> (least fraction of channels within 1e-2, within 1e-3); measured values in profiles/r02_parity_report.json
+GATES = {
+    "rtcamp6_v3_1": (0.9995, 0.9990), "rtcamp6_dodeca": (0.9995, 0.9985), "rtcamp6_v3": (0.9995, 0.9985), "rtcamp6_v1": (0.9995, 0.9985),
+    "material_examples": (0.9995, 0.9970), "simple": (0.9995, 0.9970), "cornell_mini": (0.9990, 0.9975), "tbf3": (0.9990, 0.9950),
+    "rtcamp6_v2": (0.9975, 0.9900), "spheres": (0.9975, 0.9800), "rtcamp5": (0.9965, 0.9800),
+}
+CROP_SLACK = (0.0015, 0.006)
+FRAC_OK = 0.9995   # the headline scene's gate, for the tests that render rtcamp6_v3_1
+
+
+def _fractions(acc, ref):
+    rel = np.abs(acc.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    return float((rel <= 1e-2).mean()), float((rel <= 1e-3).mean())
 
 
 def _compare(acc, ref):
-    rel = np.abs(acc.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
-    return float((rel <= ATOL_REL).mean()), float(acc.mean()), float(ref.mean())
+    return _fractions(acc, ref)[0], float(acc.mean()), float(ref.mean())
+
+
+def _check_scene(name, acc, ref, what=""):
+    f2, f3 = _fractions(acc, ref)
+    g2, g3 = GATES[name]
+    print("parity %s %s: within 1e-2 %.5f (gate %.4f), within 1e-3 %.5f (gate %.4f), mean gpu %.6g oracle %.6g" % (name, what, f2, g2, f3, g3, acc.mean(), ref.mean()))
+    assert np.isfinite(acc).all()
+    assert f2 >= g2 and f3 >= g3, (name, what, f2, f3)
+    return f2, f3
 
 
 def test_isaac64_raw_outputs_bit_exact(gpu, scenes, orc):
@@ -92,10 +114,10 @@ def test_closest_hit_matches_oracle(gpu, scenes, name):
     assert np.median(nerr) < (1e-5 if name == "rtcamp6_v3_1" else 1e-4) and np.quantile(nerr, 0.999) < 2e-3
 
 
-@pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 160, 90, 4), ("cornell_mini", 96, 64, 4), ("cornell_mini", 320, 200, 8), ("spheres", 128, 72, 2),
-                                         ("rtcamp6_dodeca", 98, 55, 2), ("rtcamp6_v3", 128, 72, 3), ("simple", 160, 90, 3),
-                                         ("material_examples", 160, 90, 3), ("rtcamp6_v1", 128, 72, 2), ("rtcamp6_v2", 128, 72, 1),
-                                         ("rtcamp5", 128, 72, 2), ("tbf3", 128, 72, 2)])
+@pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 320, 180, 4), ("cornell_mini", 96, 64, 4), ("cornell_mini", 320, 200, 8), ("spheres", 256, 144, 2),
+                                         ("rtcamp6_dodeca", 195, 111, 2), ("rtcamp6_v3", 256, 144, 3), ("simple", 256, 144, 3),
+                                         ("material_examples", 256, 144, 3), ("rtcamp6_v1", 256, 144, 2), ("rtcamp6_v2", 192, 108, 1),
+                                         ("rtcamp5", 256, 144, 2), ("tbf3", 256, 144, 2)])
 def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
     sc, o = scenes(name)
     gpu.upload_scene(sc)
@@ -105,9 +127,8 @@ def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
     acc = gpu.read_accumulator()
     gpu.set_option("batch", 0)   # back to automatic
     ref, _ = o.render(w, h, 1, s + 1, threads=0)
-    assert np.isfinite(acc).all()
-    frac, m_gpu, m_ref = _compare(acc, ref)
-    assert frac >= FRAC_OK, (frac, m_gpu, m_ref)
+    _check_scene(name, acc, ref, "%dx%dx%d" % (w, h, s))
+    m_gpu, m_ref = float(acc.mean()), float(ref.mean())
     assert abs(m_gpu - m_ref) <= 2e-3 * max(1.0, abs(m_ref)), (m_gpu, m_ref)
 
 
@@ -119,7 +140,7 @@ def test_golden_accumulator(gpu, scenes):
     gpu.set_resolution(64, 36)
     gpu.render(1, 3)
     frac, m_gpu, m_ref = _compare(gpu.read_accumulator(), g["acc"].astype(np.float64))
-    assert frac >= FRAC_OK and abs(m_gpu - m_ref) <= 2e-3 * max(1.0, m_ref)
+    assert frac >= 0.999 and abs(m_gpu - m_ref) <= 2e-3 * max(1.0, m_ref)   # 6,912 channels: one flipped path is 4e-4
 
 
 def test_sharding_and_batching_are_exact_partitions(gpu, scenes):
@@ -146,25 +167,52 @@ def test_sharding_and_batching_are_exact_partitions(gpu, scenes):
     gpu.set_option("batch", 0)   # back to automatic
 
 
-def test_full_size_properties(gpu, scenes):
-    """BASELINE size (1920x1080): path count, every pixel touched, mean radiance agrees with a low-res
-    oracle render of the same scene (the image mean is resolution independent to first order)."""
+def _crop_parity(gpu, o, name, W, H, S, crops, size=64, gates=None, crop_slack=None):
+    """GPU render of the whole W x H image, S samplings, against the oracle on `crops` (top-left corners, size x size pixels)
+    at the SAME full-image coordinates (seeds depend on them): every crop must pass the scene's gates, and the union of the
+    crops agrees in the mean to 5e-3."""
+    gpu.set_resolution(W, H)
+    gpu.set_option("batch", 0)
+    gpu.clear()
+    gpu.render(1, S + 1)
+    acc = gpu.read_accumulator()
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    got_all, ref_all, fr = [], [], []
+    for (x0, y0) in crops:
+        ref = o.render_region(W, H, x0, y0, size, size, 1, S + 1, threads=0)
+        got = acc[y0:y0 + size, x0:x0 + size].astype(np.float64)
+        f2, f3 = _fractions(got, ref)
+        print("parity %s %dx%dx%d crop (%d,%d): within 1e-2 %.5f, within 1e-3 %.5f, mean gpu %.6g oracle %.6g" % (name, W, H, S, x0, y0, f2, f3, got.mean(), ref.mean()))
+        fr.append((f2, f3))
+        got_all.append(got)
+        ref_all.append(ref)
+    g2, g3 = gates or GATES[name]
+    slack = crop_slack or CROP_SLACK
+    # a single crop holds 12,288 channels (one decorrelated path is 2.4e-4 of them) and may sit on the scene's hardest spot
+    # (refracting dodecahedron, grazing sphere rims): per crop the gates are relaxed by CROP_SLACK, pooled they hold as they are
+    for (x0, y0), (f2, f3) in zip(crops, fr):
+        assert f2 >= g2 - slack[0] and f3 >= g3 - slack[1], (name, x0, y0, f2, f3)
+    p2, p3 = _fractions(np.concatenate(got_all), np.concatenate(ref_all))
+    print("parity %s %dx%dx%d all crops: within 1e-2 %.5f (gate %.4f), within 1e-3 %.5f (gate %.4f)" % (name, W, H, S, p2, g2, p3, g3))
+    assert p2 >= g2 and p3 >= g3, (name, p2, p3)
+    g, r = np.concatenate(got_all).mean(), np.concatenate(ref_all).mean()
+    assert abs(g - r) <= 5e-3 * r, (g, r)
+    return acc
+
+
+def test_config3_full_size_crops(gpu, scenes):
+    """BASELINE config 3 (rtcamp6, 1920x1080) at its full size: exact path count, no RNG-window overflow, and oracle parity on
+    five 64x64 crops at full-image coordinates: sky, textured floor + armadillo, bunny wire silhouette, picture-frame edge
+    against the sky (mirror), and the image's bottom-right corner."""
     sc, o = scenes("rtcamp6_v3_1")
     gpu.upload_scene(sc)
-    gpu.set_resolution(1920, 1080)
     gpu.set_option("counters", 1)
-    gpu.clear()
-    gpu.render(1, 3)
-    acc = gpu.read_accumulator()
+    acc = _crop_parity(gpu, o, "rtcamp6_v3_1", 1920, 1080, 8, [(160, 130), (800, 760), (700, 250), (1500, 300), (1856, 1016)])
     st = gpu.stats()
     gpu.set_option("counters", 0)
-    assert st["paths"] == 1920 * 1080 * 4 * 2
-    assert st["rng_overflow"] == 0
-    assert np.isfinite(acc).all() and (acc >= 0).all()
+    assert st["paths"] == 1920 * 1080 * 4 * 8 and st["rng_overflow"] == 0
     assert (acc.sum(axis=2) > 0).mean() > 0.9   # black floor texels (albedo 0) and dark sky stay exactly 0
     assert 2.5 < st["rays"] / st["paths"] < 3.6          # SURVEY.md Appendix D: 3.05 rays per path
-    ref, _ = o.render(240, 135, 1, 3, threads=0)
-    assert abs(acc.mean() - ref.mean()) < 0.05 * ref.mean()
 
 
 def test_post_chain_matches_oracle(gpu, scenes, orc):
@@ -352,38 +400,44 @@ def test_bench_multirank_path_on_one_gpu(tmp_path):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "roofline" in j
 
 
-def test_4k_and_sphere_scene_properties(gpu, scenes):
-    """BASELINE configs 5 and 2 at their full sizes, size-independent properties only (the oracle needs minutes there):
-    exact path counts, no RNG-window overflow, finite non-negative radiance, the hand-off buffer cap shrinking the batch
-    at 4K, and image means that agree with a low-resolution oracle render of the same scene."""
+def test_config5_4k_crops(gpu, scenes):
+    """BASELINE config 5 (rtcamp6 + fractal dodecahedron, 3840x2160) at its full size on one GPU: exact path count, the hand-off
+    buffer cap shrinking the launch, and oracle parity on 64x64 crops at full-image coordinates: the dodecahedron (deep
+    BVH, refraction), the bunny's ear silhouette, the picture frame's edge against the sky, floor + armadillo, open sky."""
     sc, o = scenes("rtcamp6_dodeca")
     gpu.upload_scene(sc)
-    gpu.set_resolution(3840, 2160)
     gpu.set_option("counters", 1)
-    gpu.set_option("batch", 0)
-    gpu.set_option("max_tail_gib", 4)                    # one 4K sampling of hand-off records is 4.25 GB: the cap shrinks the batch to 1
+    W, H, S = 3840, 2160, 4
+    acc = _crop_parity(gpu, o, "rtcamp6_dodeca", W, H, S, [(1950, 150), (1850, 520), (3040, 640), (1620, 1560), (380, 320)])
+    st = gpu.stats()
+    assert st["paths"] == W * H * 4 * S and st["rng_overflow"] == 0 and st["trace_launches"] == 1
+    gpu.set_option("max_tail_gib", 4)                    # one 4K sampling of hand-off records is 4.25 GB: the cap shrinks the launch to 1
     gpu.clear()
     gpu.render(1, 3)
-    acc = gpu.read_accumulator()
     st = gpu.stats()
     gpu.set_option("max_tail_gib", 20)
-    assert st["paths"] == 3840 * 2160 * 4 * 2 and st["rng_overflow"] == 0
-    assert st["trace_launches"] == 2
-    assert np.isfinite(acc).all() and (acc >= 0).all()
-    ref, _ = o.render(192, 108, 1, 3, threads=0)
-    assert abs(acc.mean() - ref.mean()) < 0.05 * ref.mean()
-    sc2, o2 = scenes("spheres")
-    gpu.upload_scene(sc2)
-    gpu.set_resolution(1920, 1080)
+    gpu.set_option("counters", 0)
+    assert st["paths"] == W * H * 4 * 2 and st["trace_launches"] == 2
+    capped = gpu.read_accumulator()
     gpu.clear()
-    gpu.render(1, 5)
-    acc = gpu.read_accumulator()
+    gpu.render(1, 3)
+    whole = gpu.read_accumulator()
+    assert np.abs(capped.astype(np.float64) - whole).max() <= 1e-4 * max(1.0, float(np.abs(whole).max()))
+
+
+def test_config2_spheres_full_size_crops(gpu, scenes):
+    """BASELINE config 2 (spheres only, Diffuse + Specular, 1920x1080 x 64 samplings) at its full size: path count, no
+    triangle tests, and oracle parity on 64x64 crops: a sphere's silhouette, two overlapping spheres, cloud / sky only,
+    the bottom-left image corner (spheres cut by the border), the inside of a sphere."""
+    sc, o = scenes("spheres")
+    gpu.upload_scene(sc)
+    gpu.set_option("counters", 1)
+    # 64 samplings = 256 paths per pixel: a pixel is off by more than 1e-3 as soon as ONE of them took another branch (grazing
+    # sphere rims), so the 1e-3 fraction falls with the sampling count while the 1e-2 fraction rises — gates for this count
+    _crop_parity(gpu, o, "spheres", 1920, 1080, 64, [(900, 190), (400, 160), (1150, 590), (0, 1016), (760, 900)], gates=(0.9990, 0.975), crop_slack=(0.0015, 0.02))
     st = gpu.stats()
     gpu.set_option("counters", 0)
-    assert st["paths"] == 1920 * 1080 * 4 * 4 and st["rng_overflow"] == 0 and st["tri_tests"] == 0 and st["sphere_tests"] > 0
-    assert np.isfinite(acc).all() and (acc >= 0).all()
-    ref2, _ = o2.render(240, 135, 1, 5, threads=0)
-    assert abs(acc.mean() - ref2.mean()) < 0.05 * ref2.mean()
+    assert st["paths"] == 1920 * 1080 * 4 * 64 and st["rng_overflow"] == 0 and st["tri_tests"] == 0 and st["sphere_tests"] > 0
 
 
 def test_matches_the_reference_binarys_committed_render(gpu, scenes):
@@ -407,7 +461,7 @@ def test_matches_the_reference_binarys_committed_render(gpu, scenes):
     psnr = 10 * np.log10(255.0 ** 2 / (d ** 2).mean())
     print("PSNR %.2f dB, mean abs diff %.4f, exact channels %.4f, within 1 LSB %.4f, max %d" % (psnr, d.mean(), (d == 0).mean(), (d <= 1).mean(), d.max()))
     # measured: PSNR 74.2 dB, 99.80 % of the channels identical, 99.99 % within 1 LSB, max 7
-    assert psnr > 65.0 and (d == 0).mean() > 0.99 and (d <= 1).mean() > 0.999
+    assert psnr > 70.0 and (d == 0).mean() > 0.997 and (d <= 1).mean() > 0.9998 and d.max() <= 12
 
 
 @pytest.mark.parametrize("name,max_leaf", [("rtcamp6_v3_1", 4), ("rtcamp6_dodeca", 4), ("spheres", 2), ("cornell_mini", 1)])
@@ -454,10 +508,10 @@ def test_device_bvh_build_is_interchangeable(gpu, scenes, name, max_leaf):
     assert (e0[hit] == e1[hit]).mean() > 0.999
     assert np.isfinite(a1).all()
     frac, m1, m0 = _compare(a1, a0)
-    assert frac > FRAC_OK and abs(m1 - m0) <= 2e-3 * max(1e-3, abs(m0))
+    assert frac >= GATES[name][0] and abs(m1 - m0) <= 2e-3 * max(1e-3, abs(m0))
     ref, _ = o.render(160, 90, 1, 3, threads=0, counters=True)
     frac, m1, mr = _compare(a1, ref)
-    assert frac > FRAC_OK and abs(m1 - mr) <= 2e-3 * max(1e-3, abs(mr))
+    assert frac >= GATES[name][0] and abs(m1 - mr) <= 2e-3 * max(1e-3, abs(mr))
 
 
 def test_mark_and_wait_keep_the_pipeline_running(gpu, scenes):
@@ -526,6 +580,30 @@ def test_cli_multi_device_in_one_process(tmp_path):
         imgs.append(np.asarray(Image.open(d / "result.png")).astype(int))
     diff = np.abs(imgs[0] - imgs[1])
     assert diff.max() <= 1 and (diff == 0).mean() > 0.999
+
+
+def test_cuboid_far_from_the_origin_stays_finite(gpu, ha, orc):
+    """The cuboid face cascade compares the hit position with the face planes at an absolute EPS of 1e-4 (scene.rs:160-182); in
+    fp32 a position 2000 units from the origin is off by more than that, no face matches, and a zero normal would put NaNs
+    into the accumulator.  The kernel then takes the nearest face: the render of the `simple` scene moved 2000 units away stays
+    finite and keeps the f64 oracle's brightness."""
+    sc = ha.Scene("simple")
+    d = sc.desc
+    shift = (2000.0, 0.0, -2000.0)
+    for i in range(d.num_elements):
+        e = d.elements[i]
+        for v in (e.center, e.aabb_min, e.aabb_max):
+            v.x += shift[0]; v.y += shift[1]; v.z += shift[2]
+    d.camera.eye.x += shift[0]; d.camera.eye.y += shift[1]; d.camera.eye.z += shift[2]
+    o = orc.OracleScene(sc.desc_ptr)
+    gpu.upload_scene(sc)
+    gpu.set_resolution(160, 90)
+    gpu.clear()
+    gpu.render(1, 5)
+    acc = gpu.read_accumulator()
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    ref, _ = o.render(160, 90, 1, 5, threads=0)
+    assert abs(acc.mean() - ref.mean()) <= 0.03 * ref.mean(), (acc.mean(), ref.mean())
 
 
 def test_rccl_allreduce_of_the_accumulator(gpu, scenes, ha):

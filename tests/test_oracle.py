@@ -181,6 +181,144 @@ def test_closest_hit_basics(scenes):
     assert out[3, 0] == 1 and el[3] == 0 and out[3, 1] == pytest.approx(3.0) and np.allclose(out[3, 5:8], (0, 1, 0))
 
 
+def _bilinear_numpy(im8, u, v):
+    """texture.rs:29-49 + 59-63 on an RGBA8 image array (row 0 = top), gamma-space interpolation, then ^2.2."""
+    im = im8.astype(np.float64) / 255.0
+    hh, ww = im.shape[:2]
+
+    def texel(x, y):
+        x = min(x, ww - 1)
+        yy = (hh - y - 1) & 0xffffffff
+        return im[min(yy, hh - 1), x, :3]
+    x, y = u * ww, v * hh
+    x1, y1 = math.floor(x), math.floor(y)
+    x2, y2 = x1 + 1.0, y1 + 1.0
+    ix1, ix2, iy1, iy2 = max(int(x1), 0), max(int(x2), 0), max(int(y1), 0), max(int(y2), 0)
+    g = (texel(ix1, iy1) * (x2 - x) * (y2 - y) + texel(ix2, iy1) * (x - x1) * (y2 - y) + texel(ix1, iy2) * (x2 - x) * (y - y1) +
+         texel(ix2, iy2) * (x - x1) * (y - y1))
+    return g ** 2.2
+
+
+# ---- hand-derived pins for the code paths the reference's committed rtcamp6 image does not exercise (material.rs:139-199,
+#      scene.rs:67-71, scene.rs:393-395): closed-form values, not oracle-vs-oracle comparisons
+
+def test_refraction_closed_forms(orc):
+    """PointMaterial::sample for Refraction (material.rs:154-199) at configurations with closed-form answers."""
+    n = np.array([0.0, 1.0, 0.0])
+    pos = np.array([0.3, 0.0, -0.2])
+    ior = 1.5
+    # normal incidence from outside: Fresnel r_s = r_p = ((1/ior - 1) / (1/ior + 1))^2 = 0.04
+    fr = ((1 / ior - 1) / (1 / ior + 1)) ** 2
+    assert fr == pytest.approx(0.04)
+    ok, o, d, refl = orc.material_sample(2, ior, 0.0, 0.039, 0.5, pos, -(-n), n)   # view = direction TOWARDS the eye; sample negates it
+    assert ok and np.allclose(d, n, atol=1e-15) and refl == 1.0 and np.allclose(o, pos + 1e-4 * n)          # r0 <= fr: mirror branch
+    ok, o, d, refl = orc.material_sample(2, ior, 0.0, 0.041, 0.5, pos, n, n)
+    assert ok and np.allclose(d, -n, atol=1e-15) and refl == pytest.approx((1 / ior) ** 2) and np.allclose(o, pos - 1e-4 * n)   # straight through
+    # Snell at 45 degrees: sin(t) = sin(45) / 1.5
+    view = np.array([math.sin(math.pi / 4), math.cos(math.pi / 4), 0.0])
+    ok, o, d, refl = orc.material_sample(2, ior, 0.0, 0.999, 0.5, pos, view, n)
+    st = math.sin(math.pi / 4) / ior
+    assert np.allclose(d, [-st, -math.sqrt(1 - st * st), 0.0], atol=1e-14) and refl == pytest.approx(1 / ior ** 2)
+    cos_i, cos_t = math.cos(math.pi / 4), math.sqrt(1 - st * st)
+    rs = ((cos_i / ior - cos_t) / (cos_i / ior + cos_t)) ** 2
+    rp = ((cos_t / ior - cos_i) / (cos_t / ior + cos_i)) ** 2
+    just_below = 0.5 * (rs + rp) * (1 - 1e-9)
+    ok, o, d, refl = orc.material_sample(2, ior, 0.0, just_below, 0.5, pos, view, n)
+    assert np.allclose(d, [-view[0], view[1], 0.0], atol=1e-14) and refl == 1.0                           # the Fresnel coin at its edge
+    # from inside beyond the critical angle asin(1/1.5) = 41.8 degrees: total internal reflection whatever r0 says
+    inside = np.array([math.sin(math.radians(60)), -math.cos(math.radians(60)), 0.0])   # eye side is below the surface
+    ok, o, d, refl = orc.material_sample(2, ior, 0.0, 0.999999, 0.5, pos, inside, n)
+    assert ok and refl == 1.0 and np.allclose(d, [-inside[0], inside[1], 0.0], atol=1e-14) and np.allclose(o, pos - 1e-4 * n)
+    # from inside at normal incidence: leaves with reflectance ior^2
+    ok, o, d, refl = orc.material_sample(2, ior, 0.0, 0.5, 0.5, pos, -n, n)
+    assert np.allclose(d, n, atol=1e-15) and refl == pytest.approx(ior ** 2) and np.allclose(o, pos + 1e-4 * n)
+
+
+def test_ggx_family_closed_forms(orc):
+    """GGX / GGXRefraction at roughness 0 collapse to the mirror / to plain Refraction (material.rs:113-149, 260-269): the half
+    vector is the normal exactly (cos_theta = sqrt((1 - r1) / (1 - r1)) = 1), G = 1, so reflectance = Schlick(v.n)."""
+    n = np.array([0.0, 0.0, 1.0])
+    pos = np.zeros(3)
+    view = np.array([math.sin(0.7), 0.0, math.cos(0.7)])
+    for r0, r1 in [(0.1, 0.2), (0.83, 0.6)]:
+        ok, o, d, refl = orc.material_sample(3, 0.8, 0.0, r0, r1, pos, view, n)
+        assert ok and np.allclose(d, [-view[0], 0.0, view[2]], atol=1e-14)
+        assert refl == pytest.approx(0.8 + 0.2 * (1 - math.cos(0.7)) ** 5, rel=1e-13)
+        a = orc.material_sample(4, 1.5, 0.0, r0, r1, pos, view, n)
+        b = orc.material_sample(2, 1.5, 0.0, r0, r1, pos, view, n)
+        assert a[0] == b[0] and np.allclose(a[1], b[1], atol=1e-15) and np.allclose(a[2], b[2], atol=1e-14) and a[3] == pytest.approx(b[3], rel=1e-14)
+    # Diffuse: r1 = 0 samples the normal itself, bsdf = 1/pi; GGX bsdf below the horizon is 0
+    ok, o, d, refl = orc.material_sample(0, 0.0, 0.5, 0.37, 0.0, pos, view, n)
+    assert ok and np.allclose(d, n, atol=1e-15) and refl == 1.0
+    assert orc.material_bsdf(0, 0.0, 0.5, view, n, n) == pytest.approx(1 / math.pi)
+    assert orc.material_bsdf(3, 0.8, 0.3, view, n, np.array([0.6, 0.0, -0.8])) == 0.0
+    # GGX bsdf at the mirror configuration l = reflect: h = n, D = 1 / (pi alpha^2), G from Smith with l.n = v.n
+    alpha2 = 0.3 ** 2                                    # roughness_to_alpha2: alpha = roughness, alpha2 = roughness^2 (material.rs:250-258)
+    l = np.array([-view[0], 0.0, view[2]])
+    vn = view[2]
+    lam = 0.5 * math.sqrt(1 + alpha2 * (1 / vn ** 2 - 1)) - 0.5
+    expect = (1 / (math.pi * alpha2)) * (1 / (1 + 2 * lam)) * (0.8 + 0.2 * (1 - vn) ** 5) / (4 * vn * vn)
+    assert orc.material_bsdf(3, 0.8, 0.3, view, n, l) == pytest.approx(expect, rel=1e-12)
+
+
+def test_sphere_uv_poles_and_seam(scenes):
+    """Sphere::intersect's lat-long UVs (scene.rs:67-71): v = 1 - acos(n.y)/pi, u = 0.5 - sign(n.z) acos(n.x / |n.xz|) / 2pi."""
+    sc, o = scenes("material_examples")          # sphere 2: centre (0, 0.4, 0), r 0.4 (main.rs material_examples)
+    c, r = np.array([0.0, 0.4, 0.0]), 0.4
+    cases = [((1, 0, 0), 0.5, 0.5),            # +x: acos(1) = 0; f64::signum(+0.0) = 1
+             ((0, 0, 1), 0.25, 0.5), ((0, 0, -1), 0.75, 0.5),
+             ((-1, 0, 1e-9), 0.0, 0.5), ((-1, 0, -1e-9), 1.0, 0.5),   # the seam at -x: u jumps from 0 to 1
+             ((1, 1, 0), 0.5, 0.75), ((0, 1, 1e-6), 0.25, 1.0)]       # towards the north pole v -> 1
+    for dirn, u, v in cases:
+        nrm = np.array(dirn, dtype=np.float64)
+        nrm /= np.linalg.norm(nrm)
+        hit = o.intersect_material(c + 0.49 * nrm, -nrm)   # from inside the 0.2 gap to the neighbouring spheres
+        assert hit["hit"] and hit["element"] == 2 and hit["distance"] == pytest.approx(0.49 - r, rel=1e-10)
+        assert np.allclose(hit["normal"], nrm, atol=1e-12)
+        assert hit["u"] == pytest.approx(u, abs=2e-7) and hit["v"] == pytest.approx(v, abs=2e-6), (dirn, hit["u"], hit["v"])
+    # exactly at the pole n.xz = 0: 0/0 -> NaN u, as in the reference (the constant-colour materials of these spheres ignore it)
+    hit = o.intersect_material(c + np.array([0, 3.0, 0]), np.array([0, -1.0, 0]))
+    assert hit["hit"] and hit["v"] == 1.0 and math.isnan(hit["u"])
+    assert hit["surface"] == 1 and np.array_equal(hit["albedo"], [1, 1, 1])
+
+
+def test_textured_emitter_and_image_roughness(scenes):
+    """scene.rs:389-396: emission / roughness come from texture.sample(u, v) * tint.  rtcamp5's sphere 3 is an EMISSIVE sphere
+    textured with the earth image (tint (5,5,2)) and sphere 4 takes its roughness from the same image's red channel
+    (main.rs:252-500); the expected values are computed here from the decoded texels, texture.rs:29-49 restated in numpy."""
+    sc, o = scenes("rtcamp5")
+    e3, e4 = sc.desc.elements[3], sc.desc.elements[4]
+    assert e3.material.emission.image == 0 and e3.material.emission.color.tuple() == (5.0, 5.0, 2.0) and e4.material.roughness.image == 0
+    im = sc.image(0)
+    brightest = 0.0
+    for el, e in ((3, e3), (4, e4)):
+        c, r = np.array(e.center.tuple()), e.radius
+        for dirn in [(1, 0, 0), (0, 0, 1), (0.3, 0.5, -0.8), (-0.7, -0.1, 0.2)]:
+            nrm = np.array(dirn, dtype=np.float64)
+            nrm /= np.linalg.norm(nrm)
+            hit = o.intersect_material(c + (r + 0.02) * nrm, -nrm)    # from just outside: other objects stand close by
+            assert hit["hit"] and hit["element"] == el
+            v = 1.0 - math.acos(nrm[1]) / math.pi
+            u = 0.5 - math.copysign(1.0, nrm[2]) * math.acos(nrm[0] / math.hypot(nrm[0], nrm[2])) / (2 * math.pi)
+            assert hit["u"] == pytest.approx(u, abs=1e-9) and hit["v"] == pytest.approx(v, abs=1e-9)
+            tex = _bilinear_numpy(im, hit["u"], hit["v"])
+            if el == 3:
+                assert np.allclose(hit["emission"], tex * np.array([5.0, 5.0, 2.0]), rtol=1e-12, atol=0)
+                brightest = max(brightest, float(hit["emission"].max()))
+            else:
+                assert hit["roughness"] == pytest.approx(tex[0] * 1.0, rel=1e-12) and np.array_equal(hit["emission"], [0, 0, 0])
+    assert brightest > 0.5     # the inverted earth map is black over the oceans: at least one probe landed on a lit texel
+    # tbf3: four emitters share the image with different tints — a NEE-visible textured emitter list
+    sc2, o2 = scenes("tbf3")
+    assert o2.num_emissions() == 4
+    for el in (3, 4, 5, 6):
+        e = sc2.desc.elements[el]
+        c = np.array(e.center.tuple())
+        hit = o2.intersect_material(c + np.array([0.0, 0.0, e.radius + 0.02]), np.array([0.0, 0.0, -1.0]))
+        assert hit["hit"] and hit["element"] == el and hit["u"] == pytest.approx(0.25) and hit["v"] == pytest.approx(0.5)
+        assert np.allclose(hit["emission"], _bilinear_numpy(sc2.image(0), 0.25, 0.5) * np.array(e.material.emission.color.tuple()), rtol=1e-12)
+
+
 @pytest.mark.parametrize("x0,y0", [(200, 100), (300, 930), (936, 562), (1300, 420)])
 def test_oracle_reproduces_the_reference_binarys_committed_render(scenes, orc, x0, y0):
     """tests/golden/reference_rtcamp6_1000x4spp.png is the output of the REAL reference binary (committed in its repository,
