@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
     ap.add_argument("--trace-wgs", type=int, default=0, help="trace-kernel workgroups per CU (0 = library default)")
     ap.add_argument("--ring-policy", type=int, default=-1)
+    ap.add_argument("--quant-nodes", type=int, default=-1)
     ap.add_argument("--node-unroll", type=int, default=0)
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,6 +145,8 @@ def main():
         r.set_option("max_leaf", args.max_leaf)
     if args.bvh_builder:
         r.set_option("bvh_builder", args.bvh_builder)
+    if args.quant_nodes >= 0:
+        r.set_option("quant_nodes", args.quant_nodes)
     if args.split_ratio is not None:
         r.set_option("split_ratio", args.split_ratio)
     r.upload_scene(scene)

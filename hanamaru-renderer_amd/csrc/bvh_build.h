@@ -19,6 +19,8 @@ struct BuildPrim {
 struct BuiltBvh {
     std::vector<Node> nodes;          // 8 * num_nodes (+ 1 spare), octant-major, each octant in its own near-first preorder: box + (hit | leaf word, miss)
     uint32_t num_nodes = 0;
+    std::vector<QNode> qnodes;        // 8 * (num_nodes + 1): the same trees as 16-byte records (device_scene.h)
+    float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<uint32_t> order[3];   // per type: leaf-ordered -> caller index
     uint32_t max_depth = 0, num_leaves = 0;
     double sah_cost = 0;              // sum over nodes of area / root area (one box test each) + 1.5 x per leaf primitive

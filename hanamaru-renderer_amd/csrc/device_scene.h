@@ -42,6 +42,18 @@ HD void node_set_box(Node &n, const float *mn, const float *mx, int octant) {
 HD bool node_word_is_leaf(uint32_t a) { return (a >> 28) != 0u && a != 0xffffffffu; }
 static const uint32_t NODE_END = 0xffffffffu;
 
+// The trace kernel's node: 16 bytes, ONE load per visit.  The six planes are 16-bit coordinates on a grid over the scene's box
+// (plane = qmin + q * qstep per axis), rounded outward by at least one step — a box that only grows can add node visits, never
+// lose a hit.  The links are implicit in the layout: every octant's copy is stored in its own near-first preorder, so an inner
+// node's near child is record cur + 1 and `link` is its miss successor; a leaf's `link` is the leaf word and its successor is
+// cur + 1.  Record N of every copy is a sentinel that nothing hits and whose miss successor is NODE_END.
+struct alignas(16) QNode {
+    uint32_t xy_near;   // near.x | near.y << 16
+    uint32_t xy_far;    // far.x  | far.y  << 16
+    uint32_t z_nf;      // near.z | far.z  << 16
+    uint32_t link;      // inner: successor when the box is missed (or NODE_END); leaf: (type+1) << 28 | count << 20 | first
+};
+
 
 struct alignas(16) Tri {
     float v0[3]; float e1x;
@@ -67,6 +79,8 @@ struct CameraF {
 };
 
 struct Scene {
+    const QNode *qnodes;     // [8][num_nodes + 1], octant-major; nullptr when the tree was built in another order (device LBVH)
+    float qmin[3], qstep[3]; // the grid of the quantised planes
     const Node *nodes;       // [8][num_nodes], octant-major
     const Tri *tris;
     const f4 *spheres; const int32_t *sphere_elem;

@@ -81,6 +81,8 @@ Scene HostScene::view() const {
     Scene d;
     memset(&d, 0, sizeof d);
     d.nodes = nodes.data(); d.tris = tris.data();
+    d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
+    for (int k = 0; k < 3; k++) { d.qmin[k] = qmin[k]; d.qstep[k] = qstep[k]; }
     d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.cuboids = cuboids.data();
     d.materials = materials.data(); d.texels = texels.data(); d.images = images.data(); d.emitters = emitters.data();
     d.num_nodes = num_nodes; d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
@@ -219,6 +221,8 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         }
     }
     out.nodes = bvh.nodes; out.num_nodes = bvh.num_nodes;
+    out.qnodes = bvh.qnodes;
+    for (int k = 0; k < 3; k++) { out.qmin[k] = bvh.qmin[k]; out.qstep[k] = bvh.qstep[k]; }
     out.bvh_max_depth = bvh.max_depth; out.bvh_leaves = bvh.num_leaves; out.bvh_sah_cost = bvh.sah_cost;
 
     out.tris.assign(bvh.order[0].size(), Tri{});   // one record per reference (split triangles appear more than once)

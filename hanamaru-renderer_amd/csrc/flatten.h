@@ -13,6 +13,8 @@ namespace hr {
 
 struct HostScene {
     std::vector<Node> nodes;   // [8][num_nodes]
+    std::vector<QNode> qnodes; // [8][num_nodes + 1] (host builder only)
+    float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     uint32_t num_nodes = 0;
     std::vector<Tri> tris;
     std::vector<f4> spheres;

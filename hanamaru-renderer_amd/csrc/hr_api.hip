@@ -95,6 +95,7 @@ struct hr_ctx {
     int min_waves = 5;                       // occupancy variant of the trace kernel
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
+    bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     uint32_t ring_policy = 1;                // cache policy of the seed kernel's ring stores / fill (seed_kernels.h)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
@@ -342,7 +343,11 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.texels, &d.texels))) return r;
     c->bvh_build_ms = 0;
     if (gpu_build) { if ((r = build_bvh_on_device(c, hs))) return r; }
-    else if ((r = upload(c, hs.nodes, &d.nodes))) return r;
+    else {
+        if ((r = upload(c, hs.nodes, &d.nodes))) return r;
+        d.qnodes = nullptr;
+        if (c->quant_nodes && !hs.qnodes.empty() && (r = upload(c, hs.qnodes, &d.qnodes))) return r;
+    }
     c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
     c->have_scene = true;
     return HR_OK;
@@ -509,13 +514,14 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
-#define HR_LAUNCH_TRACE(C, W) hipLaunchKernelGGL((trace_kernel<C, W>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
+#define HR_LAUNCH_TRACE(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
+            const bool qn = c->dsc.qnodes != nullptr;
             if (c->debug_skip & 16) {
-            } else if (c->counters) HR_LAUNCH_TRACE(true, 3);
-            else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4);
-            else if (c->min_waves == 5) HR_LAUNCH_TRACE(false, 5);
-            else if (c->min_waves == 6) HR_LAUNCH_TRACE(false, 6);
-            else HR_LAUNCH_TRACE(false, 3);
+            } else if (c->counters) { if (qn) HR_LAUNCH_TRACE(true, 3, true); else HR_LAUNCH_TRACE(true, 3, false); }
+            else if (!qn) HR_LAUNCH_TRACE(false, 5, false);
+            else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4, true);
+            else if (c->min_waves == 6) HR_LAUNCH_TRACE(false, 6, true);
+            else HR_LAUNCH_TRACE(false, 5, true);
 #undef HR_LAUNCH_TRACE
         }
         HIP_TRY(hipGetLastError());
@@ -780,10 +786,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "min_waves") {
-        if (value < 3 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [3,6]");
+        if (value < 4 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [4,6]");
         c->min_waves = (int)value;
         return HR_OK;
     }
+    if (k == "quant_nodes") { c->quant_nodes = value != 0.0; return HR_OK; }
     if (k == "ring_policy") {
         if (value < 0 || value > 15) return fail(HR_ERR_INVALID, "ring_policy must be in [0,15]");
         c->ring_policy = (uint32_t)value;

@@ -62,6 +62,8 @@ typedef float f2v __attribute__((vector_size(8)));   // one packed-fp32 operand 
 struct Ray {
     V3f o, d, inv;
     uint32_t oct;     // direction octant (bit k set = component k negative)
+    // for the quantised nodes (device_scene.h QNode): distance to grid plane q = q * qinv + qc  (qinv = qstep * inv, qc = (qmin - o) * inv)
+    V3f qinv, qc;
 };
 HD void ray_set(Ray &r, V3f o, V3f d) {
     r.o = o; r.d = d;
@@ -69,6 +71,16 @@ HD void ray_set(Ray &r, V3f o, V3f d) {
     // by SIGN BIT (so that -0.0, whose reciprocal is -inf, counts as negative): the near / far planes of the per-octant
     // nodes must agree with the sign of r.inv
     r.oct = (signbit(d.x) ? 1u : 0u) | (signbit(d.y) ? 2u : 0u) | (signbit(d.z) ? 4u : 0u);
+}
+
+// A direction component of exactly zero has inv = +-inf, and q * inf + (-inf) is NaN for EVERY plane of that axis: the axis would
+// drop out of the box test altogether (still conservative, but such a ray would walk most of the tree).  Clamped to +-1e30 the
+// FMA keeps the sign of (plane - origin) down to differences of ~2e-6, far below the half step the planes are padded by.
+HD float clamp_inv(float v) { return fminf(fmaxf(v, -1e30f), 1e30f); }
+HD void ray_quantise(const Scene &sc, Ray &r) {
+    const V3f inv = v3(clamp_inv(r.inv.x), clamp_inv(r.inv.y), clamp_inv(r.inv.z));
+    r.qinv = v3(sc.qstep[0] * inv.x, sc.qstep[1] * inv.y, sc.qstep[2] * inv.z);
+    r.qc = v3((sc.qmin[0] - r.o.x) * inv.x, (sc.qmin[1] - r.o.y) * inv.y, (sc.qmin[2] - r.o.z) * inv.z);
 }
 
 struct TraceState {
@@ -119,22 +131,20 @@ HD void sphere_test(const f4 &s, const Ray &r, TraceState &ts, int32_t index, La
     float t = -b - HR_SQRT(d);
     if (t > 0.0f && t < ts.t) { ts.t = t; ts.prim = index; ts.type = 1; }
 }
-// bvh.rs:20-39: returns hit flag and the reference's `distance` (tmin if sign-positive else tmax)
-HD bool slab(const float *bmin, const float *bmax, const Ray &r, float &tmin, float &tmax) {
-    float t1 = (bmin[0] - r.o.x) * r.inv.x, t2 = (bmax[0] - r.o.x) * r.inv.x;
-    float t3 = (bmin[1] - r.o.y) * r.inv.y, t4 = (bmax[1] - r.o.y) * r.inv.y;
-    float t5 = (bmin[2] - r.o.z) * r.inv.z, t6 = (bmax[2] - r.o.z) * r.inv.z;
-    tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-    tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    return tmin <= tmax && !signbit(tmax);
-}
-// scene.rs:152-158 (hit part)
+// bvh.rs:20-39 + scene.rs:152-158 (hit part): slab test of the cuboid itself; the reference's `distance` is tmin if
+// sign-positive else tmax.  Scalars only — a small private array here gets promoted to LDS by the compiler, and a trace kernel
+// that owns even a few KiB of LDS cannot share a CU with the seed kernel, which owns all of it.  The reciprocals (bvh.rs:21-25)
+// are formed here so that the walk on the quantised nodes need not keep them.
 template <bool CNT>
 HD void cuboid_test(const f4 &mn, const f4 &mx, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
     if (CNT) cn->cuboid_tests++;
-    float tmin, tmax;
-    float bmin[3] = {mn.x, mn.y, mn.z}, bmax[3] = {mx.x, mx.y, mx.z};
-    if (!slab(bmin, bmax, r, tmin, tmax)) return;
+    const float ix = HR_RCP(r.d.x), iy = HR_RCP(r.d.y), iz = HR_RCP(r.d.z);
+    float t1 = (mn.x - r.o.x) * ix, t2 = (mx.x - r.o.x) * ix;
+    float t3 = (mn.y - r.o.y) * iy, t4 = (mx.y - r.o.y) * iy;
+    float t5 = (mn.z - r.o.z) * iz, t6 = (mx.z - r.o.z) * iz;
+    float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    if (!(tmin <= tmax && !signbit(tmax))) return;
     float dist = signbit(tmin) ? tmax : tmin;
     if (dist < ts.t) { ts.t = dist; ts.prim = index; ts.type = 2; }
 }
@@ -176,6 +186,24 @@ HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *
     const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
     if (CNT) cn->node_tests++;
     node_advance<SPEC>(ts, node_hit(nd, r, ts.t), nd.a, nd.b);
+}
+// One visit on the 16-byte nodes: a single 16-byte load; the six planes are grid coordinates, exact in fp32, and the box test is
+// six FMAs on the ray's precomputed (qinv, qc).  The grid planes lie at least one step outside the true box and the fp32 error
+// of q * qinv + qc is ~0.004 steps, so the test can only over-report hits (more visits), never lose one.  Same visits in the same order as
+// trace_node() on the 32-byte records of the same tree, plus the few extra ones the fatter boxes let through.
+template <bool CNT, bool SPEC = false>
+HD void trace_qnode(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    const QNode nd = sc.qnodes[(size_t)r.oct * (sc.num_nodes + 1u) + ts.cur];
+    if (CNT) cn->node_tests++;
+    const f2v nxy = {(float)(nd.xy_near & 0xffffu), (float)(nd.xy_near >> 16)}, fxy = {(float)(nd.xy_far & 0xffffu), (float)(nd.xy_far >> 16)};
+    const f2v zz = {(float)(nd.z_nf & 0xffffu), (float)(nd.z_nf >> 16)};
+    const f2v ixy = {r.qinv.x, r.qinv.y}, izz = {r.qinv.z, r.qinv.z}, cxy = {r.qc.x, r.qc.y}, czz = {r.qc.z, r.qc.z};
+    const f2v tn = nxy * ixy + cxy, tf = fxy * ixy + cxy, tz = zz * izz + czz;
+    const float tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
+    const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
+    const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
+    const bool leaf = node_word_is_leaf(nd.link);
+    node_advance<SPEC>(ts, hit, leaf ? nd.link : ts.cur + 1u, leaf ? ts.cur + 1u : nd.link);
 }
 template <bool CNT>
 HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
@@ -398,49 +426,57 @@ HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3
 
 // ---------------------------------------------------------------------------------------------
 // the path state machine
+// Kept small on purpose: the trace kernel holds one Path per lane for its whole life, and every register here is one the
+// shading code cannot use (the kernel is compiled for 5 waves per SIMD = 96 VGPRs).
 struct Path {
-    uint32_t q;           // path slot inside the tile batch, 0xffffffff = lane idle
+    uint32_t q;           // bits 0-5: lane of the tile (pixel, sub-sample), 6-11: sampling inside the launch's batch, 12-15: 2 * a (a = accepted
+                          // lens attempt: iteration i reads draws 2a + 2i, 2a + 2i + 1); 0xffffffff = lane idle
     uint32_t tile;        // the 4x4-pixel tile the path belongs to (a wave works on several tiles over its life)
-    uint32_t draw_base;   // lane base of this path's hand-off record inside the tile's block of records (device_scene.h rec_slot)
-    uint32_t draw0;       // 2 * a (a = accepted lens attempt): iteration i reads draws draw0 + 2 i, draw0 + 2 i + 1
-    int32_t iter;         // 1..9 (renderer.rs:174)
-    int32_t phase;        // 0 = main ray in flight, 1 = shadow ray in flight
+    uint32_t st;          // bits 0-3: iteration 1..9 (renderer.rs:174), 4: phase (0 = main ray in flight, 1 = shadow ray), 5-7: surface type of
+                          // the shaded point, 8-31: emitter the shadow ray aims at
     Ray ray;
     TraceState ts;
-    V3f accum, refl;
+    V3f accum;
+    V3f refl;             // reflectance so far; while shadow rays are in flight: refl * albedo (what one emitter's emission * bsdf * G / pdf
+                          // is multiplied by, renderer.rs:183,295) — multiplied by cur_refl afterwards (renderer.rs:197)
     // valid while a shadow ray is in flight (the bounce ray waits in next_o / next_d)
     V3f next_o, next_d;
-    V3f refl_next;        // reflectance after this iteration: refl * albedo * current_reflectance (renderer.rs:197)
-    V3f nee_scale;        // refl * albedo: what one emitter's  emission * bsdf * G / pdf  is multiplied by
-    V3f view, n; int32_t surface; float param, roughness;
+    float cur_refl;       // reflectance of the sampled bounce (PointMaterial::sample's scalar)
+    V3f view, n; float param, roughness;
     float shadow_len;     // |sample point - shadow origin|
-    int32_t emitter;
     float r0, r1;
 };
 static const uint32_t PATH_IDLE = 0xffffffffu;
+HD uint32_t path_iter(const Path &p) { return p.st & 15u; }
+HD bool path_in_shadow_phase(const Path &p) { return (p.st & 16u) != 0u; }
+HD int32_t path_surface(const Path &p) { return (int32_t)((p.st >> 5) & 7u); }
+HD uint32_t path_emitter(const Path &p) { return p.st >> 8; }
+// lane base of the path's hand-off record inside the tile's block of records (device_scene.h rec_slot)
+HD uint32_t path_draw_base(const Path &p) { return ((p.q >> 6) & 63u) * REC_ITEM_FLOATS + (p.q & 63u) * 4u; }
 
 // camera.rs:83-96 with the lens rejection loop already resolved by the seed kernel (record head: attempt a, lens x, lens y).
-// In: p.draw_base = lane base of the path's record inside `recs` (the tile's block of records).
+// In: p.q = slot of the path (bits 0-11); `recs` = the tile's block of records.
 HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const float *recs) {
     float fx = (float)px, fy = (float)(rp.height - py);
     float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
     float m = (float)(rp.width < rp.height ? rp.width : rp.height);
     float ncx = ((fx + ox) * 2.0f - (float)rp.width) * HR_RCP(m), ncy = ((fy + oy) * 2.0f - (float)rp.height) * HR_RCP(m);
     const CameraF &c = sc.cam;
-    const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(p.draw_base, REC_HEAD));
+    const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(path_draw_base(p), REC_HEAD));
     float lx = head.y * c.lens_radius, ly = head.z * c.lens_radius;
-    p.draw0 = 2u * float_as_uint(head.x);
+    p.q = (p.q & 0xfffu) | ((2u * float_as_uint(head.x)) << 12);
     V3f lens_pos = v3(c.right) * lx + v3(c.up) * ly;
     V3f dir = normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward) - lens_pos);
     ray_set(p.ray, v3(c.eye) + lens_pos, dir);
-    p.iter = 1; p.phase = 0;
+    ray_quantise(sc, p.ray);
+    p.st = 1u;            // iteration 1, main ray
     p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
     trace_begin(p.ts, T_INF);
 }
 
-// scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter p.emitter
+// scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter path_emitter(p)
 HD void nee_setup(const Scene &sc, Path &p) {
-    const Emitter em = sc.emitters[p.emitter];
+    const Emitter em = sc.emitters[path_emitter(p)];
     float unit_z = 1.0f - 2.0f * p.r1;
     float a = HR_SQRT(fmaxf(1.0f - unit_z * unit_z, 0.0f));
     float sn_, cs_;
@@ -451,17 +487,18 @@ HD void nee_setup(const Scene &sc, Path &p) {
     float sl2 = dot(sv, sv), isl = HR_RSQ(sl2);
     p.shadow_len = sl2 * isl;
     ray_set(p.ray, p.next_o, sv * isl);
+    ray_quantise(sc, p.ray);
     // a closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4),
     // so the search is limited to the sample distance + 0.03 (the reference does an unbounded closest-hit query)
     trace_begin(p.ts, p.shadow_len + 0.03f);
-    p.phase = 1;
+    p.st |= 16u;
 }
 
 // A shadow ray only contributes when its closest hit lies within 0.02 of the sample point (renderer.rs:280-282 with
 // vector.rs:89-91: |dp|^2 < 4e-4).  As soon as ANY hit is farther than that in front of the sample point the closest hit
 // is too, so the rest of the walk cannot change the outcome: stop (called after every leaf).
 HD void shadow_early_out(Path &p) {
-    if (p.phase == 1 && p.ts.t < p.shadow_len - 0.0201f) { p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0; }
+    if (path_in_shadow_phase(p) && p.ts.t < p.shadow_len - 0.0201f) { p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0; }
 }
 
 HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
@@ -473,8 +510,8 @@ template <bool CNT>
 HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *cn) {
     if (CNT) cn->rays++;
     const bool hit = p.ts.prim >= 0;
-    if (p.phase == 0) {
-        const f2v r01 = *reinterpret_cast<const f2v *>(recs + rec_slot(p.draw_base, p.draw0 + 2u * (uint32_t)p.iter));   // renderer.rs:175
+    if (!path_in_shadow_phase(p)) {
+        const f2v r01 = *reinterpret_cast<const f2v *>(recs + rec_slot(path_draw_base(p), ((p.q >> 12) & 15u) + 2u * path_iter(p)));   // renderer.rs:175
         p.r0 = r01[0]; p.r1 = r01[1];
         if (!hit) {  // scene.rs:398 + renderer.rs:196,199
             p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
@@ -485,14 +522,12 @@ HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *
         PointMat m;
         material_at(sc, s.elem, s.u, s.v, m);
         p.view = -p.ray.d;
-        float cur_refl;
-        if (!bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, cur_refl)) return true;  // renderer.rs:190-193
+        if (!bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, p.cur_refl)) return true;  // renderer.rs:190-193
         p.accum = p.accum + p.refl * m.emission;          // renderer.rs:196
-        p.refl_next = p.refl * (m.albedo * cur_refl);     // renderer.rs:197
+        p.refl = p.refl * m.albedo;                       // renderer.rs:183,295 (NEE scale) and the first factor of :197
         if (nee_available(m.surface) && sc.num_emitters > 0) {
-            p.nee_scale = p.refl * m.albedo;              // renderer.rs:183,295
-            p.n = s.n; p.surface = m.surface; p.param = m.param; p.roughness = m.roughness;
-            p.emitter = 0;
+            p.n = s.n; p.param = m.param; p.roughness = m.roughness;
+            p.st = (p.st & 15u) | ((uint32_t)m.surface << 5);   // emitter 0; the phase bit is set by nee_setup
             nee_setup(sc, p);
             return false;
         }
@@ -507,24 +542,25 @@ HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *
                 hit_surface(sc, p.ray, p.ts, true, s);
                 e = tex_sample(sc, mt.emission_img, e, s.u, s.v);
             }
-            const Emitter em = sc.emitters[p.emitter];
+            const Emitter em = sc.emitters[path_emitter(p)];
             V3f sp = p.ray.o + p.ray.d * p.shadow_len;
             V3f sn = (sp - v3(em.c)) * HR_RCP(em.r + OFFSET_F);
             float dot_0 = fabsf(dot(p.n, p.ray.d)), dot_l = fabsf(dot(sn, p.ray.d));
             float g = (dot_0 * dot_l) * HR_RCP(p.shadow_len * p.shadow_len);
             float inv_pdf = 4.0f * PI_F * em.r * em.r;
-            float w = bsdf_eval(p.surface, p.param, p.roughness, p.view, p.n, p.ray.d) * g * inv_pdf;
-            p.accum = p.accum + p.nee_scale * (e * w);
+            float w = bsdf_eval(path_surface(p), p.param, p.roughness, p.view, p.n, p.ray.d) * g * inv_pdf;
+            p.accum = p.accum + p.refl * (e * w);
         }
-        p.emitter++;
-        if ((uint32_t)p.emitter < sc.num_emitters) { nee_setup(sc, p); return false; }
-        p.phase = 0;
+        p.st += 256u;     // next emitter
+        if (path_emitter(p) < sc.num_emitters) { nee_setup(sc, p); return false; }
+        p.st &= 15u;      // back to the main ray
     }
     // renderer.rs:197-199 (a miss returned above)
-    p.refl = p.refl_next;
-    if (is_zero(p.refl) || p.iter >= 9) return true;
-    p.iter++;
+    p.refl = p.refl * p.cur_refl;
+    if (is_zero(p.refl) || path_iter(p) >= 9u) return true;
+    p.st++;
     ray_set(p.ray, p.next_o, p.next_d);
+    ray_quantise(sc, p.ray);
     trace_begin(p.ts, T_INF);
     return false;
 }

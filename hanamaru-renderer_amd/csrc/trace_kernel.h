@@ -21,7 +21,10 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 static const int TRACE_WAVES = 4;
 static const uint32_t TRACE_KCHUNK = 4;   // samplings per work unit
 
-template <bool CNT, int MINW>
+// QN: the tree is walked on the 16-byte quantised nodes (host-built trees); false: on the 32-byte fp32 records (device LBVH, whose
+// records are not in the per-octant preorder the 16-byte format relies on).  A template parameter, not a branch: each form keeps
+// only its own per-ray constants in registers.
+template <bool CNT, int MINW, bool QN>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ recs,
                                                                        float *__restrict__ accum, Counters *cnt, uint32_t *tile_counter) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -94,7 +97,6 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                     if (px < rp.width && py < rp.height) {
                         p.q = (k << 6) | j;   // slot inside the tile's batch (bits 0-5: lane of the tile -> pixel, sub-sample)
                         p.tile = cur_tile;
-                        p.draw_base = k * REC_ITEM_FLOATS + j * 4u;
                         path_start(sc, rp, p, px, py, sub, recs + (size_t)cur_tile * tile_stride);
                         npaths++;
                     }
@@ -127,8 +129,13 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 if (n_go <= walk_max) break;
                 if (CNT) { ph[2]++; ph[3] += n_go; }
                 if (go) {
-                    trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                    if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (QN) {
+                        trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
+                        if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
+                    } else {
+                        trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                        if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    }
                 }
             }
             HR_PHASE_END(2);

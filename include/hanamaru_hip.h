@@ -193,7 +193,7 @@ void *hr_total_device_ptr(hr_ctx *ctx);   /* device pointer of the all-reduced a
 
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* keys: "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase
- * thresholds), "min_waves" (3..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
+ * thresholds), "min_waves" (4..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
  * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24: how many
  * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH built on the device — replaces the reference's CPU build of

@@ -233,7 +233,7 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
                     for (uint32_t sub = 0; sub < 4; sub++) {
                         ArrRec rec;
                         Path p;
-                        p.q = 0; p.draw_base = 0;
+                        p.q = 0;
                         path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
                         path_start(sc, rp, p, x, y, sub, rec.f);
                         LaneCounters lc = {0, 0, 0, 0, 0};
@@ -274,26 +274,34 @@ int emu_render_debug(const emu_scene *e, uint32_t W, uint32_t H, int mode, float
 }
 
 // 0 = node + leaf per visit (trace_step); 1 = the trace kernel's lane schedule: walk with up to one leaf parked, stop at the
-// second (trace_node<.., SPEC>), test the parked leaves in walk order
+// second (trace_node<.., SPEC>), test the parked leaves in walk order; 2 = the same schedule on the 16-byte quantised nodes
+// (trace_qnode, host-built trees only)
 static int g_walk_mode = 0;
+static uint64_t g_node_tests = 0;
 void emu_set_walk_mode(int mode) { g_walk_mode = mode; }
+uint64_t emu_last_node_tests(void) { return g_node_tests; }
 
 int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out, int32_t *out_elem) {
     const Scene &sc = e->view;
+    g_node_tests = 0;
+    if (g_walk_mode == 2 && !sc.qnodes) return 1;
     for (uint32_t i = 0; i < n; i++) {
         Ray r;
         ray_set(r, v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
+        ray_quantise(sc, r);
         TraceState ts;
         trace_begin(ts, T_INF);
-        LaneCounters lc;
+        LaneCounters lc = {0, 0, 0, 0, 0};
         if (g_walk_mode == 0) {
-            while (ts.cur != NODE_END) trace_step<false>(sc, r, ts, &lc);
+            while (ts.cur != NODE_END) trace_step<true>(sc, r, ts, &lc);
         } else {
             while (!trace_done(ts)) {
-                while (ts.cur != NODE_END && ts.leaf2 == 0) trace_node<false, true>(sc, r, ts, &lc);
-                if (ts.leaf) { trace_leaf<false>(sc, r, ts, &lc); ts.leaf = ts.leaf2; ts.leaf2 = 0; }
+                if (g_walk_mode == 2) while (ts.cur != NODE_END && ts.leaf2 == 0) trace_qnode<true, true>(sc, r, ts, &lc);
+                else while (ts.cur != NODE_END && ts.leaf2 == 0) trace_node<true, true>(sc, r, ts, &lc);
+                if (ts.leaf) { trace_leaf<true>(sc, r, ts, &lc); ts.leaf = ts.leaf2; ts.leaf2 = 0; }
             }
         }
+        g_node_tests += lc.node_tests;
         float *o = out + (size_t)i * 8;
         int32_t elem = -1;
         if (ts.prim >= 0) {

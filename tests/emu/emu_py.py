@@ -79,8 +79,14 @@ def set_build_options(max_leaf=4, split_ratio=-1.0, builder=0):
 
 
 def set_walk_mode(mode):
-    """0 = node + leaf per visit, 1 = the trace kernel's postponed-leaf schedule (EmuScene.intersect)."""
+    """0 = node + leaf per visit, 1 = the trace kernel's postponed-leaf schedule, 2 = that schedule on the 16-byte quantised
+    nodes (EmuScene.intersect)."""
     lib().emu_set_walk_mode(mode)
+
+
+def last_node_tests():
+    lib().emu_last_node_tests.restype = C.c_uint64
+    return int(lib().emu_last_node_tests())
 
 
 def path_draws(w, h, x, y, sub, sampling, lens_shape=1):

@@ -211,3 +211,29 @@ def test_postponed_leaf_walk_gives_the_same_hits(emu, emu_scenes, name):
     finally:
         emu.set_walk_mode(0)
     assert np.array_equal(got, ref) and np.array_equal(gel, rel)
+
+
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_dodeca", "spheres", "cornell_mini", "rtcamp5", "rtcamp6_v2"])
+def test_quantised_nodes_give_the_same_hits(emu, emu_scenes, name):
+    """The trace kernel's 16-byte nodes (device_scene.h QNode): planes on a 16-bit grid, rounded outward, links implied by the
+    per-octant preorder.  Boxes that only grow can add node visits, never lose a hit: hits, t and elements are bit-identical
+    to the walk on the 32-byte fp32 records of the same tree; the fatter boxes add ~0.1 % of visits, the end-of-walk sentinel
+    record at most one per ray."""
+    sc, _, e = emu_scenes(name)
+    rays = _random_rays(sc, 6000, 41)
+    # axis-parallel and grazing rays as well: zero direction components make the grid-space FMA form produce inf - inf
+    extra = np.array([[0.1, 3.0, 0.2, 0, -1, 0], [0.1, 0.5, 6.0, 0, 0, -1], [-6.0, 0.4, 0.1, 1, 0, 0], [0.0, 1e-3, 5.0, 0, 0, -1],
+                      [0.3, 2.0, 0.3, 0.0, -0.6, -0.8], [0.3, 2.0, 0.3, 0.8, -0.6, 0.0]], dtype=np.float32)
+    rays = np.concatenate([rays, extra])
+    emu.set_walk_mode(1)
+    try:
+        ref, rel = e.intersect(rays)
+        plain = emu.last_node_tests()
+        emu.set_walk_mode(2)
+        got, gel = e.intersect(rays)
+        quant = emu.last_node_tests()
+    finally:
+        emu.set_walk_mode(0)
+    assert np.array_equal(got, ref) and np.array_equal(gel, rel)
+    print("%s: node tests plain %d, quantised %d (+%.2f %%)" % (name, plain, quant, 100.0 * (quant - plain) / plain))
+    assert plain <= quant <= 1.01 * plain + len(rays)
