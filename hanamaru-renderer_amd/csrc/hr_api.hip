@@ -207,6 +207,18 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
+    // The seed kernel owns all 160 KiB of a CU's LDS and runs next to the trace kernel of the previous batch: a trace kernel that
+    // uses ANY LDS (the compiler promotes small private arrays to LDS unless told not to, see the Makefile) could not share a CU
+    // with it — the two would silently run one after the other, 40 % slower.  Refuse to start in that state.
+    {
+        const void *trace_variants[] = {(const void *)trace_kernel<false, 5, true>, (const void *)trace_kernel<false, 5, false>, (const void *)trace_kernel<false, 4, true>,
+                                        (const void *)trace_kernel<false, 6, true>, (const void *)trace_kernel<true, 3, true>, (const void *)trace_kernel<true, 3, false>};
+        for (const void *f : trace_variants) {
+            hipFuncAttributes fa;
+            HIP_TRY(hipFuncGetAttributes(&fa, f));
+            if (fa.sharedSizeBytes != 0) return fail(HR_ERR_DEVICE, "build error: a trace kernel variant uses %zu bytes of LDS (it must use none to run beside the seed kernel)", (size_t)fa.sharedSizeBytes);
+        }
+    }
     HIP_TRY(hipMalloc((void **)&c->ovf, (size_t)c->num_cus * 2 * SEED_OVF_CAP * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&c->ovf_win, (size_t)c->num_cus * 2 * SEED_WIN_WORDS * sizeof(u64)));
     return HR_OK;

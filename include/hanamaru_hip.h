@@ -192,13 +192,16 @@ int hr_allreduce_accumulators(hr_ctx **ctxs, int n);
 void *hr_total_device_ptr(hr_ctx *ctx);   /* device pointer of the all-reduced accumulator, NULL when not valid */
 
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
-/* keys: "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase
+/* keys: "quant_nodes" (1 = the trace kernel walks the 16-byte quantised nodes of host-built trees, default; next upload),
+ * "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase
  * thresholds), "min_waves" (4..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
- * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24: how many
+ * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24 | 28: how many
  * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH built on the device — replaces the reference's CPU build of
  * bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
- * cuts the SAH cost by more than 30 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
+ * cuts the SAH cost by more than 7 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
+ * "ring_policy" (cache policy of the seed kernel's ring stores / fill), "node_unroll" (1 | 2 node visits per pass of the box phase),
+ * "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
  * "debug_skip" (bit mask that drops parts of the pipeline for timing experiments — the image is garbage) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
 

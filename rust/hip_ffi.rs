@@ -45,4 +45,11 @@ extern "C" {
     pub fn hr_accumulator_device_ptr(ctx: *mut HrCtx) -> *mut c_void;
     /// e.g. ("bvh_builder", 1.0) = build the BVH on the GPU, ("batch", 4.0) = samplings per launch; see hanamaru_hip.h
     pub fn hr_set_option(ctx: *mut HrCtx, key: *const c_char, value: f64) -> c_int;
+    // multi-GPU: one ncclAllReduce of the accumulators, issued by the library (include/hanamaru_hip.h; RCCL is dlopen'ed on first use)
+    pub fn hr_comm_get_unique_id(id_out: *mut u8 /* HR_COMM_ID_BYTES = 128 */) -> c_int;
+    pub fn hr_comm_init_rank(ctx: *mut HrCtx, id: *const u8, world_size: c_int, rank: c_int) -> c_int;
+    pub fn hr_comm_init_local(ctxs: *mut *mut HrCtx, n: c_int) -> c_int;
+    pub fn hr_allreduce_accumulator(ctx: *mut HrCtx) -> c_int;
+    pub fn hr_allreduce_accumulators(ctxs: *mut *mut HrCtx, n: c_int) -> c_int;
+    pub fn hr_comm_destroy(ctx: *mut HrCtx) -> c_int;
 }
