@@ -95,6 +95,7 @@ struct hr_ctx {
     int min_waves = 5;                       // occupancy variant of the trace kernel
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
+    uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     uint32_t ring_policy = 1;                // cache policy of the seed kernel's ring stores / fill (seed_kernels.h)
     int max_leaf = 4;                        // BVH leaf size (next upload)
@@ -484,7 +485,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.stride = stride;
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
-    rp.node_unroll = c->node_unroll; rp.ring_policy = c->ring_policy;
+    rp.node_unroll = c->node_unroll; rp.ring_policy = c->ring_policy; rp.kchunk = c->kchunk;
     rp.pad[0] = c->seed_prio;
     rp.pad[1] = c->init_prio;
     rp.pad[2] = (uint32_t)c->debug_skip;
@@ -521,7 +522,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(ev.a, c->stream));
         // persistent waves: enough workgroups to fill every CU (6 per CU covers every occupancy variant), never more
         // waves than tiles
-        const uint64_t units = (uint64_t)tiles * ((nk + TRACE_KCHUNK - 1) / TRACE_KCHUNK);   // work units of the trace kernel
+        const uint32_t kch = c->kchunk ? c->kchunk : TRACE_KCHUNK;
+        const uint64_t units = (uint64_t)tiles * ((nk + kch - 1) / kch);   // work units of the trace kernel
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
         HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
@@ -800,6 +802,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "min_waves") {
         if (value < 4 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [4,6]");
         c->min_waves = (int)value;
+        return HR_OK;
+    }
+    if (k == "kchunk") {
+        if (value < 0 || value > 64) return fail(HR_ERR_INVALID, "kchunk must be in [1,64], or 0 for the default");
+        c->kchunk = (uint32_t)value;
         return HR_OK;
     }
     if (k == "quant_nodes") { c->quant_nodes = value != 0.0; return HR_OK; }

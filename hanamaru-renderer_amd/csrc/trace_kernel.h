@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // (measured before: with one tile per wave the mean box-phase pass had 19.6 of 64 lanes active).
 // No barriers, no LDS.
 static const int TRACE_WAVES = 4;
-static const uint32_t TRACE_KCHUNK = 4;   // samplings per work unit
+static const uint32_t TRACE_KCHUNK = 4;   // samplings per work unit (default of RenderParams::kchunk)
 
 // QN: the tree is walked on the 16-byte quantised nodes (host-built trees); false: on the 32-byte fp32 records (device LBVH, whose
 // records are not in the per-octant preorder the 16-byte format relies on).  A template parameter, not a branch: each form keeps
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     unsigned long long pc[4] = {0, 0, 0, 0}, tmark = 0;   // wave-cycles per phase (counters build only)
 #define HR_PHASE_BEGIN() do { if (CNT) tmark = __builtin_readcyclecounter(); } while (0)
 #define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
-    const uint32_t nchunks = (rp.num_k + TRACE_KCHUNK - 1u) / TRACE_KCHUNK, units = tiles * nchunks;
+    const uint32_t kchunk = rp.kchunk ? rp.kchunk : TRACE_KCHUNK;
+    const uint32_t nchunks = (rp.num_k + kchunk - 1u) / kchunk, units = tiles * nchunks;
     uint32_t total = 0, cur_k0 = 0;          // wave-uniform: paths in the current unit (slot q = (k - cur_k0) * 64 + j), its first sampling
     const size_t tile_stride = (size_t)rp.num_k * REC_ITEM_FLOATS;   // floats of hand-off records per tile
     uint32_t cur_tile = 0, next = 0;          // wave-uniform: the tile of the unit being handed out and its queue head
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 if (t >= units) exhausted = true;
                 else {
                     cur_tile = t / nchunks;
-                    cur_k0 = (t - cur_tile * nchunks) * TRACE_KCHUNK;
-                    total = 64u * (rp.num_k - cur_k0 < TRACE_KCHUNK ? rp.num_k - cur_k0 : TRACE_KCHUNK);
+                    cur_k0 = (t - cur_tile * nchunks) * kchunk;
+                    total = 64u * (rp.num_k - cur_k0 < kchunk ? rp.num_k - cur_k0 : kchunk);
                     next = 0;
                 }
             }
