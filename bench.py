@@ -96,7 +96,6 @@ def main():
     ap.add_argument("--ring-policy", type=int, default=-1)
     ap.add_argument("--quant-nodes", type=int, default=-1)
     ap.add_argument("--kchunk", type=int, default=0)
-    ap.add_argument("--seed-stream", type=int, default=-1)
     ap.add_argument("--node-unroll", type=int, default=0)
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,8 +165,6 @@ def main():
         r.set_option("ring_policy", args.ring_policy)
     if args.kchunk:
         r.set_option("kchunk", args.kchunk)
-    if args.seed_stream >= 0:
-        r.set_option("seed_stream", args.seed_stream)
     if args.node_unroll:
         r.set_option("node_unroll", args.node_unroll)
     if args.seed_mode >= 0:

@@ -105,7 +105,6 @@ struct hr_ctx {
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
     int seed_mode = 1;                       // 1 = producer / consumer seed kernel, 0 = fused seed kernel
     bool seed_prof = false;                  // phase timing build of the producer / consumer seed kernel (splits 16 and 20)
-    bool seed_stream_init = false;           // init blocks >= split shared between producer (pass 1) and consumer (pass 2) through the LDS (splits 8, 12, 16)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
@@ -206,10 +205,6 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<28>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<12, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
@@ -455,12 +450,7 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     } else if (c->seed_mode == 1) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
 #define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
-#define HR_LAUNCH_PCS(HEAD, P) hipLaunchKernelGGL((seed_pc_kernel<HEAD, P, true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
-        if (c->seed_stream_init && c->seed_prof) HR_LAUNCH_PCS(12, true);
-        else if (c->seed_stream_init && c->seed_split == 8) HR_LAUNCH_PCS(8, false);
-        else if (c->seed_stream_init && c->seed_split == 16) HR_LAUNCH_PCS(16, false);
-        else if (c->seed_stream_init) HR_LAUNCH_PCS(12, false);
-        else if (c->seed_prof && c->seed_split == 20) hipLaunchKernelGGL((seed_pc_kernel<20, true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+        if (c->seed_prof && c->seed_split == 20) hipLaunchKernelGGL((seed_pc_kernel<20, true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
         else if (c->seed_prof) hipLaunchKernelGGL((seed_pc_kernel<16, true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
         else switch (c->seed_split) {
             case 8: HR_LAUNCH_PC(8); break;
@@ -857,7 +847,6 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     }
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
     if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
-    if (k == "seed_stream") { c->seed_stream_init = value != 0.0; return HR_OK; }
     if (k == "seed_mode") {
         if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "seed_mode must be 1 (producer / consumer waves, default) or 0 (fused kernel)");
         int rc = sync_all(c);

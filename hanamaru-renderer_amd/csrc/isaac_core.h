@@ -108,25 +108,6 @@ HD void isaac_init_back(Mem &mem, const u64 *st16) {
     }
 }
 
-// The same sweep cut ACROSS instead of along: the regenerated pass-1 chain (a .. h, one mix per block) does not depend on pass 2,
-// so another wave can run it one block ahead and stream its eight words per block through the rows the pass-2 results will
-// overwrite (seed_pc_kernel<.., STREAM>): isaac_pass1_block on the producer, isaac_pass2_block on the consumer.  Together they
-// are isaac_init_back: 64 - 2 SPLIT mixes, of which the consumer — the wave whose instruction stream bounds seeding — runs half.
-template <class Mem>
-HD void isaac_pass1_block(Mem &mem, int i, u64 &a, u64 &b, u64 &c, u64 &d, u64 &e, u64 &f, u64 &g, u64 &h) {
-    HR_ISAAC_MIX(a, b, c, d, e, f, g, h)
-    mem.st(i, a); mem.st(i + 1, b); mem.st(i + 2, c); mem.st(i + 3, d);
-    mem.st(i + 4, e); mem.st(i + 5, f); mem.st(i + 6, g); mem.st(i + 7, h);
-}
-template <class Mem>
-HD void isaac_pass2_block(Mem &mem, int i, u64 &A, u64 &B, u64 &C, u64 &D, u64 &E, u64 &F, u64 &G, u64 &H) {
-    A += mem.ld(i); B += mem.ld(i + 1); C += mem.ld(i + 2); D += mem.ld(i + 3);
-    E += mem.ld(i + 4); F += mem.ld(i + 5); G += mem.ld(i + 6); H += mem.ld(i + 7);
-    HR_ISAAC_MIX(A, B, C, D, E, F, G, H)
-    mem.st(i, A); mem.st(i + 1, B); mem.st(i + 2, C); mem.st(i + 3, D);
-    mem.st(i + 4, E); mem.st(i + 5, F); mem.st(i + 6, G); mem.st(i + 7, H);
-}
-
 // Mem: u64 ld(int i) / void st(int i, u64 v) / uint32_t off(int i) + u64 ldo(uint32_t) (offset of word i, load from it).  Tail: void put(int step, u64 value) for step >= 256 - TAILN (TAILN a multiple of 4, 8 .. 124).
 template <int TAILN, class Mem, class Tail>
 HD void isaac_round(Mem &mem, Tail &tail);

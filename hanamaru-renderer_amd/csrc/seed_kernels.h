@@ -220,12 +220,7 @@ struct LdsHalfMem {
 // PROF (option seed_prof): s_memtime stamps around the consumer's phases, summed per wave into Counters::seed_phase
 //   0 issue of the register loads + bookkeeping   1 wait for the 16 registers   2 isaac_init_back   3 barrier B (fill landed)
 //   4 isaac_round + record head   5 overflow note   6 barrier A (waiting for the producers / the other half)   7 groups
-// STREAM: the init blocks >= SPLIT are shared between the waves of a half (isaac_core.h isaac_pass1_block / isaac_pass2_block): the
-//   producer wave regenerates the pass-1 chain one block ahead and writes its eight words per block into the LDS rows the
-//   pass-2 results will overwrite; the consumer wave reads them and runs pass 2 only — half the mixes on the wave that bounds the
-//   kernel.  One bare s_barrier per block (the producer waits for its LDS writes first, the consumer for nothing); the producer
-//   issues its share of the fill between blocks.
-template <int SEED_SPLIT, bool PROF = false, bool STREAM = false>   // SPLIT: init blocks done by the producers at production time
+template <int SEED_SPLIT, bool PROF = false>   // SPLIT: init blocks done by the producers
 __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
                                                       uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -255,18 +250,12 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
 #define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
     typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
     u64x2_t st16v[8];   // consumer: the 16 registers of the group whose init_back comes next (fetched one round ahead)
-    // consumer: all 16 registers (pairs 0-7); STREAM: the consumer takes A .. H (pairs 4-7) into st16v[4..7], the producer a .. h
-    // (pairs 0-3) into st16v[0..3]
     auto load_regs = [&](uint64_t g) {
         const u64 *regs = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS + (size_t)SEED_SHIP_ROWS * SEED_LANES +
                           (size_t)(lane < (uint32_t)SEED_LANES ? lane : 0u) * 2u;
-        const int q0 = STREAM ? (consumer ? 4 : 0) : 0, q1 = STREAM ? (consumer ? 8 : 4) : 8;
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-            if (q >= q0 && q < q1) st16v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
+        for (int q = 0; q < 8; q++) st16v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
     };
-    constexpr int STREAM_BLOCKS = 32 - SEED_SPLIT;
-    constexpr int DMA_PER_BLOCK = STREAM ? (CHUNKS + STREAM_BLOCKS - 1) / STREAM_BLOCKS : 0;
     for (uint64_t it = 0; it <= G1 - G0; it++) {
         // ---- group G0 + it - 1 (complete in the ring since the barrier that ended the last iteration) enters the LDS:
         //      the PRODUCER wave of each half issues the fill (straight 1 KiB global_load_lds copies, no VGPR round trip; ~60
@@ -281,30 +270,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
             const uint64_t g = G0 + it - 1;
             const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
             unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
-            if (!consumer && STREAM) {
-                const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
-                if (it == 1) load_regs(g);   // later groups: fetched during the previous round
-                LdsHalfMem pm{reinterpret_cast<u64 *>(lds_half) + colr};
-                u64 a = st16v[0].x, b = st16v[0].y, c = st16v[1].x, d = st16v[1].y, e = st16v[2].x, f = st16v[2].y, g_ = st16v[3].x, h = st16v[3].y;
-                const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(src) + lane * 16u;
-                unsigned char *ldst = lds_half;
-                int q = (rp.pad[2] & 8u) ? CHUNKS : 0;
-                HR_NOUNROLL
-                for (int i = 8 * SEED_SPLIT; i < 256; i += 8) {
-                    if (lane < (uint32_t)SEED_LANES) isaac_pass1_block(pm, i, a, b, c, d, e, f, g_, h);
-#pragma unroll
-                    for (int k = 0; k < DMA_PER_BLOCK; k++) {   // this block's share of the fill (generator words 0 .. 8*SPLIT - 1)
-                        if (q < CHUNKS) {
-                            const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
-                            void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
-                            __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
-                            gsrc += 1024; ldst += 1024; q++;
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block i / 8 of pass 1 is in the LDS
-                }
-                __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the fill has landed
-            } else if (!consumer) {
+            if (!consumer) {
                 if (!(rp.pad[2] & 8u)) {
                     // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
                     // address pair serves two 1 KiB copies
@@ -337,24 +303,17 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
                 m.col = reinterpret_cast<u64 *>(lds_half) + colr;
                 HR_STAMP(0);
                 if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
-                if (STREAM) {
-                    u64 A = st16v[4].x, B = st16v[4].y, C = st16v[5].x, D = st16v[5].y, E = st16v[6].x, F = st16v[6].y, G = st16v[7].x, H = st16v[7].y;
-                    HR_NOUNROLL
-                    for (int i = 8 * SEED_SPLIT; i < 256; i += 8) {
-                        asm volatile("s_barrier" ::: "memory");   // the producer wave has written pass-1 block i / 8 into rows i .. i + 7
-                        if (lane < (uint32_t)SEED_LANES) isaac_pass2_block(m, i, A, B, C, D, E, F, G, H);
-                    }
-                } else {
-                    u64 st16[16];
+                u64 st16[16];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { st16[2 * q] = st16v[q].x; st16[2 * q + 1] = st16v[q].y; }
-                    if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);
-                }
+                for (int q = 0; q < 8; q++) { st16[2 * q] = st16v[q].x; st16[2 * q + 1] = st16v[q].y; }
+                if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);
                 HR_STAMP(2);
             }
             __syncthreads();   // B
-            if (consumer) HR_STAMP(3);
-            if ((consumer || STREAM) && it < G1 - G0) load_regs(G0 + it);   // group G0 + it has been complete since barrier A; used after this round
+            if (consumer) {
+                HR_STAMP(3);
+                if (it < G1 - G0) load_regs(G0 + it);   // group G0 + it has been complete since barrier A; used after this round
+            }
         }
         // ---- producers: complete group G0 + it + 1 in the ring (one group of slack: see load_regs above)
         const uint64_t need = (G0 + it + 2) * SEED_COLS;      // paths below `need` (clipped to this workgroup's range) must be in the ring

@@ -88,27 +88,6 @@ static void raw_draws_pc(u64 s, u64 t, uint32_t sampling, int window, uint64_t *
     isaac_round<ISAAC_TAIL>(mem, rt);
 }
 
-// the streamed form of the same split: pass-1 blocks >= HEAD written into the rows the pass-2 results then overwrite
-// (isaac_pass1_block on the producer wave, isaac_pass2_block on the consumer wave of seed_pc_kernel<.., STREAM>)
-template <int HEAD>
-static void raw_draws_stream(u64 s, u64 t, uint32_t sampling, int window, uint64_t *out) {
-    static const IsaacWarm warm = isaac_warm();
-    TailSink sink;
-    for (int i = 0; i < 256; i++) sink.m[i] = 0xdeadbeefdeadbeefULL;
-    isaac_init_front<HEAD>(sink, warm, 8700304ULL, (u64)sampling, s, t);
-    ArrMem mem;
-    for (int i = 0; i < 256; i++) mem.st(i, sink.m[i]);
-    u64 *e = sink.end;
-    u64 a = e[0], b = e[1], c = e[2], d = e[3], ee = e[4], f = e[5], g = e[6], h = e[7];
-    u64 A = e[8], B = e[9], C = e[10], D = e[11], E = e[12], F = e[13], G = e[14], H = e[15];
-    for (int i = 8 * HEAD; i < 256; i += 8) {
-        isaac_pass1_block(mem, i, a, b, c, d, ee, f, g, h);
-        isaac_pass2_block(mem, i, A, B, C, D, E, F, G, H);
-    }
-    RawTailPc rt{out, window};
-    isaac_round<ISAAC_TAIL>(mem, rt);
-}
-
 extern "C" {
 
 static int g_max_leaf = 4;
@@ -220,18 +199,6 @@ int emu_raw_draws_split(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     RawTail rt{out, window};
     isaac_round<ISAAC_TAIL>(mem, rt);
     return 0;
-}
-
-int emu_raw_draws_stream(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int window, int head, uint64_t *out) {
-    u64 s, t;
-    path_seed_words(W, H, px, py, sub, s, t);
-    switch (head) {
-        case 0: raw_draws_stream<0>(s, t, sampling, window, out); return 0;
-        case 8: raw_draws_stream<8>(s, t, sampling, window, out); return 0;
-        case 12: raw_draws_stream<12>(s, t, sampling, window, out); return 0;
-        case 16: raw_draws_stream<16>(s, t, sampling, window, out); return 0;
-        default: return 1;
-    }
 }
 
 int emu_raw_draws_pc(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int window, int head, uint64_t *out) {

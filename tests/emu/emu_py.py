@@ -23,7 +23,6 @@ def lib():
         L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws_split.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws_pc.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.c_void_p]
-        L.emu_raw_draws_stream.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -99,13 +98,6 @@ def path_draws(w, h, x, y, sub, sampling, lens_shape=1):
 def raw_draws(w, h, x, y, sub, sampling, window=64):
     out = np.empty(window, dtype=np.uint64)
     lib().emu_raw_draws(w, h, x, y, sub, sampling, window, out.ctypes.data)
-    return out
-
-
-def raw_draws_stream(w, h, x, y, sub, sampling, head, window=64):
-    out = np.empty(window, dtype=np.uint64)
-    rc = lib().emu_raw_draws_stream(w, h, x, y, sub, sampling, window, head, out.ctypes.data)
-    assert rc == 0
     return out
 
 

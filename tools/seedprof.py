@@ -7,14 +7,12 @@ sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
 import hanamaru_amd as ha
 
 split = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-stream = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 names = ["issue reg loads", "wait 16 regs", "init_back", "barrier B (fill)", "round+head", "ovf note", "barrier A", "groups"]
 sc = ha.Scene("rtcamp6_v3_1")
 r = ha.Renderer(0)
 r.upload_scene(sc)
 r.set_resolution(1920, 1080)
 r.set_option("seed_split", split)
-r.set_option("seed_stream", stream)
 for label, skip in (("seed kernel alone", 16), ("next to the trace kernel", 0)):
     r.set_option("seed_prof", 0)
     r.set_option("debug_skip", 0)
@@ -29,7 +27,6 @@ for label, skip in (("seed kernel alone", 16), ("next to the trace kernel", 0)):
     ph = st["seed_phase_cycles"]
     groups = max(1, ph[7])
     ms = st["seed_kernel_ms"] / max(1, st["seed_launches"])
-    print("stream %d " % stream, end="")
     print("split %d, %s: seed kernel %.2f ms per launch, %d consumer-wave groups" % (split, label, ms, groups))
     tot = sum(ph[:7])
     for n, v in zip(names[:7], ph[:7]):
