@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--leaf-den", type=int, default=0)
     ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--max-leaf", type=int, default=0)
-    ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH")
+    ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH, 2 = device PLOC")
     ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--seed-prio", type=int, default=-1)

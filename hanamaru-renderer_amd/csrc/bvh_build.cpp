@@ -208,26 +208,11 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
     // end keeps that paired fetch in bounds.
     out.nodes.assign(8 * N + 1, Node{});
     out.qnodes.assign(8 * (N + 1), QNode{});
-    // grid of the 16-bit planes: the root box, a little enlarged, in 65,533 steps (coordinates 1 .. 65,534 before the outward step)
-    double gmin[3], gstep[3];
-    for (int a = 0; a < 3; a++) {
-        double ext = std::max(b.nodes[0].box.mx[a] - b.nodes[0].box.mn[a], 1e-6);
-        gmin[a] = b.nodes[0].box.mn[a] - 1e-6 * ext;
-        gstep[a] = ext * (1.0 + 2e-6) / 65532.0;
-        out.qmin[a] = (float)gmin[a] - std::fabs((float)gmin[a]) * 1e-6f;     // the fp32 frame may only sit lower / be coarser
-        out.qstep[a] = (float)gstep[a] * (1.0f + 1e-6f);
+    {   // grid of the 16-bit planes (device_scene.h) over the root's padded fp32 box
+        float rmn[3], rmx[3];
+        for (int a = 0; a < 3; a++) { rmn[a] = round_down(b.nodes[0].box.mn[a], 2); rmx[a] = round_up(b.nodes[0].box.mx[a], 2); }
+        qframe_from_box(rmn, rmx, out.qmin, out.qstep);
     }
-    // Outward rounding with a margin for the kernel's fp32 arithmetic: distance = q * (qstep * inv) + (qmin - o) * inv carries
-    // three roundings of ~6e-8 relative on values up to 65,535 steps — 0.004 step each; 0.05 step covers them with room.
-    const double QMARGIN = 0.05;
-    auto qlow = [&](double v, int a) -> uint32_t {   // largest grid coordinate whose plane is safely <= v
-        double q = std::floor((v - (double)out.qmin[a]) / (double)out.qstep[a] - QMARGIN);
-        return (uint32_t)std::min(std::max(q, 0.0), 65535.0);
-    };
-    auto qhigh = [&](double v, int a) -> uint32_t {  // smallest grid coordinate whose plane is safely >= v
-        double q = std::ceil((v - (double)out.qmin[a]) / (double)out.qstep[a] + QMARGIN);
-        return (uint32_t)std::min(std::max(q, 0.0), 65535.0);
-    };
     std::vector<uint32_t> newid(N);
     for (int o = 0; o < 8; o++) {
         Node *nd = &out.nodes[(size_t)o * N];
@@ -258,17 +243,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
             for (int a = 0; a < 3; a++) { mn[a] = round_down(bn.box.mn[a], 2); mx[a] = round_up(bn.box.mx[a], 2); }
             node_set_box(n, mn, mx, o);
             n.b = after;
-            {
-                QNode &q = out.qnodes[(size_t)o * (N + 1) + newid[id]];
-                uint32_t lo[3], hi[3];
-                for (int a = 0; a < 3; a++) { lo[a] = qlow(bn.box.mn[a], a); hi[a] = qhigh(bn.box.mx[a], a); }
-                auto nearq = [&](int a) { return ((o >> a) & 1) ? hi[a] : lo[a]; };
-                auto farq = [&](int a) { return ((o >> a) & 1) ? lo[a] : hi[a]; };
-                q.xy_near = nearq(0) | (nearq(1) << 16);
-                q.xy_far = farq(0) | (farq(1) << 16);
-                q.z_nf = nearq(2) | (farq(2) << 16);
-                q.link = bn.left < 0 ? leaf_word[id] : after;
-            }
+            out.qnodes[(size_t)o * (N + 1) + newid[id]] = qnode_make(mn, mx, o, out.qmin, out.qstep, bn.left < 0 ? leaf_word[id] : after);
             if (bn.left < 0) { n.a = leaf_word[id]; continue; }
             bool neg = (o >> bn.axis) & 1;
             int nearc = neg ? bn.right : bn.left, farc = neg ? bn.left : bn.right;
@@ -277,15 +252,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
             st2.emplace_back(farc, after);
         }
     }
-    for (int o = 0; o < 8; o++) {   // sentinel behind every copy: near > far on every axis, nothing hits it; its miss successor ends the walk
-        QNode &q = out.qnodes[(size_t)o * (N + 1) + N];
-        auto nearq = [&](int a) -> uint32_t { return ((o >> a) & 1) ? 0u : 65535u; };   // entered at the far end: entry distance > exit distance
-        auto farq = [&](int a) -> uint32_t { return ((o >> a) & 1) ? 65535u : 0u; };
-        q.xy_near = nearq(0) | (nearq(1) << 16);
-        q.xy_far = farq(0) | (farq(1) << 16);
-        q.z_nf = nearq(2) | (farq(2) << 16);
-        q.link = NODE_END;
-    }
+    for (int o = 0; o < 8; o++) out.qnodes[(size_t)o * (N + 1) + N] = qnode_sentinel(o);   // sentinel behind every copy
     {
         Node &pad = out.nodes[8 * N];
         const float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};

@@ -12,6 +12,7 @@
 // "Algorithmic bytes"  are counted as 32 B per node test, 36 B per triangle test,
 // 16 B per sphere test, 24 B per cuboid test — the information content, not the padded layout.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -53,6 +54,53 @@ struct alignas(16) QNode {
     uint32_t z_nf;      // near.z | far.z  << 16
     uint32_t link;      // inner: successor when the box is missed (or NODE_END); leaf: (type+1) << 28 | count << 20 | first
 };
+// grid of the 16-bit planes: the root box, a little enlarged, in 65,532 steps.  Outward rounding leaves a margin for the kernel's
+// fp32 arithmetic: distance = q * (qstep * inv) + (qmin - o) * inv carries three roundings of ~6e-8 relative on values up to
+// 65,535 steps — 0.004 step each; QMARGIN = 0.05 step covers them with room.
+HD void qframe_from_box(const float *root_mn, const float *root_mx, float *qmin, float *qstep) {
+    for (int a = 0; a < 3; a++) {
+        double ext = (double)root_mx[a] - (double)root_mn[a];
+        if (!(ext > 1e-6)) ext = 1e-6;
+        double gmin = (double)root_mn[a] - 1e-6 * ext;
+        float fmin_ = (float)gmin;
+        fmin_ -= (fmin_ < 0 ? -fmin_ : fmin_) * 1e-6f + 1e-30f;         // the fp32 frame may only sit lower / be coarser
+        qmin[a] = fmin_;
+        qstep[a] = (float)(ext * (1.0 + 4e-6) / 65532.0) * (1.0f + 1e-6f);
+    }
+}
+HD uint32_t q_low(float v, float qmin, float qstep) {    // largest grid coordinate whose plane is safely <= v
+    double q = floor(((double)v - (double)qmin) / (double)qstep - 0.05);
+    return (uint32_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q));
+}
+HD uint32_t q_high(float v, float qmin, float qstep) {   // smallest grid coordinate whose plane is safely >= v
+    double q = ceil(((double)v - (double)qmin) / (double)qstep + 0.05);
+    return (uint32_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q));
+}
+HD QNode qnode_make(const float *mn, const float *mx, int octant, const float *qmin, const float *qstep, uint32_t link) {
+    uint32_t nearq[3], farq[3];
+    for (int a = 0; a < 3; a++) {
+        uint32_t lo = q_low(mn[a], qmin[a], qstep[a]), hi = q_high(mx[a], qmin[a], qstep[a]);
+        nearq[a] = ((octant >> a) & 1) ? hi : lo;
+        farq[a] = ((octant >> a) & 1) ? lo : hi;
+    }
+    QNode q;
+    q.xy_near = nearq[0] | (nearq[1] << 16);
+    q.xy_far = farq[0] | (farq[1] << 16);
+    q.z_nf = nearq[2] | (farq[2] << 16);
+    q.link = link;
+    return q;
+}
+// record N of every octant's copy: entered at the far end on every axis (entry distance > exit distance), its miss successor ends the walk
+HD QNode qnode_sentinel(int octant) {
+    QNode q;
+    uint32_t nearq[3], farq[3];
+    for (int a = 0; a < 3; a++) { nearq[a] = ((octant >> a) & 1) ? 0u : 65535u; farq[a] = ((octant >> a) & 1) ? 65535u : 0u; }
+    q.xy_near = nearq[0] | (nearq[1] << 16);
+    q.xy_far = farq[0] | (farq[1] << 16);
+    q.z_nf = nearq[2] | (farq[2] << 16);
+    q.link = NODE_END;
+    return q;
+}
 
 
 struct alignas(16) Tri {

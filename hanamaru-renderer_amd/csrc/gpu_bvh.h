@@ -1,4 +1,7 @@
 // GPU BVH build: kernels around csrc/lbvh_core.h + the hipCUB radix sort.  Included by hr_api.hip.
+//   keys -> radix sort -> leaf boxes -> hierarchy (LBVH: one thread per internal node | PLOC: one workgroup iterating
+//   nearest-neighbour search / merge / compaction) -> bottom-up fit -> finish (leaf words, primitive order) -> frame of the
+//   quantised planes -> emit (both record formats, per-octant preorder) -> gather the primitives into leaf order
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -12,16 +15,76 @@ __global__ void key_kernel(Prims p, int n, mkey_t *keys) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = prim_key(p, (uint32_t)i);
 }
+__global__ void leaf_kernel(Prims p, const mkey_t *keys, int n, Work w) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) fit_leaf(p, keys, n, k, w);
+}
 __global__ void hierarchy_kernel(const mkey_t *keys, int n, Work w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n - 1) hierarchy_node(keys, n, i, w);
 }
+
+// PLOC: ONE workgroup runs all iterations (the scenes of this path have 10^4 - 10^5 primitives: an iteration is m x 16 box unions,
+// there are ~40 of them, and nothing has to leave the CU or return to the host in between).  Every thread owns a contiguous chunk
+// of the cluster array: nearest neighbours, then roles counted and scanned across the workgroup, then merge + compaction in order.
+static const int PLOC_THREADS = 1024;
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[16]*/, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off);
+        if (lane >= (uint32_t)off) x += y;
+    }
+    if (lane == 63u) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+    for (uint32_t k = 0; k < PLOC_THREADS / 64; k++) { if (k < wave) base += s_wave[k]; sum += s_wave[k]; }
+    __syncthreads();
+    total = sum;
+    return base + x - v;
+}
+__global__ __launch_bounds__(PLOC_THREADS) void ploc_kernel(int n, Work w, uint32_t *cl_a, uint32_t *cl_b, uint32_t *nn) {
+    __shared__ uint32_t s_wave[PLOC_THREADS / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t k = tid; k < (uint32_t)n; k += PLOC_THREADS) cl_a[k] = (uint32_t)(n - 1) + k;
+    __syncthreads();
+    uint32_t *cur = cl_a, *nxt = cl_b;
+    uint32_t m = (uint32_t)n, next_node = (uint32_t)(n - 1);   // internal ids are handed out downwards: the last merge makes node 0, the root
+    while (m > 1u) {
+        const uint32_t chunk = (m + PLOC_THREADS - 1u) / PLOC_THREADS;
+        const uint32_t c0 = tid * chunk < m ? tid * chunk : m, c1 = c0 + chunk < m ? c0 + chunk : m;
+        for (uint32_t i = c0; i < c1; i++) nn[i] = ploc_nearest(w, cur, m, i);
+        __syncthreads();
+        uint32_t keep = 0, made = 0;
+        for (uint32_t i = c0; i < c1; i++) {
+            int role = ploc_role(nn, i);
+            keep += role != 2;
+            made += role == 1;
+        }
+        uint32_t total_keep, total_made;
+        uint32_t pos = block_exclusive_scan(keep, s_wave, total_keep);
+        uint32_t mrank = block_exclusive_scan(made, s_wave, total_made);
+        for (uint32_t i = c0; i < c1; i++) {
+            int role = ploc_role(nn, i);
+            if (role == 2) continue;
+            if (role == 1) {
+                uint32_t id = next_node - 1u - mrank++;
+                ploc_make_node(w, id, cur[i], cur[nn[i]]);
+                nxt[pos++] = id;
+            } else nxt[pos++] = cur[i];
+        }
+        __syncthreads();
+        m = total_keep;
+        next_node -= total_made;
+        uint32_t *t = cur; cur = nxt; nxt = t;
+    }
+    if (tid == 0) w.parent[0] = NODE_END;
+}
+
 // one thread per leaf walks up; the second arrival at a node fits it (its two subtrees are then complete)
-__global__ void fit_kernel(Prims p, const mkey_t *keys, int n, uint32_t max_leaf, Work w) {
+__global__ void fit_kernel(int n, uint32_t max_leaf, Work w) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    fit_leaf(p, keys, n, k, w);
-    if (n == 1) return;
+    if (k >= n || n == 1) return;
     uint32_t cur = w.parent[n - 1 + k];
     while (cur != NODE_END) {
         __threadfence();
@@ -31,24 +94,43 @@ __global__ void fit_kernel(Prims p, const mkey_t *keys, int n, uint32_t max_leaf
         cur = w.parent[cur];
     }
 }
-__global__ void emit_kernel(int n, Work w, Node *nodes) {
+__global__ void finish_kernel(Prims p, int n, Work w, uint32_t *prim_pos) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n - 1) finish_node(p, n, (uint32_t)i, w, prim_pos);
+}
+// frame[0..2] = qmin, frame[3..5] = qstep, ((uint32_t *)frame)[6] = records per octant
+__global__ void frame_kernel(Work w, float *frame) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float rmn[3], rmx[3];
+        for (int a = 0; a < 3; a++) { rmn[a] = pad_down(w.bmin[a]); rmx[a] = pad_up(w.bmax[a]); }
+        qframe_from_box(rmn, rmx, frame, frame + 3);
+        reinterpret_cast<uint32_t *>(frame)[6] = w.size[0];
+    }
+}
+__global__ void emit_kernel(int n, Work w, const float *frame, Node *nodes, QNode *qnodes) {
     int N = 2 * n - 1;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * 8) return;
     int o = idx / N, i = idx - o * N;
-    nodes[idx] = emit_node(n, i, o, w);
+    emit_node((uint32_t)i, o, w, frame, frame + 3, nodes, qnodes);
+    if (i == 0) {
+        const uint32_t total = w.size[0];
+        qnodes[(size_t)o * (total + 1u) + total] = qnode_sentinel(o);
+    }
 }
-// primitive arrays -> sorted (leaf) order per type
-__global__ void gather_kernel(Prims p, const mkey_t *keys, int n, Tri *tris, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *cuboids) {
+// primitive arrays -> leaf order per type (left-first depth-first order of the tree)
+__global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_pos, int n, Tri *tris, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *cuboids) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    uint32_t i = key_index(keys[k]);
-    if (i < p.num_tris) tris[k] = p.tris[i];
+    uint32_t i = key_index(keys[k]), d = prim_pos[k];
+    if (i < p.num_tris) tris[d] = p.tris[i];
     else if (i < p.num_tris + p.num_spheres) {
-        uint32_t l = i - p.num_tris, d = (uint32_t)k - p.num_tris;
+        uint32_t l = i - p.num_tris;
+        d -= p.num_tris;
         spheres[d] = p.spheres[l]; sphere_elem[d] = sphere_elem_in[l];
     } else {
-        uint32_t l = i - p.num_tris - p.num_spheres, d = (uint32_t)k - p.num_tris - p.num_spheres;
+        uint32_t l = i - p.num_tris - p.num_spheres;
+        d -= p.num_tris + p.num_spheres;
         cuboids[2 * d] = p.cuboids[2 * l]; cuboids[2 * d + 1] = p.cuboids[2 * l + 1];
     }
 }

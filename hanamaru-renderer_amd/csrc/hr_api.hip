@@ -6,7 +6,7 @@
 //                    refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed kernel of the NEXT
 //                    batch (own stream) — plus intersect_debug_kernel and debug_render_kernel (renderer.rs:101-146)
 //   post_kernels.h   tonemap_gamma_kernel, bilateral_quantise_kernel
-//   gpu_bvh.h        the device LBVH builder's kernels (option bvh_builder = 1)
+//   gpu_bvh.h        the device BVH builders' kernels (option bvh_builder = 1 LBVH, 2 PLOC)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -100,7 +100,7 @@ struct hr_ctx {
     uint32_t ring_policy = 1;                // cache policy of the seed kernel's ring stores / fill (seed_kernels.h)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
-    int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH (gpu_bvh.h); next upload
+    int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH, 2 = device PLOC (gpu_bvh.h); next upload
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
     int seed_mode = 1;                       // 1 = producer / consumer seed kernel, 0 = fused seed kernel
@@ -284,12 +284,17 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     LBVH_ALLOC(keys, mkey_t, n, false)
     Work w{};
     LBVH_ALLOC(parent, uint32_t, N, false) LBVH_ALLOC(left, uint32_t, n, false) LBVH_ALLOC(right, uint32_t, n, false)
-    LBVH_ALLOC(first, uint32_t, n, false) LBVH_ALLOC(last, uint32_t, n, false) LBVH_ALLOC(flags, uint32_t, n, false)
+    LBVH_ALLOC(flags, uint32_t, n, false)
     LBVH_ALLOC(bmin, float, 3 * (size_t)N, false) LBVH_ALLOC(bmax, float, 3 * (size_t)N, false)
+    LBVH_ALLOC(info, uint32_t, N, false) LBVH_ALLOC(tc, u64t, N, false) LBVH_ALLOC(size, uint32_t, N, false)
     LBVH_ALLOC(word, uint32_t, N, false) LBVH_ALLOC(axis_low, uint32_t, n, false)
-    w.parent = parent; w.left = left; w.right = right; w.first = first; w.last = last; w.flags = flags;
-    w.bmin = bmin; w.bmax = bmax; w.word = word; w.axis_low = axis_low;
-    LBVH_ALLOC(nodes, Node, 8 * (size_t)N + 1, true)   // + 1: the trace kernel fetches a record together with the one behind it
+    LBVH_ALLOC(prim_pos, uint32_t, n, false) LBVH_ALLOC(cl_a, uint32_t, n, false) LBVH_ALLOC(cl_b, uint32_t, n, false) LBVH_ALLOC(nn, uint32_t, n, false)
+    LBVH_ALLOC(frame, float, 8, false)
+    w.parent = parent; w.left = left; w.right = right; w.flags = flags;
+    w.bmin = bmin; w.bmax = bmax; w.info = info; w.tc = tc; w.size = size; w.axis_low = axis_low; w.word = word;
+    // the emitted tree has size[root] <= 2n-1 records per octant (collapsed subtrees are one record): sized for the worst case
+    LBVH_ALLOC(nodes, Node, 8 * (size_t)N + 1, true)
+    LBVH_ALLOC(qnodes, QNode, 8 * ((size_t)N + 1), true)
     LBVH_ALLOC(tris, Tri, d.num_tris, true)
     LBVH_ALLOC(spheres, f4, d.num_spheres, true)
     LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
@@ -311,21 +316,33 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
         e = hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys_in, keys, n, 0, 64, st);
     }
     if (e == hipSuccess) {
-        if (n > 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
-        fit_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, (uint32_t)c->max_leaf, w);
-        emit_kernel<<<(8 * N + T - 1) / T, T, 0, st>>>(n, w, nodes);
-        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, tris, spheres, sphere_elem, d.sphere_elem, cuboids);
+        leaf_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, w);
+        if (n > 1 && c->bvh_builder == 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
+        if (n > 1 && c->bvh_builder == 2) ploc_kernel<<<1, PLOC_THREADS, 0, st>>>(n, w, cl_a, cl_b, nn);
+        fit_kernel<<<(n + T - 1) / T, T, 0, st>>>(n, (uint32_t)c->max_leaf, w);
+        finish_kernel<<<(N + T - 1) / T, T, 0, st>>>(p, n, w, prim_pos);
+        frame_kernel<<<1, 64, 0, st>>>(w, frame);
+        emit_kernel<<<(8 * N + T - 1) / T, T, 0, st>>>(n, w, frame, nodes, qnodes);
+        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, spheres, sphere_elem, d.sphere_elem, cuboids);
         e = hipGetLastError();
     }
     (void)hipEventRecord(eb, st);
+    float hframe[8] = {0, 0, 0, 1, 1, 1, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(hframe, frame, sizeof hframe, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     float ms = 0;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ea, eb);
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     cleanup();
     if (e != hipSuccess) return fail(HR_ERR_DEVICE, "device BVH build: %s", hipGetErrorString(e));
+    uint32_t total = 0;
+    memcpy(&total, &hframe[6], sizeof total);
+    if (total == 0 || total > (uint32_t)N) return fail(HR_ERR_DEVICE, "device BVH build: implausible record count %u for %d primitives", total, n);
     c->bvh_build_ms = ms;
-    d.nodes = nodes; d.num_nodes = (uint32_t)N;
+    d.nodes = nodes; d.num_nodes = total;
+    d.qnodes = c->quant_nodes ? qnodes : nullptr;
+    for (int a = 0; a < 3; a++) { d.qmin[a] = hframe[a]; d.qstep[a] = hframe[3 + a]; }
+
     d.tris = tris; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
     return HR_OK;
 }
@@ -340,7 +357,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
 
     HostScene hs;
     std::string ferr;
-    const bool gpu_build = c->bvh_builder == 1;
+    const bool gpu_build = c->bvh_builder != 0;
     rc = flatten_scene(sd, hs, ferr, c->max_leaf, gpu_build ? 0.0 : c->split_ratio, !gpu_build);
     if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());
     Scene &d = c->dsc;
@@ -860,7 +877,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "bvh_builder") {  // 0 = host binned SAH, 1 = device LBVH; takes effect at the next hr_upload_scene
-        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "bvh_builder must be 0 (host SAH) or 1 (device LBVH)");
+        if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "bvh_builder must be 0 (host SAH), 1 (device LBVH) or 2 (device PLOC)");
         c->bvh_builder = (int)value;
         return HR_OK;
     }

@@ -1,11 +1,18 @@
-// LBVH build, per-thread bodies (BVH construction on the GPU).  Karras 2012: Morton keys of the
-// primitive centroids -> radix sort -> one thread per internal node for the hierarchy -> bottom-up box fit with
-// arrival counters; subtrees of <= max_leaf same-type primitives collapse into leaves; the result is emitted in the
-// trace kernel's format (device_scene.h): nodes[8][2n-1] with per-octant hit / miss successors, root at index 0.
+// BVH build on the GPU, per-thread bodies.  Two ways to get the hierarchy over the Morton-sorted
+// primitives, one way to finish it:
+//   builder 1  LBVH   (Karras 2012): one thread per internal node derives its children from the sorted keys alone
+//   builder 2  PLOC   (Meister & Bittner 2018): parallel locally-ordered clustering — every cluster looks for its nearest
+//              neighbour (smallest surface area of the union) within +-PLOC_RADIUS positions of the Morton order, mutual pairs
+//              merge, the array is compacted, until one cluster is left.  An agglomerative build: near-SAH quality.
+//   finish     bottom-up fit (boxes, primitive counts per type, collapse of <= max_leaf same-type primitives into leaves, emitted
+//              sizes, near / far axis), then every node finds its own place by walking up to the root: the per-type rank of a
+//              leaf's first primitive (primitives end up in left-first depth-first order), and — per ray-direction octant — its
+//              index in that octant's near-first preorder.  The tree is emitted in both of the trace kernel's formats
+//              (device_scene.h): 32-byte fp32 records with explicit links and 16-byte quantised records with implicit ones.
 //
-// The reference builds its trees on the CPU with a full sort per level (bvh.rs:107-211).  Closest-hit results do not
-// depend on the tree, so this builder is interchangeable with the host SAH builder (bvh_build.cpp).  HD functions:
-// csrc/gpu_bvh.h wraps them in kernels, tests/emu runs them sequentially on the host.
+// The reference builds its trees on the CPU with a full sort per level (bvh.rs:107-211).  Closest-hit results do not depend on
+// the tree, so these builders are interchangeable with the host SAH builder (bvh_build.cpp).  HD functions: csrc/gpu_bvh.h wraps
+// them in kernels, tests/emu runs them sequentially on the host.
 #pragma once
 #include <math.h>
 
@@ -23,8 +30,10 @@ namespace hr {
 namespace lbvh {
 
 typedef unsigned long long mkey_t;
+typedef unsigned long long u64t;
 static const int KEY_INDEX_BITS = 20;   // flatten_scene admits < 2^20 primitives
 static const int KEY_AXIS_BITS = 14;    // 42-bit Morton code
+static const int PLOC_RADIUS = 8;       // nearest-neighbour search window: +-8 positions
 
 struct Prims {   // input order: triangles, then spheres, then cuboids
     const Tri *tris; uint32_t num_tris;
@@ -34,15 +43,23 @@ struct Prims {   // input order: triangles, then spheres, then cuboids
 };
 HD uint32_t type_offset(const Prims &p, uint32_t type) { return type == 0 ? 0u : type == 1 ? p.num_tris : p.num_tris + p.num_spheres; }
 
-struct Work {          // 2n-1 nodes: internal [0, n-1), leaf k at n-1+k (k = position in sorted order)
+// 2n-1 nodes: internal [0, n-1) with the root at 0, leaf k at n-1+k (k = position in sorted order)
+struct Work {
     uint32_t *parent;             // per node
     uint32_t *left, *right;       // per internal node (node indices)
-    uint32_t *first, *last;       // per internal node: covered sorted range
-    uint32_t *flags;              // per internal node: arrival counter (zeroed)
+    uint32_t *flags;              // per internal node: arrival counter of the bottom-up fit (zeroed)
     float *bmin, *bmax;           // per node, 3 floats each
-    uint32_t *word;               // per node: leaf word (device_scene.h Node::a) or 0 = inner
+    uint32_t *info;               // per node: INFO_* bits | primitives in the subtree
+    u64t *tc;                     // per node: primitives per type in the subtree, 20 bits each
+    uint32_t *size;               // per node: records the subtree is emitted as (1 for a collapsed subtree)
     uint32_t *axis_low;           // per internal node: near/far axis | (lower child is the right one ? 4 : 0)
+    uint32_t *word;               // per node: the leaf word (device_scene.h) of a leaf top, set by finish_node; else untouched
 };
+static const uint32_t INFO_COLLAPSED = 1u << 31;   // <= max_leaf primitives of one type: the subtree is (part of) a leaf
+static const uint32_t INFO_UNIFORM = 1u << 30;     // all primitives of one type
+static const uint32_t INFO_COUNT = (1u << 24) - 1u;
+HD uint32_t info_type(uint32_t info) { return (info >> 28) & 3u; }
+HD uint32_t tc_of(u64t tc, uint32_t t) { return (uint32_t)(tc >> (20u * t)) & 0xfffffu; }
 
 HD void prim_box(const Prims &p, uint32_t i, float *mn, float *mx, uint32_t &type) {
     if (i < p.num_tris) {
@@ -95,7 +112,7 @@ HD int clz64(mkey_t v) {
 }
 HD int delta(const mkey_t *k, int n, int i, int j) { return (j < 0 || j >= n) ? -1 : clz64(k[i] ^ k[j]); }
 
-// Karras 2012 §4, internal node i of n-1
+// ---- builder 1: Karras 2012 §4, internal node i of n-1
 HD void hierarchy_node(const mkey_t *keys, int n, int i, const Work &w) {
     int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
     int dmin = delta(keys, n, i, i - d);
@@ -116,20 +133,20 @@ HD void hierarchy_node(const mkey_t *keys, int n, int i, const Work &w) {
     uint32_t lc = (lo == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
     uint32_t rc = (hi == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
     w.left[i] = lc; w.right[i] = rc;
-    w.first[i] = (uint32_t)lo; w.last[i] = (uint32_t)hi;
     w.parent[lc] = (uint32_t)i; w.parent[rc] = (uint32_t)i;
     if (i == 0) w.parent[0] = NODE_END;
 }
 
-// leaf node of sorted position k: box + one-primitive leaf word.  The primitive arrays are re-stored per type in sorted
-// order, so the rank within the type is the sorted position minus the start of the type's run.
+// ---- leaf node of sorted position k: box, type, counts
 HD void fit_leaf(const Prims &p, const mkey_t *keys, int n, int k, const Work &w) {
     float mn[3], mx[3];
     uint32_t type;
     prim_box(p, key_index(keys[k]), mn, mx, type);
     uint32_t node = (uint32_t)(n - 1 + k);
     for (int a = 0; a < 3; a++) { LBVH_ST(&w.bmin[node * 3 + a], mn[a]); LBVH_ST(&w.bmax[node * 3 + a], mx[a]); }
-    LBVH_ST(&w.word[node], ((type + 1u) << 28) | (1u << 20) | ((uint32_t)k - type_offset(p, type)));
+    LBVH_ST(&w.info[node], INFO_COLLAPSED | INFO_UNIFORM | (type << 28) | 1u);
+    LBVH_ST(&w.tc[node], (u64t)1 << (20u * type));
+    LBVH_ST(&w.size[node], 1u);
 }
 // internal node whose two subtrees are complete
 HD void fit_inner(int n, uint32_t cur, uint32_t max_leaf, const Work &w) {
@@ -148,44 +165,102 @@ HD void fit_inner(int n, uint32_t cur, uint32_t max_leaf, const Work &w) {
     for (int a = 1; a < 3; a++) if (fabsf(cl[a] - cr[a]) > best) { best = fabsf(cl[a] - cr[a]); axis = a; }
     w.axis_low[cur] = (uint32_t)axis | (cr[axis] < cl[axis] ? 4u : 0u);
     // collapse: a subtree of <= max_leaf primitives of ONE type becomes a leaf
-    uint32_t f = w.first[cur], la = w.last[cur], cnt = la - f + 1;
-    uint32_t wl = LBVH_LD(&w.word[n - 1 + f]), wr = LBVH_LD(&w.word[n - 1 + la]);
-    uint32_t word = 0;
-    if (cnt <= max_leaf && (wl >> 28) == (wr >> 28)) word = (wl & 0xf0000000u) | (cnt << 20) | (wl & 0xfffffu);
-    LBVH_ST(&w.word[cur], word);
+    const uint32_t il = LBVH_LD(&w.info[l]), ir = LBVH_LD(&w.info[r]);
+    const uint32_t cnt = (il & INFO_COUNT) + (ir & INFO_COUNT);
+    const bool uniform = (il & INFO_UNIFORM) && (ir & INFO_UNIFORM) && info_type(il) == info_type(ir);
+    const bool collapsed = uniform && cnt <= max_leaf;
+    LBVH_ST(&w.info[cur], (collapsed ? INFO_COLLAPSED : 0u) | (uniform ? INFO_UNIFORM : 0u) | (info_type(il) << 28) | cnt);
+    LBVH_ST(&w.tc[cur], LBVH_LD(&w.tc[l]) + LBVH_LD(&w.tc[r]));
+    LBVH_ST(&w.size[cur], collapsed ? 1u : 1u + LBVH_LD(&w.size[l]) + LBVH_LD(&w.size[r]));
+}
+
+// ---- builder 2: PLOC.  `cl` = the current clusters (node ids) in Morton order, m of them
+HD float union_area(const Work &w, uint32_t a, uint32_t b) {
+    float d[3];
+    for (int k = 0; k < 3; k++) d[k] = fmaxf(w.bmax[a * 3 + k], w.bmax[b * 3 + k]) - fminf(w.bmin[a * 3 + k], w.bmin[b * 3 + k]);
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+HD uint32_t ploc_nearest(const Work &w, const uint32_t *cl, uint32_t m, uint32_t i) {
+    uint32_t lo = i > (uint32_t)PLOC_RADIUS ? i - PLOC_RADIUS : 0u, hi = i + PLOC_RADIUS < m - 1u ? i + PLOC_RADIUS : m - 1u;
+    uint32_t best = i == lo ? i + 1u : lo;
+    float ba = 3.0e38f;
+    for (uint32_t j = lo; j <= hi; j++) {
+        if (j == i) continue;
+        float a = union_area(w, cl[i], cl[j]);
+        if (a < ba) { ba = a; best = j; }   // ties: the lower position — both partners of a pair then agree
+    }
+    return best;
+}
+// 1 = cluster i merges with nn[i] and the new node takes its place, 2 = it is the absorbed partner, 0 = it stays
+HD int ploc_role(const uint32_t *nn, uint32_t i) {
+    uint32_t j = nn[i];
+    if (nn[j] != i) return 0;
+    return i < j ? 1 : 2;
+}
+HD void ploc_make_node(const Work &w, uint32_t id, uint32_t l, uint32_t r) {
+    w.left[id] = l; w.right[id] = r;
+    w.parent[l] = id; w.parent[r] = id;
+    for (int a = 0; a < 3; a++) {
+        w.bmin[id * 3 + a] = fminf(w.bmin[l * 3 + a], w.bmin[r * 3 + a]);
+        w.bmax[id * 3 + a] = fmaxf(w.bmax[l * 3 + a], w.bmax[r * 3 + a]);
+    }
+}
+
+// ---- finish: every node finds its own place by walking up
+HD bool is_collapsed(const Work &w, uint32_t node) { return (w.info[node] & INFO_COLLAPSED) != 0u; }
+// a leaf of the emitted tree: collapsed, and not inside a bigger collapsed subtree
+HD bool is_leaf_top(const Work &w, uint32_t node) {
+    if (!is_collapsed(w, node)) return false;
+    uint32_t par = w.parent[node];
+    return par == NODE_END || !is_collapsed(w, par);
+}
+HD bool is_emitted(const Work &w, uint32_t node) { return !is_collapsed(w, node) || is_leaf_top(w, node); }
+// primitives of type t that precede the subtree of `node` in left-first depth-first order
+HD uint32_t type_rank(const Work &w, uint32_t node, uint32_t t) {
+    uint32_t r = 0, c = node;
+    for (uint32_t par = w.parent[c]; par != NODE_END; c = par, par = w.parent[c])
+        if (c == w.right[par]) r += tc_of(w.tc[w.left[par]], t);
+    return r;
+}
+HD bool near_is_right(const Work &w, uint32_t inner, int o) {
+    uint32_t al = w.axis_low[inner];
+    bool neg = (o >> (al & 3u)) & 1;           // ray travels toward -axis: the higher-coordinate child is nearer
+    return neg != (bool)(al & 4u);
+}
+// index of an emitted node in octant o's near-first preorder
+HD uint32_t preorder_index(const Work &w, uint32_t node, int o) {
+    uint32_t idx = 0, c = node;
+    for (uint32_t par = w.parent[c]; par != NODE_END; c = par, par = w.parent[c]) {
+        uint32_t nearc = near_is_right(w, par, o) ? w.right[par] : w.left[par];
+        idx += (c == nearc) ? 1u : 1u + w.size[nearc];
+    }
+    return idx;
+}
+// per node: leaf word of a leaf top; per primitive leaf (node >= n-1): where its primitive goes in the per-type arrays
+HD void finish_node(const Prims &p, int n, uint32_t node, const Work &w, uint32_t *prim_pos) {
+    const uint32_t info = w.info[node], t = info_type(info);
+    if (is_leaf_top(w, node)) w.word[node] = ((t + 1u) << 28) | ((info & INFO_COUNT) << 20) | type_rank(w, node, t);
+    if (node >= (uint32_t)(n - 1)) prim_pos[node - (uint32_t)(n - 1)] = type_offset(p, t) + type_rank(w, node, t);
 }
 
 HD float pad_down(float v) { return nextafterf(nextafterf(v, -INFINITY), -INFINITY); }
 HD float pad_up(float v) { return nextafterf(nextafterf(v, INFINITY), INFINITY); }
 
-// record of node i for ray-direction octant o.  Nodes below a collapsed ancestor are unreachable; their records are inert.
-HD Node emit_node(int n, int i, int o, const Work &w) {
-    Node nd;
+// records of node `node` for ray-direction octant o, written at its preorder index; total = w.size[0] records per octant
+HD void emit_node(uint32_t node, int o, const Work &w, const float *qmin, const float *qstep, Node *nodes, QNode *qnodes) {
+    if (!is_emitted(w, node)) return;
+    const uint32_t total = w.size[0], idx = preorder_index(w, node, o);
     float mn[3], mx[3];
-    for (int a = 0; a < 3; a++) { mn[a] = pad_down(w.bmin[i * 3 + a]); mx[a] = pad_up(w.bmax[i * 3 + a]); }  // slack like bvh_build.cpp
+    for (int a = 0; a < 3; a++) { mn[a] = pad_down(w.bmin[node * 3 + a]); mx[a] = pad_up(w.bmax[node * 3 + a]); }  // slack like bvh_build.cpp
+    const bool leaf = is_leaf_top(w, node);
+    uint32_t after = idx + w.size[node];
+    if (after == total) after = NODE_END;
+    Node nd;
     node_set_box(nd, mn, mx, o);
-    uint32_t word = w.word[i];
-    if (word) nd.a = word;
-    else {
-        uint32_t al = w.axis_low[i];
-        bool neg = (o >> (al & 3u)) & 1;           // ray travels toward -axis: the higher-coordinate child is nearer
-        bool near_right = neg != (bool)(al & 4u);
-        nd.a = near_right ? w.right[i] : w.left[i];
-    }
-    // miss / leaf done: climb until this subtree is the NEAR child of an ancestor -> that ancestor's far child
-    uint32_t cur = (uint32_t)i, miss = NODE_END;
-    for (;;) {
-        uint32_t par = w.parent[cur];
-        if (par == NODE_END) break;
-        uint32_t al = w.axis_low[par];
-        bool neg = (o >> (al & 3u)) & 1;
-        bool near_right = neg != (bool)(al & 4u);
-        uint32_t nearc = near_right ? w.right[par] : w.left[par], farc = near_right ? w.left[par] : w.right[par];
-        if (cur == nearc) { miss = farc; break; }
-        cur = par;
-    }
-    nd.b = miss;
-    return nd;
+    nd.a = leaf ? w.word[node] : idx + 1u;
+    nd.b = after;
+    nodes[(size_t)o * total + idx] = nd;
+    qnodes[(size_t)o * (total + 1u) + idx] = qnode_make(mn, mx, o, qmin, qstep, leaf ? w.word[node] : after);
 }
 
 }  // namespace lbvh

@@ -120,7 +120,7 @@ typedef struct hr_stats {
     /* counters build only: wave-level phase statistics of the trace kernel (invocations, lanes served) */
     uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
     uint64_t phase_cycles[4];  /* counters build: wave-cycles in A shade, B refill, C box phase, C leaf phase */
-    double bvh_build_ms;       /* device BVH build of the last hr_upload_scene (option bvh_builder = 1), else 0 */
+    double bvh_build_ms;       /* device BVH build of the last hr_upload_scene (option bvh_builder = 1 | 2), else 0 */
     uint64_t seed_phase_cycles[8]; /* option seed_prof: consumer-wave cycles per phase of the seed kernel, [7] = groups */
 } hr_stats;
 
@@ -197,8 +197,8 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  * thresholds), "min_waves" (4..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
  * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24 | 28: how many
  * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
- * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH built on the device — replaces the reference's CPU build of
- * bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
+ * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH, 2 = PLOC (agglomerative, tree quality of the host build) built on
+ * the device — replaces the reference's CPU build of bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
  * cuts the SAH cost by more than 7 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
  * "ring_policy" (cache policy of the seed kernel's ring stores / fill), "node_unroll" (1 | 2 node visits per pass of the box phase),
  * "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),

@@ -92,12 +92,13 @@ extern "C" {
 
 static int g_max_leaf = 4;
 static double g_split_ratio = -1.0;   // automatic, as the library
-static int g_builder = 0;   // 0 = host SAH (bvh_build.cpp), 1 = LBVH (lbvh_core.h, the device builder's per-thread code run sequentially)
+static int g_builder = 0;   // 0 = host SAH (bvh_build.cpp), 1 = LBVH, 2 = PLOC (lbvh_core.h, the device builders' per-thread code run sequentially)
 void emu_set_build_options(int max_leaf, double split_ratio) { g_max_leaf = max_leaf; g_split_ratio = split_ratio; }
 void emu_set_builder(int builder) { g_builder = builder; }
 
-// what build_bvh_on_device (hr_api.hip) does, with std::sort for the radix sort and loops for the kernels
-static void lbvh_build_host(HostScene &hs, int max_leaf) {
+// what build_bvh_on_device (hr_api.hip) does, with std::sort for the radix sort and loops for the kernels.
+// builder 1 = LBVH hierarchy (Karras), 2 = PLOC (the single-workgroup kernel's phases, run by one "thread")
+static void device_build_host(HostScene &hs, int max_leaf, int builder) {
     using namespace lbvh;
     Prims p{};
     p.tris = hs.tris.data(); p.num_tris = (uint32_t)hs.tris.size();
@@ -112,13 +113,33 @@ static void lbvh_build_host(HostScene &hs, int max_leaf) {
     std::vector<mkey_t> keys(n);
     for (int i = 0; i < n; i++) keys[i] = prim_key(p, (uint32_t)i);
     std::sort(keys.begin(), keys.end());
-    std::vector<uint32_t> parent(N, NODE_END), left(n), right(n), first(n), last(n), flags(n, 0), word(N, 0), axis_low(n, 0);
+    std::vector<uint32_t> parent(N, NODE_END), left(n), right(n), flags(n, 0), info(N, 0), size(N, 0), axis_low(n, 0), word(N, 0), prim_pos(n, 0);
+    std::vector<u64t> tc(N, 0);
     std::vector<float> bmin(3 * (size_t)N), bmax(3 * (size_t)N);
-    Work w{parent.data(), left.data(), right.data(), first.data(), last.data(), flags.data(), bmin.data(), bmax.data(), word.data(), axis_low.data()};
-    for (int i = 0; i < n - 1; i++) hierarchy_node(keys.data(), n, i, w);
-    for (int k = 0; k < n; k++) {
-        fit_leaf(p, keys.data(), n, k, w);
-        if (n == 1) break;
+    Work w{parent.data(), left.data(), right.data(), flags.data(), bmin.data(), bmax.data(), info.data(), tc.data(), size.data(), axis_low.data(), word.data()};
+    for (int k = 0; k < n; k++) fit_leaf(p, keys.data(), n, k, w);
+    if (builder == 1) {
+        for (int i = 0; i < n - 1; i++) hierarchy_node(keys.data(), n, i, w);
+    } else if (n > 1) {
+        std::vector<uint32_t> cl(n), nxt(n), nn(n);
+        for (int k = 0; k < n; k++) cl[k] = (uint32_t)(n - 1 + k);
+        uint32_t m = (uint32_t)n, next_node = (uint32_t)(n - 1);   // internal ids are handed out downwards: the last merge makes node 0, the root
+        while (m > 1) {
+            for (uint32_t i = 0; i < m; i++) nn[i] = ploc_nearest(w, cl.data(), m, i);
+            uint32_t pos = 0, made = 0;
+            for (uint32_t i = 0; i < m; i++) {
+                int role = ploc_role(nn.data(), i);
+                if (role == 2) continue;
+                if (role == 1) { uint32_t id = next_node - 1u - made++; ploc_make_node(w, id, cl[i], cl[nn[i]]); nxt[pos++] = id; }
+                else nxt[pos++] = cl[i];
+            }
+            next_node -= made;
+            m = pos;
+            cl.swap(nxt);
+        }
+        parent[0] = NODE_END;
+    }
+    for (int k = 0; k < n && n > 1; k++) {   // bottom-up fit: the second arrival at a node fits it
         uint32_t cur = parent[n - 1 + k];
         while (cur != NODE_END) {
             if (flags[cur]++ == 0) break;
@@ -126,28 +147,36 @@ static void lbvh_build_host(HostScene &hs, int max_leaf) {
             cur = parent[cur];
         }
     }
-    hs.nodes.resize(8 * (size_t)N + 1);
-    for (int o = 0; o < 8; o++)
-        for (int i = 0; i < N; i++) hs.nodes[(size_t)o * N + i] = emit_node(n, i, o, w);
-    hs.num_nodes = (uint32_t)N;
+    for (int i = 0; i < N; i++) finish_node(p, n, (uint32_t)i, w, prim_pos.data());
+    const uint32_t total = size[0];
+    float rmn[3], rmx[3];
+    for (int a = 0; a < 3; a++) { rmn[a] = pad_down(bmin[a]); rmx[a] = pad_up(bmax[a]); }
+    qframe_from_box(rmn, rmx, hs.qmin, hs.qstep);
+    hs.nodes.assign(8 * (size_t)total + 1, Node{});
+    hs.qnodes.assign(8 * ((size_t)total + 1), QNode{});
+    for (int o = 0; o < 8; o++) {
+        for (int i = 0; i < N; i++) emit_node((uint32_t)i, o, w, hs.qmin, hs.qstep, hs.nodes.data(), hs.qnodes.data());
+        hs.qnodes[(size_t)o * (total + 1) + total] = qnode_sentinel(o);
+    }
+    hs.num_nodes = total;
     std::vector<Tri> tris(hs.tris.size());
     std::vector<f4> spheres(hs.spheres.size()), cuboids(hs.cuboids.size());
     std::vector<int32_t> sphere_elem(hs.sphere_elem.size());
     for (int k = 0; k < n; k++) {
-        uint32_t i = key_index(keys[k]);
-        if (i < p.num_tris) tris[k] = hs.tris[i];
-        else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris, d = k - p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; }
-        else { uint32_t l = i - p.num_tris - p.num_spheres, d = k - p.num_tris - p.num_spheres; cuboids[2 * d] = hs.cuboids[2 * l]; cuboids[2 * d + 1] = hs.cuboids[2 * l + 1]; }
+        uint32_t i = key_index(keys[k]), d = prim_pos[k];
+        if (i < p.num_tris) tris[d] = hs.tris[i];
+        else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris; d -= p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; }
+        else { uint32_t l = i - p.num_tris - p.num_spheres; d -= p.num_tris + p.num_spheres; cuboids[2 * d] = hs.cuboids[2 * l]; cuboids[2 * d + 1] = hs.cuboids[2 * l + 1]; }
     }
     hs.tris.swap(tris); hs.spheres.swap(spheres); hs.sphere_elem.swap(sphere_elem); hs.cuboids.swap(cuboids);
-    // reachable leaves / depth for the stats call
+    // leaves / depth of the emitted tree for the stats call
     hs.bvh_leaves = 0; hs.bvh_max_depth = 0;
     std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}};
     while (!st.empty()) {
         auto [id, depth] = st.back();
         st.pop_back();
         hs.bvh_max_depth = std::max(hs.bvh_max_depth, depth);
-        if (word[id]) { hs.bvh_leaves++; continue; }
+        if (is_collapsed(w, id)) { hs.bvh_leaves++; continue; }
         st.push_back({left[id], depth + 1}); st.push_back({right[id], depth + 1});
     }
 }
@@ -157,7 +186,7 @@ int emu_scene_create(const hr_scene_desc *sd, emu_scene **out) {
     std::string err;
     int rc = flatten_scene(sd, e->hs, err, g_max_leaf, g_builder ? 0.0 : g_split_ratio, g_builder == 0);
     if (rc) { fprintf(stderr, "emu: %s\n", err.c_str()); delete e; return rc; }
-    if (g_builder) lbvh_build_host(e->hs, g_max_leaf);
+    if (g_builder) device_build_host(e->hs, g_max_leaf, g_builder);
     e->view = e->hs.view();
     *out = e;
     return 0;

@@ -73,7 +73,7 @@ class EmuScene:
 
 
 def set_build_options(max_leaf=4, split_ratio=-1.0, builder=0):
-    """builder: 0 = host SAH, 1 = LBVH (the device builder's per-thread code, run sequentially)."""
+    """builder: 0 = host SAH, 1 = LBVH, 2 = PLOC (the device builders' per-thread code, run sequentially)."""
     lib().emu_set_build_options(max_leaf, split_ratio)
     lib().emu_set_builder(builder)
 

@@ -134,12 +134,14 @@ def _random_rays(sc, n, seed):
     return np.concatenate([org, d], axis=1).astype(np.float32)
 
 
+@pytest.mark.parametrize("builder", [1, 2])
 @pytest.mark.parametrize("name,max_leaf", [("rtcamp6_v3_1", 4), ("rtcamp6_v3_1", 1), ("cornell_mini", 4), ("spheres", 2), ("rtcamp6_dodeca", 8)])
-def test_lbvh_closest_hit_is_tree_independent(scenes, emu, emu_scenes, name, max_leaf):
-    """The closest hit must not depend on the tree: LBVH and host-SAH trees over the same fp32 primitives return the
-    same element and the same t bit for bit (the primitive tests are the same code), and agree with the f64 oracle."""
+def test_lbvh_closest_hit_is_tree_independent(scenes, emu, emu_scenes, name, max_leaf, builder):
+    """The closest hit must not depend on the tree: the device builders' trees (1 = LBVH, 2 = PLOC) and the host-SAH tree over
+    the same fp32 primitives return the same element and the same t bit for bit (the primitive tests are the same code), on
+    the 32-byte records and on the 16-byte quantised ones, and agree with the f64 oracle."""
     sc, o, e_sah = emu_scenes(name)
-    emu.set_build_options(max_leaf=max_leaf, builder=1)
+    emu.set_build_options(max_leaf=max_leaf, builder=builder)
     try:
         e = emu.EmuScene(sc.desc_ptr)
     finally:
@@ -148,10 +150,16 @@ def test_lbvh_closest_hit_is_tree_independent(scenes, emu, emu_scenes, name, max
     n = st["tris"] + st["spheres"] + st["cuboids"]
     # (the host tree may hold long thin triangles as several split references; the device LBVH holds every triangle once)
     assert st["tris"] <= st0["tris"] and (st["spheres"], st["cuboids"]) == (st0["spheres"], st0["cuboids"])
-    assert st["nodes"] == 2 * n - 1 and st["leaves"] >= (n + max_leaf - 1) // max_leaf and st["max_depth"] < 64
+    assert st["nodes"] == 2 * st["leaves"] - 1 and st["leaves"] >= (n + max_leaf - 1) // max_leaf and st["max_depth"] < 64
     rays = _random_rays(sc, 4000, 23)
     got, gel = e.intersect(rays)
     ref, rel = e_sah.intersect(rays)
+    emu.set_walk_mode(2)                     # the trace kernel's walk on the quantised records of the device-built tree
+    try:
+        gotq, gelq = e.intersect(rays)
+    finally:
+        emu.set_walk_mode(0)
+    assert np.array_equal(gotq, got) and np.array_equal(gelq, gel)
     assert np.array_equal(got[:, 0], ref[:, 0])
     hit = ref[:, 0] == 1
     # equal-t ties between adjacent triangles may resolve to either one; everything else is identical
@@ -161,9 +169,10 @@ def test_lbvh_closest_hit_is_tree_independent(scenes, emu, emu_scenes, name, max
     assert (got[:, 0] == oref[:, 0]).mean() > 0.999
 
 
-def test_lbvh_radiance(scenes, emu, orc):
+@pytest.mark.parametrize("builder", [1, 2])
+def test_lbvh_radiance(scenes, emu, orc, builder):
     sc, o = scenes("cornell_mini")
-    emu.set_build_options(builder=1)
+    emu.set_build_options(builder=builder)
     try:
         e = emu.EmuScene(sc.desc_ptr)
     finally:
@@ -175,7 +184,8 @@ def test_lbvh_radiance(scenes, emu, orc):
     assert (err < ATOL_REL).mean() > FRAC_OK
 
 
-def test_lbvh_single_primitive(ha, emu):
+@pytest.mark.parametrize("builder", [1, 2])
+def test_lbvh_single_primitive(ha, emu, builder):
     """n = 1: no internal node, the lone leaf is the root."""
     import ctypes as C
     el = (ha.Element * 1)()
@@ -188,7 +198,7 @@ def test_lbvh_single_primitive(ha, emu):
     C.memmove(C.byref(d), base.desc_ptr, C.sizeof(d))
     d.elements = C.cast(el, C.POINTER(ha.Element))
     d.num_elements = 1
-    emu.set_build_options(builder=1)
+    emu.set_build_options(builder=builder)
     try:
         e = emu.EmuScene(C.addressof(d))
     finally:
@@ -237,3 +247,30 @@ def test_quantised_nodes_give_the_same_hits(emu, emu_scenes, name):
     assert np.array_equal(got, ref) and np.array_equal(gel, rel)
     print("%s: node tests plain %d, quantised %d (+%.2f %%)" % (name, plain, quant, 100.0 * (quant - plain) / plain))
     assert plain <= quant <= 1.01 * plain + len(rays)
+
+
+def test_device_builders_tree_quality(scenes, emu, emu_scenes):
+    """Node tests per ray of the device-built trees against the host SAH tree (same rays): the Morton-median LBVH costs about 1.4x,
+    the agglomerative PLOC build must stay within 15 %."""
+    out = {}
+    for name in ("rtcamp6_v3_1", "rtcamp6_dodeca"):
+        sc, _, e_sah = emu_scenes(name)
+        rays = _random_rays(sc, 6000, 57)
+        emu.set_walk_mode(1)
+        try:
+            e_sah.intersect(rays)
+            counts = [emu.last_node_tests()]
+            for builder in (1, 2):
+                emu.set_build_options(builder=builder)
+                try:
+                    e = emu.EmuScene(sc.desc_ptr)
+                finally:
+                    emu.set_build_options()
+                e.intersect(rays)
+                counts.append(emu.last_node_tests())
+        finally:
+            emu.set_walk_mode(0)
+        out[name] = counts
+        print("%s: node tests host SAH %d, LBVH %d (x%.2f), PLOC %d (x%.2f)" % (name, counts[0], counts[1], counts[1] / counts[0], counts[2], counts[2] / counts[0]))
+    for name, (sah, lb, pl) in out.items():
+        assert pl <= 1.15 * sah and pl < lb, (name, sah, lb, pl)

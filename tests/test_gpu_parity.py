@@ -244,7 +244,7 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 65), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_split", 10), ("bvh_builder", 2), ("rng_window", 32)]:
+    for key, bad in [("batch", 65), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_split", 10), ("bvh_builder", 3), ("rng_window", 32)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
     with pytest.raises(ha.HipError):
@@ -466,10 +466,11 @@ def test_matches_the_reference_binarys_committed_render(gpu, scenes):
 
 @pytest.mark.parametrize("name,max_leaf", [("rtcamp6_v3_1", 4), ("rtcamp6_dodeca", 4), ("spheres", 2), ("cornell_mini", 1)])
 def test_device_bvh_build_is_interchangeable(gpu, scenes, name, max_leaf):
-    """Option bvh_builder = 1 builds the tree on the GPU (LBVH, csrc/gpu_bvh.h).  Closest hits do not depend on the tree:
-    against the host-SAH tree over the same fp32 primitives the hit flag and t are identical bit for bit (pt_core.h
-    spells its FMAs out, so a primitive test returns the same bits in every leaf slot); the radiance accumulator then
-    differs only through equal-t ties between adjacent triangles and the atomics' summation order."""
+    """Options bvh_builder = 1 (LBVH) and 2 (PLOC) build the tree on the GPU (csrc/gpu_bvh.h) and emit it in the trace kernel's
+    16-byte preorder format.  Closest hits do not depend on the tree: against the host-SAH tree over the same fp32 primitives
+    the hit flag and t are identical bit for bit (pt_core.h spells its FMAs out, so a primitive test returns the same bits in
+    every leaf slot); the radiance accumulator then differs only through equal-t ties between adjacent triangles and the
+    atomics' summation order.  The PLOC tree must cost about as many node tests as the host SAH tree, the LBVH clearly more."""
     sc, o = scenes(name)
     rng = np.random.default_rng(5)
     n = 20000
@@ -481,37 +482,47 @@ def test_device_bvh_build_is_interchangeable(gpu, scenes, name, max_leaf):
     rays = np.concatenate([org, d], axis=1).astype(np.float32)
     res = {}
     try:
-        for builder in (0, 1):
+        for builder in (0, 1, 2):
             gpu.set_option("bvh_builder", builder)
             gpu.set_option("max_leaf", max_leaf)
             gpu.upload_scene(sc)
             st = gpu.stats()
             if builder:
                 nprim = st["triangles"] + st["spheres"] + st["cuboids"]
-                assert st["bvh_nodes"] == 2 * nprim - 1 and 0 < st["bvh_build_ms"] < 50.0
+                assert st["bvh_nodes"] % 2 == 1 and nprim // max_leaf <= st["bvh_nodes"] <= 2 * nprim - 1 and 0 < st["bvh_build_ms"] < 50.0
             else:
                 assert st["bvh_build_ms"] == 0
             hit, el = gpu.debug_intersect(rays)
             gpu.set_resolution(160, 90)
+            gpu.set_option("counters", 1)
             gpu.clear()
             gpu.render(1, 3)
-            res[builder] = (hit, el, gpu.read_accumulator().astype(np.float64))
+            acc = gpu.read_accumulator().astype(np.float64)
+            st = gpu.stats()
+            gpu.set_option("counters", 0)
+            res[builder] = (hit, el, acc, st["node_tests"] / max(1, st["rays"]), st["bvh_build_ms"])
     finally:
         gpu.set_option("bvh_builder", 0)
         gpu.set_option("max_leaf", 4)
-    (h0, e0, a0), (h1, e1, a1) = res[0], res[1]
-    assert np.array_equal(h0[:, 0], h1[:, 0])
-    hit = h0[:, 0] == 1
-    dt = np.abs(h0[hit, 1].astype(np.float64) - h1[hit, 1]) / np.maximum(1.0, h0[hit, 1])
-    print("device-vs-host tree: exact t %.5f, max rel dt %.3g, same element %.5f" % ((dt == 0).mean(), dt.max(), (e0[hit] == e1[hit]).mean()))
-    assert dt.max() == 0
-    assert (e0[hit] == e1[hit]).mean() > 0.999
-    assert np.isfinite(a1).all()
-    frac, m1, m0 = _compare(a1, a0)
-    assert frac >= GATES[name][0] and abs(m1 - m0) <= 2e-3 * max(1e-3, abs(m0))
+        gpu.set_option("counters", 0)
+    h0, e0, a0, nt0, _ = res[0]
     ref, _ = o.render(160, 90, 1, 3, threads=0, counters=True)
-    frac, m1, mr = _compare(a1, ref)
-    assert frac >= GATES[name][0] and abs(m1 - mr) <= 2e-3 * max(1e-3, abs(mr))
+    for builder in (1, 2):
+        h1, e1, a1, nt1, ms = res[builder]
+        assert np.array_equal(h0[:, 0], h1[:, 0])
+        hit = h0[:, 0] == 1
+        dt = np.abs(h0[hit, 1].astype(np.float64) - h1[hit, 1]) / np.maximum(1.0, h0[hit, 1])
+        print("%s builder %d vs host tree: exact t %.5f, max rel dt %.3g, same element %.5f, node tests per ray %.1f vs %.1f, build %.2f ms" %
+              (name, builder, (dt == 0).mean(), dt.max(), (e0[hit] == e1[hit]).mean(), nt1, nt0, ms))
+        assert dt.max() == 0
+        assert (e0[hit] == e1[hit]).mean() > 0.999
+        assert np.isfinite(a1).all()
+        frac, m1, m0 = _compare(a1, a0)
+        assert frac >= GATES[name][0] and abs(m1 - m0) <= 2e-3 * max(1e-3, abs(m0))
+        frac, m1, mr = _compare(a1, ref)
+        assert frac >= GATES[name][0] and abs(m1 - mr) <= 2e-3 * max(1e-3, abs(mr))
+    if name.startswith("rtcamp6"):
+        assert res[2][3] <= 1.15 * nt0 and res[2][3] < res[1][3]      # PLOC: within 15 % of the host SAH tree, better than the LBVH
 
 
 def test_mark_and_wait_keep_the_pipeline_running(gpu, scenes):
