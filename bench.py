@@ -93,7 +93,6 @@ def main():
     ap.add_argument("--seed-split", type=int, default=-1)
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
     ap.add_argument("--trace-wgs", type=int, default=0, help="trace-kernel workgroups per CU (0 = library default)")
-    ap.add_argument("--ring-policy", type=int, default=-1)
     ap.add_argument("--quant-nodes", type=int, default=-1)
     ap.add_argument("--kchunk", type=int, default=0)
     ap.add_argument("--node-unroll", type=int, default=0)
@@ -161,8 +160,6 @@ def main():
         r.set_option("min_waves", args.min_waves)
     if args.trace_wgs:
         r.set_option("trace_wgs", args.trace_wgs)
-    if args.ring_policy >= 0:
-        r.set_option("ring_policy", args.ring_policy)
     if args.kchunk:
         r.set_option("kchunk", args.kchunk)
     if args.node_unroll:

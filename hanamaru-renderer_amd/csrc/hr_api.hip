@@ -97,7 +97,6 @@ struct hr_ctx {
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
-    uint32_t ring_policy = 1;                // cache policy of the seed kernel's ring stores / fill (seed_kernels.h)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
     int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH, 2 = device PLOC (gpu_bvh.h); next upload
@@ -502,7 +501,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.stride = stride;
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
-    rp.node_unroll = c->node_unroll; rp.ring_policy = c->ring_policy; rp.kchunk = c->kchunk;
+    rp.node_unroll = c->node_unroll; rp.ring_policy = 0; rp.kchunk = c->kchunk;
     rp.pad[0] = c->seed_prio;
     rp.pad[1] = c->init_prio;
     rp.pad[2] = (uint32_t)c->debug_skip;
@@ -827,11 +826,6 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "quant_nodes") { c->quant_nodes = value != 0.0; return HR_OK; }
-    if (k == "ring_policy") {
-        if (value < 0 || value > 15) return fail(HR_ERR_INVALID, "ring_policy must be in [0,15]");
-        c->ring_policy = (uint32_t)value;
-        return HR_OK;
-    }
     if (k == "node_unroll") {
         if (value != 1 && value != 2) return fail(HR_ERR_INVALID, "node_unroll must be 1 or 2");
         c->node_unroll = (uint32_t)value;

@@ -167,46 +167,64 @@ static const size_t SEED_LDS_HALF_BYTES = (size_t)256 * SEED_LANES * 8;  // 80 K
 
 // Ring stores: a lane owns one column, so its words i and i + 1 are a row (320 B) apart.  Lane pairs (l, l ^ 1) swap one
 // word each so that the even lane stores row i and the odd lane row i + 1 as 16-byte pieces {column 2k, column 2k + 1}:
-// one dwordx4 store instruction then writes whole rows.
+// one dwordx4 store instruction then writes whole rows.  The swap is two v_cndmask_b32_dpp per word pair
+// (even lane: {own v0, partner's v0}; odd lane: {partner's v1, own v1}), written by hand on the registers the mix leaves its
+// result in (two-instruction hazard distances counted from isaac_mix_gfx950.h): the compiler's form of the same thing took 34 issue slots per block, this 18.
+// The caller masks lanes without a path off around the whole init (lanes 2m, 2m + 1 are always on or off together).
 template <int HEAD>
 struct RingState {
     u64 *pair;   // even lane: &row0[col]; odd lane: &row1[col - 1]
-    bool on, odd;
-    uint32_t policy;   // cache policy of the ring stores: 0 plain, 1 sc1 (write-through, not kept in the XCD's L2), 2 nt, 3 sc0 sc1
-    __device__ __forceinline__ RingState(u64 *half_base, uint32_t column, bool on_, uint32_t lane, uint32_t policy_) : on(on_), odd(lane & 1u), policy(policy_) {
+    __device__ __forceinline__ RingState(u64 *half_base, uint32_t column, uint32_t lane) {
         u64 *col = half_base + column;
-        pair = odd ? col + SEED_LANES - 1 : col;
+        pair = (lane & 1u) ? col + SEED_LANES - 1 : col;
         regs = half_base + (size_t)PcLayout<HEAD>::SHIP_ROWS * SEED_LANES + (size_t)column * 2u;
     }
-    static __device__ __forceinline__ u64 swap_pair(u64 v) {   // value of lane ^ 1
-        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-        hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xf, 0xf, true);
-        return ((u64)hi << 32) | lo;
-    }
-    __device__ __forceinline__ void row2(int row, u64 v0, u64 v1) {   // rows `row` (v0) and `row + 1` (v1) of this lane's column
-        u64 got = swap_pair(odd ? v0 : v1);            // even receives the partner's v0, odd the partner's v1
+    // block i / 8 of the pass-2 sweep: words i .. i + 7 of this lane's column
+    __device__ __forceinline__ void st8(int i, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) {
         typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-        u64x2 q;
-        q.x = odd ? got : v0;
-        q.y = odd ? v1 : got;
-        if (on) {
-            u64x2 *dst = reinterpret_cast<u64x2 *>(pair + row * SEED_LANES);
-            switch (policy) {   // wave-uniform
-                case 1: asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(q) : "memory"); break;
-                case 2: asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(q) : "memory"); break;
-                case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(q) : "memory"); break;
-                default: *dst = q; break;
-            }
-        }
+        const u64 even = 0x5555555555555555ULL, odd = 0xAAAAAAAAAAAAAAAAULL;
+        // D = vcc ? src1 : dpp(src0).  The DPP operands are read >= 2 instructions after the mix last wrote them (VALU -> DPP hazard):
+        // B, D, F, H first (H's last write is four instructions before the end of the mix), G — written last — at the very end.
+#define HR_SWZ(dst, own, other) "v_cndmask_b32_dpp " dst ", " other ", " own ", vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define HR_LO(v) "v"((uint32_t)(v))
+#define HR_HI(v) "v"((uint32_t)((v) >> 32))
+        uint32_t x0l, x0h, x1l, x1h, x2l, x2h, x3l, x3h, y0l, y0h, y1l, y1h, y2l, y2h, y3l, y3h;
+        asm("s_mov_b64 vcc, %24\n\t"
+            HR_SWZ("%0", "%8", "%10") HR_SWZ("%1", "%9", "%11")        // q0.x = even ? A : partner's B
+            HR_SWZ("%2", "%12", "%14") HR_SWZ("%3", "%13", "%15")      // q1.x = even ? C : partner's D
+            HR_SWZ("%4", "%16", "%18") HR_SWZ("%5", "%17", "%19")      // q2.x = even ? E : partner's F
+            HR_SWZ("%6", "%20", "%22") HR_SWZ("%7", "%21", "%23")      // q3.x = even ? G : partner's H
+            : "=&v"(x0l), "=&v"(x0h), "=&v"(x1l), "=&v"(x1h), "=&v"(x2l), "=&v"(x2h), "=&v"(x3l), "=&v"(x3h)
+            : HR_LO(A), HR_HI(A), HR_LO(B), HR_HI(B), HR_LO(C), HR_HI(C), HR_LO(D), HR_HI(D), HR_LO(E), HR_HI(E), HR_LO(F), HR_HI(F), HR_LO(G), HR_HI(G), HR_LO(H), HR_HI(H), "s"(even)
+            : "vcc");
+        asm("s_mov_b64 vcc, %24\n\t"
+            HR_SWZ("%0", "%10", "%8") HR_SWZ("%1", "%11", "%9")        // q0.y = odd ? B : partner's A
+            HR_SWZ("%2", "%14", "%12") HR_SWZ("%3", "%15", "%13")      // q1.y = odd ? D : partner's C
+            HR_SWZ("%4", "%18", "%16") HR_SWZ("%5", "%19", "%17")      // q2.y = odd ? F : partner's E
+            HR_SWZ("%6", "%22", "%20") HR_SWZ("%7", "%23", "%21")      // q3.y = odd ? H : partner's G
+            : "=&v"(y0l), "=&v"(y0h), "=&v"(y1l), "=&v"(y1h), "=&v"(y2l), "=&v"(y2h), "=&v"(y3l), "=&v"(y3h)
+            : HR_LO(A), HR_HI(A), HR_LO(B), HR_HI(B), HR_LO(C), HR_HI(C), HR_LO(D), HR_HI(D), HR_LO(E), HR_HI(E), HR_LO(F), HR_HI(F), HR_LO(G), HR_HI(G), HR_LO(H), HR_HI(H), "s"(odd)
+            : "vcc");
+#undef HR_SWZ
+#undef HR_LO
+#undef HR_HI
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 q0 = {x0l, x0h, y0l, y0h}, q1 = {x1l, x1h, y1l, y1h}, q2 = {x2l, x2h, y2l, y2h}, q3 = {x3l, x3h, y3l, y3h};
+        // sc1: written through, not kept in the XCD's L2 (measured against plain / nt / sc0 sc1 stores: the trace kernel next door
+        // keeps more of its tree in L2).  Fixed at compile time: a wave-uniform switch cost ~3 scalar issue slots per store.
+        u64x2 *dst = reinterpret_cast<u64x2 *>(pair + i * SEED_LANES);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                     "global_store_dwordx4 %0, %2, off offset:640 sc1\n\t"
+                     "global_store_dwordx4 %0, %3, off offset:1280 sc1\n\t"
+                     "global_store_dwordx4 %0, %4, off offset:1920 sc1" : : "v"(dst), "v"(q0), "v"(q1), "v"(q2), "v"(q3) : "memory");
+        static_assert(SEED_LANES * 8 * 2 == 640, "row pair stride of the ring");
     }
-    __device__ __forceinline__ void st2(int i, u64 v0, u64 v1) { row2(i, v0, v1); }
     // registers j, j + 1 (j even) of this lane's column: [j / 2][column][2] behind the shipped rows, no lane swap needed
     __device__ __forceinline__ void end2(int j, u64 v0, u64 v1) {
         typedef u64 u64x2 __attribute__((ext_vector_type(2)));
         u64x2 q;
         q.x = v0; q.y = v1;
-        if (on) *reinterpret_cast<u64x2 *>(regs + (j >> 1) * (2 * SEED_LANES)) = q;
+        *reinterpret_cast<u64x2 *>(regs + (j >> 1) * (2 * SEED_LANES)) = q;
     }
     u64 *regs;   // &half[SHIP_ROWS * 40 + column * 2]
 };
@@ -220,6 +238,133 @@ struct LdsHalfMem {
 // PROF (option seed_prof): s_memtime stamps around the consumer's phases, summed per wave into Counters::seed_phase
 //   0 issue of the register loads + bookkeeping   1 wait for the 16 registers   2 isaac_init_back   3 barrier B (fill landed)
 //   4 isaac_round + record head   5 overflow note   6 barrier A (waiting for the producers / the other half)   7 groups
+// The two roles are two separate loops that meet at the same two barriers per iteration: the register allocation of one role
+// then does not carry the other's live values (the consumer's 32 prefetched registers through the producer's init, ...), and the
+// kernel stays at <= 128 VGPRs — one more and the trace kernel next door loses a wave per SIMD.
+struct PcRange {
+    uint64_t paths, G0, G1, first_path, end_path;
+    u64 *ring_wg;
+};
+template <int SEED_SPLIT, bool PROF>
+__device__ __forceinline__ void seed_pc_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
+                                                 float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    typedef PcLayout<SEED_SPLIT> L;
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * SEED_OVF_CAP;
+    uint32_t ovf_count = 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
+#define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
+    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t st16v[8];   // the 16 registers of the group whose init_back comes next (fetched one round ahead)
+    const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+    auto load_regs = [&](uint64_t g) {
+        const u64 *regs = r.ring_wg + (g & (SEED_RING_GROUPS - 1)) * L::GROUP_WORDS + half * L::HALF_WORDS + (size_t)L::SHIP_ROWS * SEED_LANES + (size_t)colr * 2u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) st16v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
+    };
+    unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+    LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
+    const uint64_t n_groups = r.G1 - r.G0;
+    __syncthreads();   // A of iteration 0: group G0 is complete in the ring
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        // ---- group g enters the LDS: the producer wave of this half copies words < 8*SPLIT from the ring; this wave fetches the 16
+        //      registers and finishes init blocks >= SPLIT straight into LDS meanwhile (no mix is computed twice).  Barrier B: complete.
+        if (PROF) tm = __builtin_readcyclecounter();
+        const uint64_t g = r.G0 + it - 1;
+        if (it == 1) load_regs(g);   // later groups: fetched during the previous round
+        const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
+        const bool in_range = pid < r.paths;
+        const uint32_t item = (uint32_t)((in_range ? pid : r.paths - 1) >> 6), j = (uint32_t)((in_range ? pid : r.paths - 1) & 63u);
+        uint32_t tile = item / rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        const bool valid = in_range && px < rp.width && py < rp.height;
+        HR_STAMP(0);
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
+        u64 st16[16];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { st16[2 * q] = st16v[q].x; st16[2 * q + 1] = st16v[q].y; }
+        if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);
+        HR_STAMP(2);
+        __syncthreads();   // B
+        HR_STAMP(3);
+        if (it < n_groups) load_regs(r.G0 + it);   // group G0 + it has been complete since barrier A; used after this round
+        // ---- the round of group g
+        RecStore rs(recs, pid);
+        RecordTail<RecStore> lt(rs, lens_shape);
+        if (lane < (uint32_t)SEED_LANES) {
+            isaac_round<REC_DRAWS>(m, lt);
+            lt.finish();
+        }
+        HR_STAMP(4);
+        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count);
+        HR_STAMP(5);
+        if (PROF) pc[7]++;
+        __syncthreads();   // A: group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
+        HR_STAMP(6);
+    }
+#undef HR_STAMP
+    if (PROF && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
+    const bool lane_on = lane < (uint32_t)SEED_LANES;
+    seed_fixup_wave(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
+}
+template <int SEED_SPLIT>
+__device__ __forceinline__ void seed_pc_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half) {
+    typedef PcLayout<SEED_SPLIT> L;
+    constexpr int CHUNKS = L::SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
+    static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
+    const IsaacWarm warm = isaac_warm();
+    uint64_t frontier = r.first_path & ~63ull;                   // first path not yet produced (chunk aligned)
+    const uint64_t n_groups = r.G1 - r.G0;
+    for (uint64_t it = 0; it <= n_groups; it++) {
+        if (it > 0) {
+            // the fill of group G0 + it - 1 (complete in the ring since the barrier that ended the last iteration): straight 1 KiB
+            // global_load_lds copies, no VGPR round trip; ~60 cycles of issue each, which the consumer's critical path does not pay
+            if (!(rp.pad[2] & 8u)) {
+                const uint64_t g = r.G0 + it - 1;
+                const u64 *src = r.ring_wg + (g & (SEED_RING_GROUPS - 1)) * L::GROUP_WORDS + half * L::HALF_WORDS;
+                // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one address pair
+                // serves two 1 KiB copies
+                const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(src) + lane * 16u;
+                unsigned char *ldst = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+#pragma unroll 5
+                for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
+                    const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
+                    void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2);      // aux 2 = nt: read once, do not keep
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
+                }
+                __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): landed
+            }
+            __syncthreads();   // B
+        }
+        // ---- complete group G0 + it + 1 in the ring (one group of slack: the consumer fetches the registers of group `it` while it
+        //      runs the round of group it - 1)
+        const uint64_t need = (r.G0 + it + 2) * SEED_COLS;      // paths below `need` (clipped to this workgroup's range) must be in the ring
+        uint32_t n = 0;
+        while (frontier < need && frontier < r.end_path) {
+            if ((n & 1u) == half) {
+                const uint64_t pid0 = frontier + lane;
+                const bool on = pid0 >= r.first_path && pid0 < r.end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
+                const uint64_t ppid = pid0 >= r.first_path && pid0 < r.end_path ? pid0 : r.end_path - 1;
+                const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
+                uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+                uint32_t px, py, sub;
+                tile_lane_pixel(rp, tile, j, px, py, sub);
+                bool pvalid = px < rp.width && py < rp.height;
+                u64 s, t;
+                path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
+                const uint64_t g = ppid / SEED_COLS;
+                const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS);
+                RingState<SEED_SPLIT> out(r.ring_wg + (g & (SEED_RING_GROUPS - 1)) * L::GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? L::HALF_WORDS : 0), c80 % SEED_LANES, lane);
+                if (on) isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+            }
+            frontier += 64;
+            n++;
+        }
+        __syncthreads();   // A
+    }
+}
 template <int SEED_SPLIT, bool PROF = false>   // SPLIT: init blocks done by the producers
 __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
                                                       uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
@@ -233,137 +378,14 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
     }
-    const uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
-    const uint64_t groups = (paths + SEED_COLS - 1) / SEED_COLS;
-    const uint64_t G0 = groups * blockIdx.x / gridDim.x, G1 = groups * (blockIdx.x + 1) / gridDim.x;   // this workgroup's groups
-    const uint64_t first_path = G0 * SEED_COLS, end_path = G1 * SEED_COLS < paths ? G1 * SEED_COLS : paths;
-    u64 *ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
-    const IsaacWarm warm = isaac_warm();
-    typedef PcLayout<SEED_SPLIT> L;
-    constexpr int SEED_SHIP_ROWS = L::SHIP_ROWS;
-    constexpr size_t SEED_HALF_WORDS = L::HALF_WORDS, SEED_GROUP_WORDS = L::GROUP_WORDS;
-    constexpr int CHUNKS = SEED_SHIP_ROWS * SEED_LANES * 8 / 1024;   // 1 KiB per wave-instruction
-    uint64_t frontier = first_path & ~63ull;                   // first path not yet produced (chunk aligned)
-    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * SEED_OVF_CAP;   // consumer waves only
-    uint32_t ovf_count = 0;
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
-#define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
-    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
-    u64x2_t st16v[8];   // consumer: the 16 registers of the group whose init_back comes next (fetched one round ahead)
-    auto load_regs = [&](uint64_t g) {
-        const u64 *regs = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS + (size_t)SEED_SHIP_ROWS * SEED_LANES +
-                          (size_t)(lane < (uint32_t)SEED_LANES ? lane : 0u) * 2u;
-#pragma unroll
-        for (int q = 0; q < 8; q++) st16v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
-    };
-    for (uint64_t it = 0; it <= G1 - G0; it++) {
-        // ---- group G0 + it - 1 (complete in the ring since the barrier that ended the last iteration) enters the LDS:
-        //      the PRODUCER wave of each half issues the fill (straight 1 KiB global_load_lds copies, no VGPR round trip; ~60
-        //      cycles of issue each, which the consumer's critical path does not pay) and waits for it to land; the CONSUMER
-        //      wave fetches the 16 registers and finishes init blocks >= SPLIT straight into LDS meanwhile (isaac_init_back,
-        //      no mix is computed twice).  Barrier B: the half is complete.
-        LdsHalfMem m{nullptr};
-        uint64_t pid = 0;
-        bool valid = false;
-        if (it > 0) {
-            if (PROF) tm = __builtin_readcyclecounter();
-            const uint64_t g = G0 + it - 1;
-            const u64 *src = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + half * SEED_HALF_WORDS;
-            unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
-            if (!consumer) {
-                if (!(rp.pad[2] & 8u)) {
-                    // generator words 0 .. 8*SPLIT - 1 of every column; the instruction offset advances both addresses, so one
-                    // address pair serves two 1 KiB copies
-                    static_assert(CHUNKS % 2 == 0, "fill is unrolled by two");
-                    const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(src) + lane * 16u;
-                    unsigned char *ldst = lds_half;
-#pragma unroll 5
-                    for (int q = 0; q < CHUNKS; q += 2, gsrc += 2048, ldst += 2048) {
-                        const void __attribute__((address_space(1))) *gp = (const void __attribute__((address_space(1))) *)gsrc;
-                        void __attribute__((address_space(3))) *lp = (void __attribute__((address_space(3))) *)ldst;
-                        switch (rp.ring_policy >> 2) {   // cache policy of the fill: 0 nt, 1 sc1, 2 sc1 nt, 3 default
-                            case 1: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 16); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 16); break;
-                            case 2: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 18); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 18); break;
-                            case 3: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0); break;
-                            default: __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2); __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2); break;
-                        }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): landed
-                }
-            } else {
-                const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
-                if (it == 1) load_regs(g);   // later groups: fetched during the previous round
-                pid = g * SEED_COLS + half * SEED_LANES + colr;
-                const bool in_range = pid < paths;
-                const uint32_t item = (uint32_t)((in_range ? pid : paths - 1) >> 6), j = (uint32_t)((in_range ? pid : paths - 1) & 63u);
-                uint32_t tile = item / rp.num_k;
-                uint32_t px, py, sub;
-                tile_lane_pixel(rp, tile, j, px, py, sub);
-                valid = in_range && px < rp.width && py < rp.height;
-                m.col = reinterpret_cast<u64 *>(lds_half) + colr;
-                HR_STAMP(0);
-                if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
-                u64 st16[16];
-#pragma unroll
-                for (int q = 0; q < 8; q++) { st16[2 * q] = st16v[q].x; st16[2 * q + 1] = st16v[q].y; }
-                if (lane < (uint32_t)SEED_LANES) isaac_init_back<SEED_SPLIT>(m, st16);
-                HR_STAMP(2);
-            }
-            __syncthreads();   // B
-            if (consumer) {
-                HR_STAMP(3);
-                if (it < G1 - G0) load_regs(G0 + it);   // group G0 + it has been complete since barrier A; used after this round
-            }
-        }
-        // ---- producers: complete group G0 + it + 1 in the ring (one group of slack: see load_regs above)
-        const uint64_t need = (G0 + it + 2) * SEED_COLS;      // paths below `need` (clipped to this workgroup's range) must be in the ring
-        uint32_t n = 0;
-        while (frontier < need && frontier < end_path) {
-            if (!consumer && (n & 1u) == half) {
-                const uint64_t pid0 = frontier + lane;
-                const bool on = pid0 >= first_path && pid0 < end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
-                const uint64_t ppid = pid0 >= first_path && pid0 < end_path ? pid0 : end_path - 1;
-                const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
-                uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
-                uint32_t px, py, sub;
-                tile_lane_pixel(rp, tile, j, px, py, sub);
-                bool pvalid = px < rp.width && py < rp.height;
-                u64 s, t;
-                path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
-                const uint64_t g = ppid / SEED_COLS;
-                const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS);
-                RingState<SEED_SPLIT> out(ring_wg + (g & (SEED_RING_GROUPS - 1)) * SEED_GROUP_WORDS + (c80 >= (uint32_t)SEED_LANES ? SEED_HALF_WORDS : 0), c80 % SEED_LANES,
-                              on, lane, rp.ring_policy & 3u);
-                isaac_init_front<SEED_SPLIT>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
-            }
-            frontier += 64;
-            n++;
-        }
-        // ---- consumers: the round of group G0 + it - 1
-        if (consumer && it > 0) {
-            RecStore rs(recs, pid);
-            RecordTail<RecStore> lt(rs, lens_shape);
-            if (lane < (uint32_t)SEED_LANES) {
-                isaac_round<REC_DRAWS>(m, lt);
-                lt.finish();
-            }
-            HR_STAMP(4);
-            ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count);
-            HR_STAMP(5);
-            if (PROF) pc[7]++;
-        }
-        __syncthreads();   // A: group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
-        if (consumer && it > 0) HR_STAMP(6);
-    }
-#undef HR_STAMP
-    if (PROF && consumer && lane == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
-    if (consumer) {
-        const bool lane_on = lane < (uint32_t)SEED_LANES;
-        const uint32_t l40 = lane_on ? lane : 0u;
-        seed_fixup_wave(rp, lens_shape, LdsHalfMem{reinterpret_cast<u64 *>(smem + (size_t)half * SEED_LDS_HALF_BYTES) + l40}, l40, lane_on, ovf_list, ovf_count,
-                        win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
-    }
+    PcRange r;
+    r.paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t groups = (r.paths + SEED_COLS - 1) / SEED_COLS;
+    r.G0 = groups * blockIdx.x / gridDim.x; r.G1 = groups * (blockIdx.x + 1) / gridDim.x;   // this workgroup's groups
+    r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
+    r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
+    if (consumer) seed_pc_consumer<SEED_SPLIT, PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
+    else seed_pc_producer<SEED_SPLIT>(rp, r, smem, lane, half);
 }
 
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p

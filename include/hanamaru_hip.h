@@ -200,7 +200,7 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH, 2 = PLOC (agglomerative, tree quality of the host build) built on
  * the device — replaces the reference's CPU build of bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
  * cuts the SAH cost by more than 7 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
- * "ring_policy" (cache policy of the seed kernel's ring stores / fill), "node_unroll" (1 | 2 node visits per pass of the box phase),
+ * "node_unroll" (1 | 2 node visits per pass of the box phase),
  * "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
  * "debug_skip" (bit mask that drops parts of the pipeline for timing experiments — the image is garbage) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);

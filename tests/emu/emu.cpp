@@ -29,7 +29,7 @@ struct ArrMem {
     uint32_t off(int i) const { return (uint32_t)i; }
     u64 ldo(uint32_t o) const { return m[o]; }
     void st(int i, u64 v) { m[i] = v; }
-    void st2(int i, u64 v0, u64 v1) { m[i] = v0; m[i + 1] = v1; }
+    void st8(int i, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) { m[i] = A; m[i + 1] = B; m[i + 2] = C; m[i + 3] = D; m[i + 4] = E; m[i + 5] = F; m[i + 6] = G; m[i + 7] = H; }
 };
 // one hand-off record (device_scene.h) and a window of raw outputs for the fix-up path
 struct ArrRec {   // lane 0 of a one-item block in the device layout [quad][64 lanes][4]
@@ -72,7 +72,7 @@ struct RawTailPc { uint64_t *out; int window; void put(int step, u64 v) { int k 
 // continues from, isaac_init_back does the rest), then isaac_round
 struct TailSink {
     u64 m[256]; u64 end[16];
-    void st2(int i, u64 v0, u64 v1) { m[i] = v0; m[i + 1] = v1; }
+    void st8(int i, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) { m[i] = A; m[i + 1] = B; m[i + 2] = C; m[i + 3] = D; m[i + 4] = E; m[i + 5] = F; m[i + 6] = G; m[i + 7] = H; }
     void end2(int j, u64 v0, u64 v1) { end[j] = v0; end[j + 1] = v1; }
 };
 template <int HEAD>
