@@ -15,10 +15,13 @@ python bench.py > $OUT/${TAG}_bench_full_unprofiled.json.log 2>> $OUT/bench_full
 python bench.py --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres.json.log 2>> $OUT/bench_full.err
 python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --steps 8 --warmup 1 --spp-per-step 4 --no-cpu-baseline > $OUT/${TAG}_bench_c5_4k_dodeca.json.log 2>> $OUT/bench_full.err
 python bench.py --bvh-builder 1 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_lbvh.json.log 2>> $OUT/bench_full.err
+python bench.py --bvh-builder 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
 tools/bin/issueprobe > $OUT/${TAG}_issueprobe.txt 2>&1
 tools/bin/roundprobe2 > $OUT/${TAG}_roundprobe2.txt 2>&1
+tools/bin/roundprobe3 > $OUT/${TAG}_roundprobe3.txt 2>&1
+tools/bin/simdprobe > $OUT/${TAG}_simdprobe.txt 2>&1
 tools/prof_pmc.sh $OUT/pmc $TAG > $OUT/pmc.log 2>&1
 cp $OUT/pmc/summary.txt $OUT/${TAG}_pmc_summary.txt; cp $OUT/pmc/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
 tail -3 $OUT/pytest_gpu.log; cat $OUT/${TAG}_bench_full_unprofiled.json.log | head -c 400; echo; cat $OUT/${TAG}_bench_kernel_stats.md | head -12
