@@ -182,6 +182,9 @@ static const int LENS_FAST = 5;       // 2 * (LENS_FAST - 1 + 9) + 1 < REC_DRAWS
 static const int DRAWS_PER_PATH = 20; // what a path can consume at most (debug API)
 static const uint32_t REC_ITEM_FLOATS = 64u * REC_FLOATS;   // one item = 8 KiB
 // float index of `slot` of the path whose lane base is item * REC_ITEM_FLOATS + lane * 4
+// seed_seg_kernel: the init sweep of 32 blocks as three runs of SEG_NBLK blocks starting at blocks 0, SEG_B1, SEG_B2 (the last two
+// overlap by one block, which both write with the same values: every run has the same length, no lane is masked)
+static const int SEG_B1 = 11, SEG_B2 = 21, SEG_NBLK = 11;
 HD uint32_t rec_slot(uint32_t lane_base, uint32_t slot) { return lane_base + (slot >> 2) * 256u + (slot & 3u); }
 
 struct Counters {

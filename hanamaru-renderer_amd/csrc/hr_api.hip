@@ -206,6 +206,8 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<28>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
     // The seed kernel owns all 160 KiB of a CU's LDS and runs next to the trace kernel of the previous batch: a trace kernel that
     // uses ANY LDS (the compiler promotes small private arrays to LDS unless told not to, see the Makefile) could not share a CU
@@ -463,6 +465,10 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
     if (c->debug_skip & 2) {
+    } else if (c->seed_mode == 2) {
+        if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
+        if (c->seed_prof) hipLaunchKernelGGL((seed_seg_kernel<true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+        else hipLaunchKernelGGL((seed_seg_kernel<false>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
     } else if (c->seed_mode == 1) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
 #define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
@@ -859,7 +865,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
     if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
     if (k == "seed_mode") {
-        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "seed_mode must be 1 (producer / consumer waves, default) or 0 (fused kernel)");
+        if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "seed_mode must be 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
         int rc = sync_all(c);
         if (rc) return rc;
         c->seed_mode = (int)value;

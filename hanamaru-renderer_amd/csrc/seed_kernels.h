@@ -216,7 +216,8 @@ struct RingState {
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
                      "global_store_dwordx4 %0, %2, off offset:640 sc1\n\t"
                      "global_store_dwordx4 %0, %3, off offset:1280 sc1\n\t"
-                     "global_store_dwordx4 %0, %4, off offset:1920 sc1" : : "v"(dst), "v"(q0), "v"(q1), "v"(q2), "v"(q3) : "memory");
+                     "global_store_dwordx4 %0, %4, off offset:1920 sc1\n\t"
+                     "s_nop 1" : : "v"(dst), "v"(q0), "v"(q1), "v"(q2), "v"(q3) : "memory");   // s_nop: the data registers may be rewritten right after (VMEM-store-data hazard, invisible to the compiler here)
         static_assert(SEED_LANES * 8 * 2 == 640, "row pair stride of the ring");
     }
     // registers j, j + 1 (j even) of this lane's column: [j / 2][column][2] behind the shipped rows, no lane swap needed
@@ -386,6 +387,169 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
     if (consumer) seed_pc_consumer<SEED_SPLIT, PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
     else seed_pc_producer<SEED_SPLIT>(rp, r, smem, lane, half);
+}
+
+// ---- three-run seeding (option seed_mode = 2) ---------------------------------------------------------------------------------
+// Same four waves, same LDS halves, same round — but NO generator words travel through memory.  The init sweep of a group is cut
+// into three runs of SEG_NBLK blocks (device_scene.h) that are computed at the same time, in the window in which the half's LDS is
+// free, by different LANES: the mix is the same instruction stream whatever block it works on, so one wave can advance 64
+// (generator, run) pairs at once, and a consumer wave has 24 lanes to spare:
+//     consumer wave of the half   lanes 0-39: generators 0-39, run 3 (blocks 21-31)     lanes 40-63: generators 0-23, run 2 (blocks 11-21)
+//     producer wave of the half   lanes 0-39: generators 0-39, run 1 (blocks 0-10)      lanes 40-55: generators 24-39, run 2
+// Each lane starts from the 16 registers the sweep holds at its first block.  Those come from the producer wave's AHEAD pass, which
+// runs the same sweep two groups early without its stores (registers only: isaac_init_ahead) while the consumer is in its round, and
+// leaves three 128-byte states per generator in a small ring (15 KiB per half and group instead of 45 KiB + an LDS-DMA fill).
+// The window is 11 blocks long instead of 16, and the ring traffic that slows the trace kernel next door falls by two thirds.
+struct SegLayout {
+    static const size_t STATE_WORDS = (size_t)16 * SEED_LANES;   // one state of every column of a half: [8 pairs][40 columns][2] u64
+    static const size_t HALF_WORDS = 3 * STATE_WORDS;
+    static const size_t GROUP_WORDS = 2 * HALF_WORDS;
+};
+static_assert(SEED_RING_GROUPS * SegLayout::GROUP_WORDS <= SEED_RING_WORDS_MAX, "the ring allocation of the producer / consumer kernel holds it");
+struct SegStateOut {
+    u64 *base;   // &half[0][0][column][0]
+    __device__ __forceinline__ void state(int k, u64 a, u64 b, u64 c, u64 d, u64 e, u64 f, u64 g, u64 h, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 *dst = reinterpret_cast<u64x2 *>(base + (size_t)k * SegLayout::STATE_WORDS);
+        const u64x2 q[8] = {{a, b}, {c, d}, {e, f}, {g, h}, {A, B}, {C, D}, {E, F}, {G, H}};
+#pragma unroll
+        // (the compiler does not know this is a store: a VALU write to the data registers in the next slot would race with the
+        // store still reading them 16 lanes at a time — gfx9's VMEM-store-data hazard — hence the s_nop)
+        for (int j = 0; j < 8; j++) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst + j * SEED_LANES), "v"(q[j]) : "memory");
+    }
+};
+// what a lane does in the window: which generator (column of the half), which run
+struct SegLane {
+    uint32_t col, run;
+    bool on;
+};
+__device__ __forceinline__ SegLane seg_lane(bool consumer, uint32_t lane) {
+    SegLane l;
+    if (lane < (uint32_t)SEED_LANES) { l.col = lane; l.run = consumer ? 2u : 0u; l.on = true; }
+    else if (consumer) { l.col = lane - (uint32_t)SEED_LANES; l.run = 1u; l.on = true; }                 // 24 lanes: generators 0-23
+    else { l.col = lane - 16u; l.run = 1u; l.on = lane < 56u; if (!l.on) l.col = (uint32_t)SEED_LANES - 1u; }   // 16 lanes: generators 24-39
+    return l;
+}
+struct SegRegs {
+    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t v[8];
+    __device__ __forceinline__ void load(const u64 *ring_wg, uint64_t g, uint32_t half, const SegLane &l) {
+        const u64 *regs = ring_wg + (g & (SEED_RING_GROUPS - 1)) * SegLayout::GROUP_WORDS + half * SegLayout::HALF_WORDS + (size_t)l.run * SegLayout::STATE_WORDS + (size_t)l.col * 2u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
+    }
+    __device__ __forceinline__ void run(unsigned char *lds_half, const SegLane &l) const {
+        u64 st16[16];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { st16[2 * q] = v[q].x; st16[2 * q + 1] = v[q].y; }
+        const uint32_t first = l.run == 0u ? 0u : l.run == 1u ? (uint32_t)SEG_B1 : (uint32_t)SEG_B2;
+        LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + l.col + (size_t)first * 8u * SEED_LANES};
+        if (l.on) isaac_init_run<SEG_NBLK>(m, st16);
+    }
+};
+template <bool PROF>
+__device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
+                                                  float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * SEED_OVF_CAP;
+    uint32_t ovf_count = 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
+#define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
+    const SegLane sl = seg_lane(true, lane);
+    SegRegs regs;
+    const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+    unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+    LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
+    const uint64_t n_groups = r.G1 - r.G0;
+    __syncthreads();   // A of iteration 0: the states of groups G0 and G0 + 1 are in the ring
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        if (PROF) tm = __builtin_readcyclecounter();
+        const uint64_t g = r.G0 + it - 1;
+        if (it == 1) regs.load(r.ring_wg, g, half, sl);   // later groups: fetched during the previous round
+        const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
+        const bool in_range = pid < r.paths;
+        const uint32_t item = (uint32_t)((in_range ? pid : r.paths - 1) >> 6), j = (uint32_t)((in_range ? pid : r.paths - 1) & 63u);
+        uint32_t tile = item / rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        const bool valid = in_range && px < rp.width && py < rp.height;
+        HR_STAMP(0);
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
+        regs.run(lds_half, sl);                          // the window: this wave's runs of the sweep, straight into LDS
+        HR_STAMP(2);
+        __syncthreads();   // B: all three runs of every column are in
+        HR_STAMP(3);
+        if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);
+        RecStore rs(recs, pid);
+        RecordTail<RecStore> lt(rs, lens_shape);
+        if (lane < (uint32_t)SEED_LANES) {
+            isaac_round<REC_DRAWS>(m, lt);
+            lt.finish();
+        }
+        HR_STAMP(4);
+        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count);
+        HR_STAMP(5);
+        if (PROF) pc[7]++;
+        __syncthreads();   // A: the LDS is free again; the states of group G0 + it + 1 are in the ring
+        HR_STAMP(6);
+    }
+#undef HR_STAMP
+    if (PROF && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
+    const bool lane_on = lane < (uint32_t)SEED_LANES;
+    seed_fixup_wave(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
+}
+__device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half) {
+    const IsaacWarm warm = isaac_warm();
+    const SegLane sl = seg_lane(false, lane);
+    SegRegs regs;
+    unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+    const uint64_t n_groups = r.G1 - r.G0;
+    uint64_t next_group = r.G0;                              // first group whose states are not in the ring yet
+    for (uint64_t it = 0; it <= n_groups; it++) {
+        if (it > 0) {
+            if (it == 1) regs.load(r.ring_wg, r.G0, half, sl);
+            regs.run(lds_half, sl);
+            __syncthreads();   // B
+            if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);
+        }
+        // ---- ahead pass: the states of every group up to G0 + it + 1 (one group of slack, as in the producer / consumer kernel)
+        for (; next_group < r.G1 && next_group <= r.G0 + it + 1; next_group++) {
+            const uint64_t pid0 = next_group * SEED_COLS + half * SEED_LANES + (lane < (uint32_t)SEED_LANES ? lane : 0u);
+            const uint64_t ppid = pid0 < r.paths ? pid0 : r.paths - 1;
+            const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
+            uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+            uint32_t px, py, sub;
+            tile_lane_pixel(rp, tile, j, px, py, sub);
+            bool pvalid = px < rp.width && py < rp.height;
+            u64 s, t;
+            path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
+            SegStateOut out{r.ring_wg + (next_group & (SEED_RING_GROUPS - 1)) * SegLayout::GROUP_WORDS + half * SegLayout::HALF_WORDS + (size_t)(lane < (uint32_t)SEED_LANES ? lane : 0u) * 2u};
+            if (lane < (uint32_t)SEED_LANES && !(rp.pad[2] & 4u)) isaac_init_ahead<SEG_B1, SEG_B2>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+        }
+        __syncthreads();   // A
+    }
+}
+template <bool PROF = false>
+__global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
+                                                       uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
+    const bool consumer = wave < 2u;
+    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1];
+    switch (prio) {  // s_setprio takes an immediate
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+    PcRange r;
+    r.paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t groups = (r.paths + SEED_COLS - 1) / SEED_COLS;
+    r.G0 = groups * blockIdx.x / gridDim.x; r.G1 = groups * (blockIdx.x + 1) / gridDim.x;
+    r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
+    r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
+    if (consumer) seed_seg_consumer<PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
+    else seed_seg_producer(rp, r, smem, lane, half);
 }
 
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p

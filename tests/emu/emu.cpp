@@ -88,6 +88,35 @@ static void raw_draws_pc(u64 s, u64 t, uint32_t sampling, int window, uint64_t *
     isaac_round<ISAAC_TAIL>(mem, rt);
 }
 
+// the three-run form of the seed_seg_kernel: isaac_init_ahead hands out the sweep's registers at blocks 0, B1, B2; three runs of NBLK
+// blocks (the last two overlapping by one block when 3 * NBLK > 32, as in the kernel) fill the state; then isaac_round
+struct StateSink {
+    u64 st[3][16];
+    void state(int k, u64 a, u64 b, u64 c, u64 d, u64 e, u64 f, u64 g, u64 h, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) {
+        u64 v[16] = {a, b, c, d, e, f, g, h, A, B, C, D, E, F, G, H};
+        for (int i = 0; i < 16; i++) st[k][i] = v[i];
+    }
+};
+struct ShiftMem { u64 *m; void st(int i, u64 v) { m[i] = v; } };
+template <int B1, int B2, int NBLK>
+static void raw_draws_seg(u64 s, u64 t, uint32_t sampling, int window, uint64_t *out) {
+    static_assert(B1 <= NBLK && B2 <= B1 + NBLK && 32 <= B2 + NBLK, "runs cover the sweep");
+    static const IsaacWarm warm = isaac_warm();
+    StateSink sink;
+    isaac_init_ahead<B1, B2>(sink, warm, 8700304ULL, (u64)sampling, s, t);
+    ArrMem mem;
+    for (int i = 0; i < 256; i++) mem.st(i, 0xdeadbeefdeadbeefULL);
+    u64 stage[256 + 8 * NBLK];
+    const int first[3] = {0, B1, B2};
+    for (int k = 2; k >= 0; k--) {   // any order: overlapping blocks get the same values from both runs
+        ShiftMem sm{stage};
+        isaac_init_run<NBLK>(sm, sink.st[k]);
+        for (int i = 0; i < 8 * NBLK && first[k] * 8 + i < 256; i++) mem.st(first[k] * 8 + i, stage[i]);
+    }
+    RawTailPc rt{out, window};
+    isaac_round<ISAAC_TAIL>(mem, rt);
+}
+
 extern "C" {
 
 static int g_max_leaf = 4;
@@ -241,6 +270,13 @@ int emu_raw_draws_pc(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t 
         case 32: raw_draws_pc<32>(s, t, sampling, window, out); return 0;
         default: return 1;
     }
+}
+
+int emu_raw_draws_seg(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int window, uint64_t *out) {
+    u64 s, t;
+    path_seed_words(W, H, px, py, sub, s, t);
+    raw_draws_seg<SEG_B1, SEG_B2, SEG_NBLK>(s, t, sampling, window, out);
+    return 0;
 }
 
 // counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests

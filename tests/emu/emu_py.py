@@ -107,6 +107,13 @@ def raw_draws_split(w, h, x, y, sub, sampling, window=64):
     return out
 
 
+def raw_draws_seg(w, h, x, y, sub, sampling, window=64):
+    out = np.empty(window, dtype=np.uint64)
+    rc = lib().emu_raw_draws_seg(w, h, x, y, sub, sampling, window, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
 def raw_draws_pc(w, h, x, y, sub, sampling, head, window=64):
     out = np.empty(window, dtype=np.uint64)
     rc = lib().emu_raw_draws_pc(w, h, x, y, sub, sampling, window, head, out.ctypes.data)

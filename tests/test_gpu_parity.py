@@ -244,7 +244,7 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 65), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 2), ("seed_split", 10), ("bvh_builder", 3), ("rng_window", 32)]:
+    for key, bad in [("batch", 65), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 3), ("seed_split", 10), ("bvh_builder", 3), ("rng_window", 32)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
     with pytest.raises(ha.HipError):
@@ -357,7 +357,7 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
         for (w, h, s) in [(130, 71, 6), (640, 360, 9)]:   # ragged: tiles hang over the right and bottom edges; many groups per CU
             gpu.set_resolution(w, h)
             ref = None
-            for mode, head in [(0, 16), (1, 16), (1, 8), (1, 12), (1, 24)]:
+            for mode, head in [(0, 16), (1, 16), (1, 8), (1, 12), (1, 24), (2, 16)]:   # 2: the three-run kernel (no state ring)
                 gpu.set_option("seed_mode", mode)
                 gpu.set_option("seed_split", head)
                 gpu.clear()
@@ -559,13 +559,14 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
             end = begin + stride * int(rng.integers(1, 9))
             gpu.set_resolution(w, h)
             outs = []
-            for mode in (0, 1):
+            for mode in (0, 1, 2):
                 gpu.set_option("seed_mode", mode)
                 gpu.clear()
                 gpu.render(begin, end, stride)
                 outs.append(gpu.read_accumulator().astype(np.float64))
-            assert np.isfinite(outs[1]).all()
-            assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max()), (w, h, begin, end, stride)
+            for o in outs[1:]:
+                assert np.isfinite(o).all()
+                assert np.abs(outs[0] - o).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max()), (w, h, begin, end, stride)
     finally:
         gpu.set_option("seed_mode", 1)
 

@@ -70,6 +70,8 @@ def test_kernel_generator_core_matches_oracle(emu, orc):
             # producer / consumer form: the producer ships blocks >= HEAD + the pass-1 end state, the consumer redoes the rest
             for head in (0, 8, 16, 24, 32):
                 assert np.array_equal(emu.raw_draws_pc(w, h, x, y, sub, s, head, 64), ref)
+            # three-run form (seed_seg_kernel): the sweep's registers at blocks 0 / 11 / 21 computed ahead, three runs of 11 blocks
+            assert np.array_equal(emu.raw_draws_seg(w, h, x, y, sub, s, 64), ref)
 
 
 def test_kernel_lens_rejection_matches_oracle(emu, orc):
