@@ -1,6 +1,7 @@
 // hr_api.hip — the device context and the C ABI of include/hanamaru_hip.h (gfx950).  One translation unit with its kernels:
-//   seed_kernels.h   seed_pc_kernel (default: producer waves run the ISAAC-64 init in registers, consumer waves the
-//                    LDS-bound round, hand-off through a per-CU ring), seed_isaac64_kernel (fused form), seed_debug_kernel
+//   seed_kernels.h   seed_seg_kernel (default: the ISAAC-64 init sweep as three runs computed side by side from states the producer
+//                    waves work out ahead in registers, consumer waves run the LDS-bound round), seed_pc_kernel (the same roles with
+//                    a ring of generator words), seed_isaac64_kernel (fused form), seed_debug_kernel
 //   trace_kernel.h   trace_kernel — the path-tracing megakernel: persistent waves pull 4x4-pixel tiles from a global
 //                    counter, one lane per path, stackless threaded-BVH traversal in box / leaf phases, finished lanes are
 //                    refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed kernel of the NEXT
@@ -80,7 +81,7 @@ struct hr_ctx {
     uint32_t *ovf = nullptr;                 // per consumer wave: list of the paths it re-derives at the end of a launch (seed_fixup_wave)
     u64 *ovf_win = nullptr;                  // per consumer wave: raw-output window of that fix-up
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
-    u64 *ring = nullptr;                     // producer / consumer seeding: ring of group buffers, <= 640 KiB per CU
+    u64 *ring = nullptr;                     // seed kernels' hand-off ring (three-run kernel: 120 KiB per CU of 16-register states; ring kernel: <= 680 KiB per CU)
     int seed_split = 16;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24, 28)
     uint32_t init_prio = 1;                  // s_setprio of the producer waves
     hipEvent_t seed_done[2] = {nullptr, nullptr}, trace_done[2] = {nullptr, nullptr};
@@ -102,8 +103,8 @@ struct hr_ctx {
     int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH, 2 = device PLOC (gpu_bvh.h); next upload
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
-    int seed_mode = 1;                       // 1 = producer / consumer seed kernel, 0 = fused seed kernel
-    bool seed_prof = false;                  // phase timing build of the producer / consumer seed kernel (splits 16 and 20)
+    int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
+    bool seed_prof = false;                  // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)

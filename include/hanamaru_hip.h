@@ -195,7 +195,8 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* keys: "quant_nodes" (1 = the trace kernel walks the 16-byte quantised nodes of host-built trees, default; next upload),
  * "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase
  * thresholds), "min_waves" (4..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
- * "seed_mode" (1 = producer / consumer seed kernel, default; 0 = fused seed kernel), "seed_split" (8 | 12 | 16 | 20 | 24 | 28: how many
+ * "seed_mode" (2 = three-run seed kernel, default: the ISAAC-64 init sweep as three runs computed side by side from states the producer
+ * waves compute ahead in registers; 1 = producer / consumer kernel with a ring of generator words; 0 = fused seed kernel), "seed_split" (seed_mode 1 only; 8 | 12 | 16 | 20 | 24 | 28: how many
  * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
  * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH, 2 = PLOC (agglomerative, tree quality of the host build) built on
  * the device — replaces the reference's CPU build of bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it

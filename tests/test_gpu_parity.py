@@ -369,7 +369,7 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
                 else:
                     assert np.abs(ref - acc).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (w, h, mode, head)
     finally:
-        gpu.set_option("seed_mode", 1)
+        gpu.set_option("seed_mode", 2)
         gpu.set_option("seed_split", 16)
 
 
@@ -568,7 +568,7 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
                 assert np.isfinite(o).all()
                 assert np.abs(outs[0] - o).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max()), (w, h, begin, end, stride)
     finally:
-        gpu.set_option("seed_mode", 1)
+        gpu.set_option("seed_mode", 2)
 
 
 def test_cli_multi_device_in_one_process(tmp_path):

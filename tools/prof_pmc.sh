@@ -46,7 +46,7 @@ with open(out + "/summary.txt", "w") as o:
             n = max(1, len(disp[k][c]))
             o.write("   %-36s %.6g   (%d dispatches)\n" % (c, v, n))
             per[c] = v / n
-        name = "trace_kernel" if "trace_kernel" in k else ("seed_pc_kernel" if "seed_pc" in k else k.replace("void ", "").strip())
+        name = "trace_kernel" if "trace_kernel" in k else ("seed_seg_kernel" if "seed_seg" in k else "seed_pc_kernel" if "seed_pc" in k else k.replace("void ", "").strip())
         e = {}
         # FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (x2)
         if "FETCH_SIZE" in per: e["fetch_bytes_per_path"] = per["FETCH_SIZE"] * 1024 * 2.0 / PATHS
