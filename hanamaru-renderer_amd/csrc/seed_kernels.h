@@ -363,6 +363,7 @@ __device__ __forceinline__ void seed_pc_producer(const RenderParams &rp, const P
             frontier += 64;
             n++;
         }
+        __builtin_amdgcn_s_waitcnt(0);   // the ring stores are hand-written: the compiler does not wait for them at the barrier by itself
         __syncthreads();   // A
     }
 }
@@ -504,7 +505,7 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
     SegRegs regs;
     unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
     const uint64_t n_groups = r.G1 - r.G0;
-    uint64_t next_group = r.G0;                              // first group whose states are not in the ring yet
+    uint64_t frontier = r.first_path & ~63ull;               // first path whose states are not in the ring yet (chunks of 64 paths)
     for (uint64_t it = 0; it <= n_groups; it++) {
         if (it > 0) {
             if (it == 1) regs.load(r.ring_wg, r.G0, half, sl);
@@ -512,10 +513,15 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
             __syncthreads();   // B
             if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);
         }
-        // ---- ahead pass: the states of every group up to G0 + it + 1 (one group of slack, as in the producer / consumer kernel)
-        for (; next_group < r.G1 && next_group <= r.G0 + it + 1; next_group++) {
-            const uint64_t pid0 = next_group * SEED_COLS + half * SEED_LANES + (lane < (uint32_t)SEED_LANES ? lane : 0u);
-            const uint64_t ppid = pid0 < r.paths ? pid0 : r.paths - 1;
+        // ---- ahead pass: the states of every path below group G0 + it + 2 (one group of slack, as in the producer / consumer kernel),
+        //      in chunks of 64 consecutive paths — all 64 lanes busy, whatever group / half boundary a chunk straddles; the two producer
+        //      waves take alternate chunks
+        const uint64_t need = (r.G0 + it + 2) * SEED_COLS;
+        for (; frontier < need && frontier < r.end_path; frontier += 64) {
+            if (((frontier >> 6) & 1u) != half) continue;
+            const uint64_t pid0 = frontier + lane;
+            const bool on = pid0 >= r.first_path && pid0 < r.end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
+            const uint64_t ppid = pid0 >= r.first_path && pid0 < r.end_path ? pid0 : r.end_path - 1;
             const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
             uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
             uint32_t px, py, sub;
@@ -523,9 +529,12 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
             bool pvalid = px < rp.width && py < rp.height;
             u64 s, t;
             path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
-            SegStateOut out{r.ring_wg + (next_group & (SEED_RING_GROUPS - 1)) * SegLayout::GROUP_WORDS + half * SegLayout::HALF_WORDS + (size_t)(lane < (uint32_t)SEED_LANES ? lane : 0u) * 2u};
-            if (lane < (uint32_t)SEED_LANES && !(rp.pad[2] & 4u)) isaac_init_ahead<SEG_B1, SEG_B2>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
+            const uint64_t g = ppid / SEED_COLS;
+            const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS), hh = c80 >= (uint32_t)SEED_LANES ? 1u : 0u;
+            SegStateOut out{r.ring_wg + (g & (SEED_RING_GROUPS - 1)) * SegLayout::GROUP_WORDS + hh * SegLayout::HALF_WORDS + (size_t)(c80 - hh * (uint32_t)SEED_LANES) * 2u};
+            if (on) isaac_init_ahead<SEG_B1, SEG_B2>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
         }
+        __builtin_amdgcn_s_waitcnt(0);   // the state stores are hand-written: the compiler does not wait for them at the barrier by itself
         __syncthreads();   // A
     }
 }
