@@ -506,17 +506,10 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
     unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
     const uint64_t n_groups = r.G1 - r.G0;
     uint64_t frontier = r.first_path & ~63ull;               // first path whose states are not in the ring yet (chunks of 64 paths)
-    for (uint64_t it = 0; it <= n_groups; it++) {
-        if (it > 0) {
-            if (it == 1) regs.load(r.ring_wg, r.G0, half, sl);
-            regs.run(lds_half, sl);
-            __syncthreads();   // B
-            if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);
-        }
-        // ---- ahead pass: the states of every path below group G0 + it + 2 (one group of slack, as in the producer / consumer kernel),
-        //      in chunks of 64 consecutive paths — all 64 lanes busy, whatever group / half boundary a chunk straddles; the two producer
-        //      waves take alternate chunks
-        const uint64_t need = (r.G0 + it + 2) * SEED_COLS;
+    // ahead pass: the states of every path below group `upto`, in chunks of 64 consecutive paths — all 64 lanes busy, whatever group /
+    // half boundary a chunk straddles; the two producer waves take alternate chunks
+    auto ahead = [&](uint64_t upto) {
+        const uint64_t need = upto * SEED_COLS;
         for (; frontier < need && frontier < r.end_path; frontier += 64) {
             if (((frontier >> 6) & 1u) != half) continue;
             const uint64_t pid0 = frontier + lane;
@@ -535,6 +528,16 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
             if (on) isaac_init_ahead<SEG_B1, SEG_B2>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t);
         }
         __builtin_amdgcn_s_waitcnt(0);   // the state stores are hand-written: the compiler does not wait for them at the barrier by itself
+    };
+    // iteration 0: the states of groups G0 and G0 + 1 (one group of slack, as in the producer / consumer kernel)
+    ahead(r.G0 + 2);
+    __syncthreads();   // A
+    if (n_groups >= 1) regs.load(r.ring_wg, r.G0, half, sl);
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        regs.run(lds_half, sl);          // the window
+        __syncthreads();   // B
+        if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);   // for the next window; complete in the ring since the last barrier A
+        ahead(r.G0 + it + 2);
         __syncthreads();   // A
     }
 }
