@@ -23,6 +23,7 @@ def lib():
         L.emu_raw_draws.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws_split.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_raw_draws_pc.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.c_void_p]
+        L.emu_raw_draws_seg.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
