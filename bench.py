@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--seed-prio", type=int, default=-1)
+    ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 / 1 = fixed")
     ap.add_argument("--init-prio", type=int, default=-1)
     ap.add_argument("--seed-split", type=int, default=-1)
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
@@ -166,6 +167,8 @@ def main():
         r.set_option("node_unroll", args.node_unroll)
     if args.seed_mode >= 0:
         r.set_option("seed_mode", args.seed_mode)
+    if args.trace_boost >= -1:
+        r.set_option("trace_boost", args.trace_boost)
     if args.seed_prio >= 0:
         r.set_option("seed_prio", args.seed_prio)
     if args.max_tail_gib:

@@ -97,6 +97,9 @@ struct hr_ctx {
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
+    int trace_boost = -1;                    // box phase of the trace kernel above the producer waves: -1 = governed by the measured kernel times (default), 0 / 1 = fixed
+    bool boost_now = true;                   // the governor's current choice
+    size_t gov_next = 0;                     // first launch (index into seed_events / trace_events) the governor has not looked at
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
@@ -132,7 +135,21 @@ static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
     *out = reinterpret_cast<const T *>(d);
     return HR_OK;
 }
+// Priority governor (see hr_render): lean towards the slower kernel of a finished launch, 3 % hysteresis
+static void govern(hr_ctx *c, float seed_ms, float trace_ms) {
+    if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0)) return;
+    if (c->boost_now && seed_ms > 1.03f * trace_ms) c->boost_now = false;
+    else if (!c->boost_now && trace_ms > 1.03f * seed_ms) c->boost_now = true;
+}
 static int drain_events(hr_ctx *c) {
+    {   // the lists about to be emptied still have something to tell the governor: the launch before the last one (the last trace
+        // kernel had the chip to itself, the first seed kernel too)
+        const size_t n = std::min(c->seed_events.size(), c->trace_events.size());
+        float sm = 0, tm = 0;
+        if (n >= 3 && n - 2 >= c->gov_next && hipEventElapsedTime(&sm, c->seed_events[n - 2].a, c->seed_events[n - 2].b) == hipSuccess &&
+            hipEventElapsedTime(&tm, c->trace_events[n - 2].a, c->trace_events[n - 2].b) == hipSuccess)
+            govern(c, sm, tm);
+    }
     auto sum = [](std::vector<EventPair> &ev, double &acc) -> hipError_t {
         for (auto &e : ev) {
             float ms = 0;
@@ -148,6 +165,7 @@ static int drain_events(hr_ctx *c) {
     HIP_TRY(sum(c->seed_events, c->seed_ms));
     HIP_TRY(sum(c->trace_events, c->trace_ms));
     HIP_TRY(sum(c->post_events, c->post_ms));
+    c->gov_next = 0;
     return HR_OK;
 }
 static int sync_all(hr_ctx *c) {
@@ -508,9 +526,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.stride = stride;
     rp.adv_den = c->adv_den;
     rp.leaf_den = c->leaf_den;
-    rp.node_unroll = c->node_unroll; rp.ring_policy = 0; rp.kchunk = c->kchunk;
+    rp.node_unroll = c->node_unroll; rp.kchunk = c->kchunk;
     rp.pad[0] = c->seed_prio;
-    rp.pad[1] = c->init_prio;
     rp.pad[2] = (uint32_t)c->debug_skip;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     // the hand-off costs 8 KiB per (tile, sampling): keep each of the two buffers under max_tail_bytes
@@ -532,6 +549,24 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         rp.num_k = nk;
         int slot = (int)(c->batch_counter & 1);
         c->batch_counter++;
+        // Priority governor: the two kernels share every SIMD, and which of them should win the issue slots of the producers'
+        // SIMDs depends on which is the slower one on this scene.  Look at the newest launch whose seed and trace kernel have both
+        // finished and lean towards the slower kernel (3 % hysteresis).  Results do not depend on it.
+        if (c->trace_boost < 0) {
+            const size_t n = std::min(c->seed_events.size(), c->trace_events.size());
+            if (c->gov_next > n) c->gov_next = 0;   // the lists were drained
+            for (size_t j = n > 0 ? n - 1 : 0; j-- > c->gov_next;) {   // not the newest launch: its trace kernel may have run alone
+                if (hipEventQuery(c->seed_events[j].b) != hipSuccess || hipEventQuery(c->trace_events[j].b) != hipSuccess) continue;
+                float sm = 0, tm = 0;
+                if (hipEventElapsedTime(&sm, c->seed_events[j].a, c->seed_events[j].b) == hipSuccess &&
+                    hipEventElapsedTime(&tm, c->trace_events[j].a, c->trace_events[j].b) == hipSuccess)
+                    govern(c, sm, tm);
+                c->gov_next = j + 1;
+                break;
+            }
+        } else c->boost_now = c->trace_boost != 0;
+        rp.trace_boost = c->boost_now ? 1u : 0u;
+        rp.pad[1] = c->boost_now ? 0u : c->init_prio;   // the producer waves step below the boosted box phase
         hipStream_t sstream = c->seed_stream;  // (alternating two seed streams to overlap kernel tails was measured: no gain)
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(sstream, c->trace_done[slot], 0));
@@ -825,6 +860,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     if (k == "min_waves") {
         if (value < 4 || value > 6) return fail(HR_ERR_INVALID, "min_waves must be in [4,6]");
         c->min_waves = (int)value;
+        return HR_OK;
+    }
+    if (k == "trace_boost") {
+        if (value != -1 && value != 0 && value != 1) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times), 0 or 1");
+        c->trace_boost = (int)value;
         return HR_OK;
     }
     if (k == "kchunk") {

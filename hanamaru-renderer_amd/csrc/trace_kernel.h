@@ -123,6 +123,11 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
             const uint32_t walk_max = n_trav - park;
             HR_PHASE_BEGIN();
+            // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
+            // box pass is the trace kernel's critical loop.  Switched by the host from the measured times of the two kernels
+            // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
+            // and costs ~1 % when the seed kernel is.
+            if (rp.trace_boost) __builtin_amdgcn_s_setprio(1);
             for (;;) {
                 // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
                 const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                     }
                 }
             }
+            if (rp.trace_boost) __builtin_amdgcn_s_setprio(0);
             HR_PHASE_END(2);
             HR_PHASE_BEGIN();
             if (CNT) {

@@ -202,7 +202,8 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  * the device — replaces the reference's CPU build of bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
  * cuts the SAH cost by more than 7 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
  * "node_unroll" (1 | 2 node visits per pass of the box phase),
- * "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
+ * "trace_boost" (-1 = the library decides from the measured kernel times whether the trace kernel's box phase runs above the seed kernel's
+ * producer waves, default; 0 / 1 = fixed), "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
  * "debug_skip" (bit mask that drops parts of the pipeline for timing experiments — the image is garbage) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
 
