@@ -317,11 +317,11 @@ def main():
         # The other kernel of the pair: per-path ISAAC-64 seeding.  Bound neither by HBM nor by MFMA but by how fast ONE wave can
         # issue: the LDS holds 80 generator states per CU (2 KiB each), two consumer waves of 40 lanes run their rounds, and a
         # lone wave issues one instruction per ~4.5 cycles (LDS reads ~8, LDS writes ~16: tools/issueprobe.hip).  Ceiling =
-        # 80 states / (256 round steps x ~110 cycles + 11 init blocks x ~510 cycles at 2.4 GHz = 14.1 us) x 256 CUs.
+        # 80 states / (256 round steps x ~101 cycles of issue + 11 init blocks x ~510 cycles at 2.4 GHz = 13.2 us) x 256 CUs.
         seed_ms = st["seed_kernel_ms"] / max(1, st["seed_launches"])
         if seed_ms > 0:
             seed_rate = paths_per_launch / (seed_ms * 1e-3) / 1e6
-            ceiling = 80.0 / 14.1e-6 * 256 / 1e6
+            ceiling = 80.0 / 13.2e-6 * 256 / 1e6
             out["seed_kernel"] = {"kernel": "seed_seg_kernel", "bound": "lds_capacity_x_single_wave_issue_rate", "avg_launch_ms": round(seed_ms, 4),
                                   "achieved": round(seed_rate, 1), "peak": round(ceiling, 1), "unit": "Mpaths/s", "frac": round(seed_rate / ceiling, 4)}
 
