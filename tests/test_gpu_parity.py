@@ -373,6 +373,28 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
         gpu.set_option("seed_split", 16)
 
 
+def test_priority_governor_does_not_change_results(gpu, scenes):
+    """Option trace_boost (the trace kernel's box phase above the seed kernel's producer waves; -1 = decided from the measured kernel
+    times) only moves issue slots between the two kernels: the accumulator is the same up to the atomics' summation order."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(320, 180)
+    outs = []
+    try:
+        for boost in (0, 1, -1):
+            gpu.set_option("trace_boost", boost)
+            gpu.clear()
+            gpu.render(1, 13)
+            outs.append(gpu.read_accumulator().astype(np.float64))
+        with pytest.raises(Exception):
+            gpu.set_option("trace_boost", 2)
+    finally:
+        gpu.set_option("trace_boost", -1)
+    assert outs[0].sum() > 0
+    for o in outs[1:]:
+        assert np.abs(outs[0] - o).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max())
+
+
 def test_bench_multirank_path_on_one_gpu(tmp_path):
     """bench.py's N > 1 code path (sharding by sampling index, accumulate into a torch tensor, one all-reduce) run as two
     ranks on ONE GPU (HR_BENCH_ONE_DEVICE: gloo on a host copy, RCCL refuses two ranks per device): the summed accumulator
