@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
     ap.add_argument("--seed-mode", type=int, default=-1)
     ap.add_argument("--seed-prio", type=int, default=-1)
-    ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 / 1 = fixed")
+    ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 / 1 / 2 = fixed level")
     ap.add_argument("--init-prio", type=int, default=-1)
     ap.add_argument("--seed-split", type=int, default=-1)
     ap.add_argument("--max-tail-gib", type=float, default=0.0)

@@ -151,7 +151,7 @@ struct RenderParams {
     uint32_t adv_den;                 // trace kernel: leave the traversal loop when 1/adv_den of the live lanes are done
     uint32_t leaf_den;                // trace kernel: run the leaf phase when 1/leaf_den of the traversing lanes parked a leaf
     uint32_t pad[3];                  // seed kernel: [0] s_setprio of the consumer waves, [1] of the producer waves, [2] debug_skip bits
-    uint32_t trace_boost;             // trace kernel: 1 = its box phase runs at priority 1, above the seed kernel's producer waves (hr_api.hip sets it from measured kernel times)
+    uint32_t trace_boost;             // trace kernel: 1 = its box phase, 2 = box and leaf phases run at priority 1, above the seed kernel's producer waves (hr_api.hip sets it from measured kernel times)
     uint32_t node_unroll;             // trace kernel: node fetches per pass of the box-phase loop (1 or 2)
     uint32_t kchunk;                  // trace kernel: samplings per work unit (0 = 4)
 };

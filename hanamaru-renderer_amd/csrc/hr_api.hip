@@ -97,8 +97,9 @@ struct hr_ctx {
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
-    int trace_boost = -1;                    // box phase of the trace kernel above the producer waves: -1 = governed by the measured kernel times (default), 0 / 1 = fixed
-    bool boost_now = true;                   // the governor's current choice
+    int trace_boost = -1;                    // trace-kernel phases above the producer waves: -1 = governed by the measured kernel times (default), 0 / 1 (box phase) / 2 (box and leaf phases) = fixed
+    int boost_now = 1;                       // the governor's current level
+    float gov_known[3] = {0, 0, 0};          // per level: smoothed max(seed, trace) ms of the launches measured at it (0 = not tried on this scene / size)
     size_t gov_next = 0;                     // first launch (index into seed_events / trace_events) the governor has not looked at
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     int max_leaf = 4;                        // BVH leaf size (next upload)
@@ -135,12 +136,22 @@ static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
     *out = reinterpret_cast<const T *>(d);
     return HR_OK;
 }
-// Priority governor (see hr_render): lean towards the slower kernel of a finished launch, 3 % hysteresis
+// Priority governor (see hr_render).  Three levels (trace kernel's box phase / box and leaf phases above the producer waves).
+// A finished launch says how long the slower of the two kernels took at the current level; an untried neighbouring level is tried
+// when the balance asks for it (trace kernel more than 3 % behind -> up, seed kernel -> down), otherwise the best level known wins.
 static void govern(hr_ctx *c, float seed_ms, float trace_ms) {
     if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0)) return;
-    if (c->boost_now && seed_ms > 1.03f * trace_ms) c->boost_now = false;
-    else if (!c->boost_now && trace_ms > 1.03f * seed_ms) c->boost_now = true;
+    const int L = c->boost_now;
+    const float m = std::max(seed_ms, trace_ms);
+    c->gov_known[L] = c->gov_known[L] > 0 ? 0.5f * (c->gov_known[L] + m) : m;
+    if (trace_ms > 1.03f * seed_ms && L < 2 && c->gov_known[L + 1] == 0) { c->boost_now = L + 1; return; }
+    if (seed_ms > 1.03f * trace_ms && L > 0 && c->gov_known[L - 1] == 0) { c->boost_now = L - 1; return; }
+    int best = L;
+    for (int k = 0; k < 3; k++)
+        if (c->gov_known[k] > 0 && c->gov_known[k] < 0.995f * c->gov_known[best]) best = k;
+    c->boost_now = best;
 }
+static void govern_reset(hr_ctx *c) { c->gov_known[0] = c->gov_known[1] = c->gov_known[2] = 0; if (c->trace_boost < 0) c->boost_now = 1; }
 static int drain_events(hr_ctx *c) {
     {   // the lists about to be emptied still have something to tell the governor: the launch before the last one (the last trace
         // kernel had the chip to itself, the first seed kernel too)
@@ -400,6 +411,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     }
     c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
     c->have_scene = true;
+    govern_reset(c);   // another scene: the balance of the two kernels is another one
     return HR_OK;
 }
 
@@ -423,6 +435,7 @@ int hr_set_resolution(hr_ctx *c, uint32_t w, uint32_t h) {
     HIP_TRY(hipMalloc((void **)&c->d_rgb8, n));
     c->W = w; c->H = h;
     c->accum = c->accum_own;
+    govern_reset(c);
     return HR_OK;
 }
 
@@ -564,9 +577,9 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
                 c->gov_next = j + 1;
                 break;
             }
-        } else c->boost_now = c->trace_boost != 0;
-        rp.trace_boost = c->boost_now ? 1u : 0u;
-        rp.pad[1] = c->boost_now ? 0u : c->init_prio;   // the producer waves step below the boosted box phase
+        } else c->boost_now = c->trace_boost;
+        rp.trace_boost = (uint32_t)c->boost_now;
+        rp.pad[1] = c->boost_now ? 0u : c->init_prio;   // the producer waves step below the boosted phases
         hipStream_t sstream = c->seed_stream;  // (alternating two seed streams to overlap kernel tails was measured: no gain)
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(sstream, c->trace_done[slot], 0));
@@ -863,8 +876,9 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "trace_boost") {
-        if (value != -1 && value != 0 && value != 1) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times), 0 or 1");
+        if (value != -1 && value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times), 0, 1 or 2");
         c->trace_boost = (int)value;
+        govern_reset(c);
         return HR_OK;
     }
     if (k == "kchunk") {

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
             // box pass is the trace kernel's critical loop.  Switched by the host from the measured times of the two kernels
             // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
-            // and costs ~1 % when the seed kernel is.
+            // and costs ~1 % when the seed kernel is.  Level 2 adds the leaf phase (another +1 - 2 % where the trace kernel is far behind).
             if (rp.trace_boost) __builtin_amdgcn_s_setprio(1);
             for (;;) {
                 // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             if (rp.trace_boost) __builtin_amdgcn_s_setprio(0);
             HR_PHASE_END(2);
             HR_PHASE_BEGIN();
+            if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(1);   // level 2: the leaf phase too
             if (CNT) {
                 uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
                 if (n) { ph[4]++; ph[5] += n; }
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 p.ts.leaf2 = 0;
                 shadow_early_out(p);
             }
+            if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(0);
             HR_PHASE_END(3);
         }
     }

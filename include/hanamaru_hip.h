@@ -203,7 +203,7 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  * cuts the SAH cost by more than 7 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
  * "node_unroll" (1 | 2 node visits per pass of the box phase),
  * "trace_boost" (-1 = the library decides from the measured kernel times whether the trace kernel's box phase runs above the seed kernel's
- * producer waves, default; 0 / 1 = fixed), "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
+ * producer waves, and whether its leaf phase does too, default; 0 / 1 / 2 = fixed level), "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
  * "debug_skip" (bit mask that drops parts of the pipeline for timing experiments — the image is garbage) */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
 

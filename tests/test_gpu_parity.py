@@ -381,13 +381,13 @@ def test_priority_governor_does_not_change_results(gpu, scenes):
     gpu.set_resolution(320, 180)
     outs = []
     try:
-        for boost in (0, 1, -1):
+        for boost in (0, 1, 2, -1):
             gpu.set_option("trace_boost", boost)
             gpu.clear()
             gpu.render(1, 13)
             outs.append(gpu.read_accumulator().astype(np.float64))
         with pytest.raises(Exception):
-            gpu.set_option("trace_boost", 2)
+            gpu.set_option("trace_boost", 3)
     finally:
         gpu.set_option("trace_boost", -1)
     assert outs[0].sum() > 0
