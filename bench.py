@@ -6,19 +6,31 @@
 Workload (config.workload): the reference's live scene `rtcamp6_v3_1` at 1920x1080.  One STEP = one
 hr_render() call of `--spp-per-step` samplings (default 16, launched 4 at a time) of the whole image on every GPU
 = 16 x 1920 x 1080 x 4 camera paths per GPU.  The default K = 64 steps is exactly BASELINE's 1920x1080 x 1024 samplings on one GPU.
-With N GPUs the sampling indices are sharded round-robin ((s-1) mod N == rank, one process per GPU), every
-GPU still renders `spp-per-step` samplings per step (weak scaling), and the fp32 radiance accumulators are
-summed with ONE all-reduce (RCCL) inside the timed region.  Inputs (scene, textures) are resident in HBM
-before the timed region; nothing is skipped inside it (seed kernel + trace kernel + accumulation).
+With N GPUs the sampling indices are sharded round-robin ((s-1) mod N == rank), every GPU still renders `spp-per-step`
+samplings per step (weak scaling), and the fp32 radiance accumulators are summed with ONE all-reduce inside the timed region.
+Inputs (scene, textures) are resident in HBM before the timed region; nothing is skipped inside it (seed kernel + trace
+kernel + accumulation + the all-reduce).
+
+Two ways to run N > 1, the same library calls underneath:
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, WORLD_SIZE set): one process
+    per GPU, hr_comm_init_rank + hr_allreduce_accumulator = ncclAllReduce (RCCL) inside libhanamaru_hip.so; torch.distributed
+    only carries the ncclUniqueId, the barriers and the max over ranks;
+  * without a launcher (`python bench.py --gpus N ...`): ONE process drives N contexts (hr_render only enqueues; one host thread
+    keeps N GPUs busy), hr_comm_init_local + hr_allreduce_accumulators = one RCCL group all-reduce over the N devices.  On a box
+    with fewer than N GPUs all contexts share device 0 and the library sums them with a kernel on that device (RCCL wants one
+    rank per device) — labelled in config.parallelism; that is the path the 1-GPU test tier exercises.
 
 Extra objects on the JSON line:
-  roofline     — trace kernel: algorithmic bytes per launch (32 B/node test, 36 B/triangle test,
-                 16 B/sphere, 24 B/cuboid, counted by an instrumented run of the same kernel on the same seeds)
-                 divided by the kernel's mean launch duration (HIP events on its stream), vs 8 TB/s HBM peak.
+  roofline     — trace kernel: bytes its lanes load for the tests it performs (counted by an instrumented run of the same kernel
+                 on the same seeds: 16 B per node visit on the quantised records, 48 B per triangle, 16 B per sphere, 32 B per
+                 cuboid) divided by the kernel's mean launch duration (HIP events on its stream), vs 8 TB/s HBM peak; next to it
+                 SURVEY.md §8(d)'s normalised figure (32 / 36 / 16 / 24 B), the traversal section's share, the traversal-only
+                 workload (hr_render_debug, Depth mode) and the PMC view of what physically bounds the kernel.
   cpu_baseline — the CPU oracle (f64 restatement of the reference path, oracle/) timed on this box's host cores
                  on a bounded sample; reported, not optimised.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,6 +41,10 @@ sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0  # same guide: aggregate L2 bandwidth
+# ceiling of the seed kernel: 80 generator states per CU, each resident for one window of 11 init blocks
+# (~510 cycles each) plus 256 round steps whose serial chain is one dependent LDS gather (72 cycles) + four dependent issue
+# slots of a lone wave (~101 cycles per step) = 31.5 k cycles = 13.1 us at 2.4 GHz
+SEED_CEILING_US_PER_GROUP = 13.2
 
 
 def usable_cpus():
@@ -57,6 +73,16 @@ def usable_cpus():
     return n, (os.cpu_count() or 1), quota
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources: a PMC summary taken on other kernels is reported as stale."""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "hanamaru-renderer_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def latest_pmc_traffic():
     """profiles/rNN_pmc_traffic.json of the newest round (written by tools/prof_pmc.sh), or None."""
     import glob
@@ -81,23 +107,16 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--batch", type=int, default=0, help="samplings per kernel launch (0 = the library's automatic choice: 4 at 1080p)")
     ap.add_argument("--scene", default="rtcamp6_v3_1")
-    ap.add_argument("--adv-den", type=int, default=0, help="trace kernel early-exit denominator (0 = library default)")
-    ap.add_argument("--leaf-den", type=int, default=0)
-    ap.add_argument("--min-waves", type=int, default=0)
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH, 2 = device PLOC")
     ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
-    ap.add_argument("--seed-mode", type=int, default=-1)
-    ap.add_argument("--seed-prio", type=int, default=-1)
     ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 / 1 / 2 = fixed level")
-    ap.add_argument("--init-prio", type=int, default=-1)
-    ap.add_argument("--seed-split", type=int, default=-1)
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
-    ap.add_argument("--trace-wgs", type=int, default=0, help="trace-kernel workgroups per CU (0 = library default)")
     ap.add_argument("--quant-nodes", type=int, default=-1)
-    ap.add_argument("--kchunk", type=int, default=0)
-    ap.add_argument("--node-unroll", type=int, default=0)
-    ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: skip seeding kernels after the warm-up (image is garbage)")
+    ap.add_argument("--russian-roulette", type=int, default=0, help="NOT the reference's estimator: first iteration that plays (0 = off, default)")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
+                    help="measurement knob of hr_set_debug_option (adv_den, leaf_den, min_waves, kchunk, node_unroll, trace_wgs, seed_mode, seed_split, seed_prio, init_prio)")
+    ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: drop parts of the pipeline after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -107,148 +126,173 @@ def main():
     import hanamaru_amd as ha
     from hanamaru_amd.sharding import step_range
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    # HR_BENCH_ONE_DEVICE=1 is a debugging aid for boxes with a single GPU: every rank uses cuda:0 and the
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    launcher = env_world > 1
+    rank = int(os.environ.get("RANK", "0")) if launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launcher else 0
+    world = env_world if launcher else max(1, args.gpus)
+    # HR_BENCH_ONE_DEVICE=1 is a debugging aid for the launcher path on boxes with a single GPU: every rank uses cuda:0 and the
     # collective runs over gloo on a host copy (RCCL refuses two ranks on one device).  Never set by the driver.
-    one_device = os.environ.get("HR_BENCH_ONE_DEVICE") == "1"
+    one_device = launcher and os.environ.get("HR_BENCH_ONE_DEVICE") == "1"
     dist = None
-    if world > 1:
+    if launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if one_device else "nccl", rank=rank, world_size=world)
     if one_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    def all_reduce_(t, op):
-        if one_device:
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=op)
-
-    # The accumulators are summed by the LIBRARY (hr_allreduce_accumulator: ncclAllReduce on the device accumulator, RCCL loaded
-    # by libhanamaru_hip.so); torch.distributed only carries the ncclUniqueId to the ranks, the barriers and the max over ranks.
-    lib_rccl = dist is not None and not one_device
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # the contexts this process drives: (global rank, device)
+    if launcher:
+        mine = [(rank, local_rank)]
+        how = "gloo on a host copy: HR_BENCH_ONE_DEVICE debugging aid" if one_device else "one process per GPU, ncclAllReduce (RCCL) inside libhanamaru_hip.so"
+    elif world == 1:
+        mine = [(0, 0)]
+        how = "single rank"
+    elif ndev >= world:
+        mine = [(r, r) for r in range(world)]
+        how = "one process drives %d GPUs, one RCCL group all-reduce (hr_allreduce_accumulators) inside libhanamaru_hip.so" % world
+    else:
+        mine = [(r, 0) for r in range(world)]
+        how = "FALLBACK: %d contexts share device 0 (the box has %d GPU), summed by the library's kernel on that device instead of RCCL" % (world, ndev)
+    torch.cuda.set_device(mine[0][1])
+    dev = torch.device("cuda", mine[0][1])
 
     W, H, SPS = args.width, args.height, args.spp_per_step
     scene = ha.Scene(args.scene)
-    r = ha.Renderer(local_rank)
-    if args.max_leaf:
-        r.set_option("max_leaf", args.max_leaf)
-    if args.bvh_builder:
-        r.set_option("bvh_builder", args.bvh_builder)
-    if args.quant_nodes >= 0:
-        r.set_option("quant_nodes", args.quant_nodes)
-    if args.split_ratio is not None:
-        r.set_option("split_ratio", args.split_ratio)
-    r.upload_scene(scene)
-    r.set_resolution(W, H)
-    r.set_option("batch", args.batch)
-    if args.adv_den:
-        r.set_option("adv_den", args.adv_den)
-    if args.leaf_den:
-        r.set_option("leaf_den", args.leaf_den)
-    if args.min_waves:
-        r.set_option("min_waves", args.min_waves)
-    if args.trace_wgs:
-        r.set_option("trace_wgs", args.trace_wgs)
-    if args.kchunk:
-        r.set_option("kchunk", args.kchunk)
-    if args.node_unroll:
-        r.set_option("node_unroll", args.node_unroll)
-    if args.seed_mode >= 0:
-        r.set_option("seed_mode", args.seed_mode)
-    if args.trace_boost >= -1:
-        r.set_option("trace_boost", args.trace_boost)
-    if args.seed_prio >= 0:
-        r.set_option("seed_prio", args.seed_prio)
-    if args.max_tail_gib:
-        r.set_option("max_tail_gib", args.max_tail_gib)
-    if args.seed_split >= 0:
-        r.set_option("seed_split", args.seed_split)
-    if args.init_prio >= 0:
-        r.set_option("init_prio", args.init_prio)
-    acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    r.bind_accumulator(acc.data_ptr())
+    rs = []
+    for _, d in mine:
+        r = ha.Renderer(d)
+        if args.max_leaf:
+            r.set_option("max_leaf", args.max_leaf)
+        if args.bvh_builder:
+            r.set_option("bvh_builder", args.bvh_builder)
+        if args.quant_nodes >= 0:
+            r.set_option("quant_nodes", args.quant_nodes)
+        if args.split_ratio is not None:
+            r.set_option("split_ratio", args.split_ratio)
+        r.upload_scene(scene)
+        r.set_resolution(W, H)
+        r.set_option("batch", args.batch)
+        if args.trace_boost >= -1:
+            r.set_option("trace_boost", args.trace_boost)
+        if args.max_tail_gib:
+            r.set_option("max_tail_gib", args.max_tail_gib)
+        if args.russian_roulette:
+            r.set_option("russian_roulette", args.russian_roulette)
+        for kv in args.debug:
+            k, v = kv.split("=")
+            r.set_debug_option(k, float(v))
+        rs.append(r)
+    r0 = rs[0]
+    acc = None
+    if one_device:     # the gloo aid sums a torch tensor the accumulator is bound to
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        r0.bind_accumulator(acc.data_ptr())
+    lib_rccl = launcher and not one_device
     if lib_rccl:
         uid = [ha.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        r.comm_init_rank(uid[0], world, rank)
-        r.allreduce_accumulator()      # warm-up: the first collective sets up the rings
-        r.synchronize()
+        r0.comm_init_rank(uid[0], world, rank)
+    elif len(rs) > 1:
+        ha.comm_init_local(rs)
+
+    def all_reduce():
+        """ONE all-reduce of the accumulators, enqueued behind the render work."""
+        if lib_rccl:
+            r0.allreduce_accumulator()
+        elif len(rs) > 1:
+            ha.allreduce_accumulators(rs)
+
+    def sync_all():
+        for r in rs:
+            r.synchronize()
+
+    if lib_rccl or len(rs) > 1:
+        all_reduce()      # warm-up: the first collective sets up the rings
+        sync_all()
     paths_per_step_gpu = W * H * 4 * SPS
 
     def run_step(i):
-        # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; this rank takes (s-1) % world == rank
-        r.render(*step_range(i, SPS, world, rank))
+        # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; rank g takes (s-1) % world == g
+        for r, (g, _) in zip(rs, mine):
+            r.render(*step_range(i, SPS, world, g))
 
     def barrier():
         if dist is not None:
             dist.barrier()
+        sync_all()
         torch.cuda.synchronize()
 
-    # ---- algorithmic bytes per path: instrumented run of the same kernel (outside the timed region)
-    bytes_per_path = None
+    # ---- test counts per path: instrumented run of the same kernel on the same seeds (outside the timed region)
     counters = None
     if rank == 0 and not args.no_counters:
-        r.set_option("counters", 1)
+        r0.set_option("counters", 1)
+        r0.clear()
+        r0.render(1, 3)
+        r0.synchronize()
+        counters = r0.stats()
+        r0.set_option("counters", 0)
+    for r in rs:
         r.clear()
-        r.render(1, 3)
-        r.synchronize()
-        counters = r.stats()
-        r.set_option("counters", 0)
-        alg = 32 * counters["node_tests"] + 36 * counters["tri_tests"] + 16 * counters["sphere_tests"] + 24 * counters["cuboid_tests"]
-        bytes_per_path = alg / max(1, counters["paths"])
-    r.clear()
 
     for i in range(args.warmup):
         run_step(i)
-    r.synchronize()
-    r.clear()
+    sync_all()
+    for r in rs:
+        r.clear()
     if args.debug_skip:
-        r.set_option("debug_skip", args.debug_skip)
+        for r in rs:
+            r.set_debug_option("debug_skip", args.debug_skip)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(i)
-    if lib_rccl:
-        r.allreduce_accumulator()      # enqueued on the render stream behind the last step
-    r.synchronize()
-    if dist is not None and not lib_rccl:
-        all_reduce_(acc, dist.ReduceOp.SUM)
+    all_reduce()
+    sync_all()
+    if one_device:
+        h = acc.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        acc.copy_(h)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce_(t, dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = r.stats()
-    acc_mean = float(r.read_accumulator().mean()) if lib_rccl else float(acc.mean().item())   # after the all-reduce: the total
-    # ---- the trace kernel with the chip to itself (seed kernel skipped: the hand-off buffers still hold the previous
-    #      batches' draws, so the workload is the same) — outside the timed region, reported next to the concurrent figure
-    alone_ms = None
-    if rank == 0 and not args.debug_skip and not args.no_counters:
-        if os.environ.get("HR_BENCH_CHECKSUM") == "1":
-            sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % acc_mean)
-        r.set_option("debug_skip", 2)
-        r.render(*step_range(0, SPS, world, rank))
-        r.synchronize()
-        st2 = r.stats()
-        r.set_option("debug_skip", 0)
-        alone_ms = (st2["trace_kernel_ms"] - st["trace_kernel_ms"]) / max(1, st2["trace_launches"] - st["trace_launches"])
-
-    if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0 and alone_ms is None:
+    st = r0.stats()
+    acc_mean = float(acc.mean().item()) if one_device else float(r0.read_accumulator().mean())   # after the all-reduce: the total
+    if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0:
         sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % acc_mean)
+
+    # ---- outside the timed region, rank 0: the trace kernel with the chip to itself, and the traversal-only workload
+    alone_ms = None
+    trav = None
+    if rank == 0 and not args.debug_skip and not args.no_counters:
+        # seed kernel skipped: the hand-off buffers still hold the previous batches' draws, so the workload is the same
+        r0.set_debug_option("debug_skip", 2)
+        r0.render(*step_range(0, SPS, world, mine[0][0]))
+        r0.synchronize()
+        st2 = r0.stats()
+        r0.set_debug_option("debug_skip", 0)
+        alone_ms = (st2["trace_kernel_ms"] - st["trace_kernel_ms"]) / max(1, st2["trace_launches"] - st["trace_launches"])
+        # traversal only (SURVEY.md §8f rank 4): DebugRenderer's Depth mode through the render kernel's traversal — camera rays,
+        # closest hits, nothing shaded, no seed kernel beside it.  Counts from one instrumented launch, time from ten plain ones.
+        r0.clear()
+        r0.set_option("counters", 1)
+        r0.render_debug(2)
+        tc = r0.stats()
+        r0.set_option("counters", 0)
+        r0.clear()
+        for _ in range(10):
+            r0.render_debug(2)
+        ts = r0.stats()
+        r0.clear()
+        trav = (tc, ts["debug_kernel_ms"] / max(1, ts["debug_launches"]))
+
     if rank == 0:
         total_paths = paths_per_step_gpu * world * args.steps
         value = total_paths / elapsed / 1e6
@@ -260,50 +304,94 @@ def main():
             "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
             "config": {"workload": "%s %dx%d, %d samplings (x4 sub-samples) per step per GPU; K=64 steps = 1024 samplings" % (args.scene, W, H, SPS),
                        "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": paths_per_step_gpu * world,
-                       "parallelism": "spp-sharded x%d, one all-reduce (%s)" % (world, "ncclAllReduce inside libhanamaru_hip.so" if lib_rccl else
-                                                                                  ("gloo on a host copy: HR_BENCH_ONE_DEVICE debugging aid" if dist is not None else "single rank"))},
+                       "parallelism": "spp-sharded x%d, one all-reduce (%s)" % (world, how), "devices": sorted(set(d for _, d in mine)) if not launcher else [local_rank],
+                       "estimator": "reference (no Russian roulette)" if not args.russian_roulette else "NON-PARITY: Russian roulette from iteration %d" % args.russian_roulette},
             "rays_per_s_M": None,
         }
         launches = max(1, st["trace_launches"])
         avg_ms = st["trace_kernel_ms"] / launches
         # the library may cap the samplings per launch (hand-off buffer size): use what was actually launched
         paths_per_launch = st["paths"] / launches if st["paths"] else W * H * 4 * min(args.batch or 4, SPS)
+        quant = args.quant_nodes != 0
+        node_b = 16 if quant else 32
+        builder = {0: "host-sah", 1: "device-lbvh", 2: "device-ploc"}.get(args.bvh_builder, "?")
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
-                "bvh_builder": "device-lbvh" if args.bvh_builder else "host-sah", "bvh_build_ms": round(st["bvh_build_ms"], 4)}
-        if bytes_per_path is not None and avg_ms > 0:
-            gbs = bytes_per_path * paths_per_launch / (avg_ms * 1e-3) / 1e9
-            roof.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_path": round(bytes_per_path, 1),
-                         "algorithmic_bytes_per_launch": int(bytes_per_path * paths_per_launch),
-                         "node_tests_per_ray": round(counters["node_tests"] / max(1, counters["rays"]), 2),
-                         "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
-                         "rays_per_path": round(counters["rays"] / max(1, counters["paths"]), 3),
-                         "lanes_per_shade_call": round(counters["shade_lanes"] / max(1, counters["shade_calls"]), 1),
-                         "lanes_per_box_pass": round(counters["box_lanes"] / max(1, counters["box_passes"]), 1),
-                         "lanes_per_leaf_call": round(counters["leaf_lanes"] / max(1, counters["leaf_calls"]), 1),
-                         "wave_passes_per_path": {k: round(counters[k] / max(1, counters["paths"]), 3) for k in ("shade_calls", "box_passes", "leaf_calls")},
-                         "phase_share_of_wave_cycles": dict(zip(("shade", "refill", "box", "leaf"),
-                                                                [round(float(v) / max(1.0, float(sum(counters["phase_cycles"]))), 3) for v in counters["phase_cycles"]]))})
-            out["rays_per_s_M"] = round(value * counters["rays"] / max(1, counters["paths"]), 1)
+                "bvh_builder": builder, "bvh_build_ms": round(st["bvh_build_ms"], 4)}
+
+        def loaded_bytes(c):   # what the lanes request for the tests they perform (device_scene.h record sizes)
+            return node_b * c["node_tests"] + 48 * c["tri_tests"] + 16 * c["sphere_tests"] + 32 * c["cuboid_tests"]
+
+        def survey_bytes(c):   # the information content of a test, whatever the layout
+            return 32 * c["node_tests"] + 36 * c["tri_tests"] + 16 * c["sphere_tests"] + 24 * c["cuboid_tests"]
+
+        if counters is not None and avg_ms > 0:
+            npaths = max(1, counters["paths"])
+            lb, sb = loaded_bytes(counters) / npaths, survey_bytes(counters) / npaths
+            gbs = lb * paths_per_launch / (avg_ms * 1e-3) / 1e9
+            sgbs = sb * paths_per_launch / (avg_ms * 1e-3) / 1e9
+            pc = [float(v) for v in counters["phase_cycles"]]
+            share = dict(zip(("shade", "refill", "box", "leaf"), [round(v / max(1.0, sum(pc)), 3) for v in pc]))
+            trav_share = (pc[2] + pc[3]) / max(1.0, sum(pc))
+            roof.update({
+                "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "definition": "bytes the kernel's lanes load for the tests they perform (%d B per node visit on the %s records, 48 B per triangle, 16 B per sphere, "
+                              "32 B per cuboid; test counts from the instrumented build of the same kernel on the same seeds) per launch / mean launch duration "
+                              "(HIP events), over the HBM3E peak.  The tree is L2-resident (see `traffic` and `l2`): HBM is not what bounds the kernel" % (node_b, "16-byte quantised" if quant else "32-byte fp32"),
+                "algorithmic_bytes_per_path": round(lb, 1), "algorithmic_bytes_per_launch": int(lb * paths_per_launch),
+                "survey_8d": {"bytes_per_path": round(sb, 1), "achieved": round(sgbs, 1), "frac": round(sgbs / HBM_PEAK_GBS, 4),
+                              "note": "normalised traversal rate: SURVEY.md §8(d) books 32 B per node test, 36 B per triangle, 16 B per sphere, 24 B per cuboid whatever the "
+                                      "record format.  Comparable across rounds and layouts; NOT a physical fraction of HBM bandwidth (a node visit loads 16 B here and the "
+                                      "tree is served by L2), so it may exceed 1"},
+                "node_tests_per_ray": round(counters["node_tests"] / max(1, counters["rays"]), 2),
+                "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
+                "rays_per_path": round(counters["rays"] / npaths, 3),
+                "lanes_per_shade_call": round(counters["shade_lanes"] / max(1, counters["shade_calls"]), 1),
+                "lanes_per_box_pass": round(counters["box_lanes"] / max(1, counters["box_passes"]), 1),
+                "lanes_per_leaf_call": round(counters["leaf_lanes"] / max(1, counters["leaf_calls"]), 1),
+                "wave_passes_per_path": {k: round(counters[k] / npaths, 3) for k in ("shade_calls", "box_passes", "leaf_calls")},
+                "phase_share_of_wave_cycles": share,
+                # north_star's "traversal section": the box + leaf phases' share of the wave cycles applied to the kernel's time
+                "traversal_section": {"share_of_wave_cycles": round(trav_share, 3), "ms_per_launch": round(avg_ms * trav_share, 4),
+                                      "achieved": round(gbs / max(trav_share, 1e-9), 1), "frac": round(gbs / max(trav_share, 1e-9) / HBM_PEAK_GBS, 4),
+                                      "note": "all of the kernel's traversal bytes over the time its waves spend in the box and leaf phases (shade and refill excluded)"}})
+            out["rays_per_s_M"] = round(value * counters["rays"] / npaths, 1)
             if alone_ms:
-                gbs_alone = bytes_per_path * paths_per_launch / (alone_ms * 1e-3) / 1e9
-                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs_alone, 1), "frac_alone": round(gbs_alone / HBM_PEAK_GBS, 4),
+                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs * avg_ms / alone_ms, 1), "frac_alone": round(gbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4),
                              "note": "achieved / frac: trace kernel running concurrently with the seed kernel of the next batch (the production schedule); "
                                      "*_alone: the same kernel on the same workload with the chip to itself"})
-        # L2: the BVH working set is L2-resident, so the same algorithmic bytes are also quoted against the aggregate L2 bandwidth
-        if roof.get("achieved"):
-            roof["l2"] = {"achieved": roof["achieved"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(roof["achieved"] / L2_PEAK_GBS, 4),
-                          "note": "algorithmic traversal bytes per second vs the aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s)"}
+                roof["survey_8d"]["frac_alone"] = round(sgbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4)
+            # L2 is the level that serves the tree: the same bytes against its aggregate bandwidth
+            roof["l2"] = {"achieved": roof["achieved"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4),
+                          "frac_alone": round(gbs * avg_ms / alone_ms / L2_PEAK_GBS, 4) if alone_ms else None,
+                          "note": "the same loaded bytes per second vs the aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s); part of them is served by the CUs' L1"}
+        if trav is not None:
+            tc, tms = trav
+            rays = max(1, tc["rays"])
+            tb = loaded_bytes(tc)
+            roof["traversal_only"] = {
+                "workload": "hr_render_debug Depth mode: %dx%dx4 pinhole camera rays through the render kernel's traversal, closest hit, nothing shaded, chip to itself" % (W, H),
+                "ms_per_launch": round(tms, 4), "Mrays_per_s": round(rays / (tms * 1e-3) / 1e6, 1),
+                "node_tests_per_ray": round(tc["node_tests"] / rays, 2), "tri_tests_per_ray": round(tc["tri_tests"] / rays, 2),
+                "lanes_per_box_pass": round(tc["box_lanes"] / max(1, tc["box_passes"]), 1),
+                "achieved": round(tb / (tms * 1e-3) / 1e9, 1), "frac": round(tb / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frac_l2": round(tb / (tms * 1e-3) / 1e9 / L2_PEAK_GBS, 4),
+                "survey_8d_frac": round(survey_bytes(tc) / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # HBM / fabric traffic and instruction counts are PMC measurements (separate rocprofv3 --pmc passes of this same command,
         # tools/prof_pmc.sh, which also writes the JSON read here); per launch like `achieved`
         pmc = latest_pmc_traffic()
         if pmc and (W, H, args.scene) == (1920, 1080, "rtcamp6_v3_1"):
+            stale = pmc.get("csrc_sha") != kernel_source_sha()
             tk = pmc["kernels"].get("trace_kernel", {})
             if "fetch_bytes_per_path" in tk:
                 roof["traffic"] = int(tk["fetch_bytes_per_path"] * paths_per_launch)
                 roof["traffic_source"] = pmc["source"]
+                roof["traffic_stale"] = stale   # true: the PMC passes were taken on other kernel sources than the ones running now
                 roof["traffic_write"] = int(tk.get("write_bytes_per_path", 0) * paths_per_launch)
+            phys = {k: tk[k] for k in ("l2_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "l1_line_accesses_per_path", "l1_to_l2_requests_per_path") if k in tk}
+            if phys:
+                phys["note"] = "what bounds the kernel physically (PMC, kernel alone on the chip): the L1's tag lookups — one cache line per clock per CU — and SIMD lane divergence, not bytes"
+                roof["physical"] = phys
             # issue: wave-level instructions per path of BOTH kernels vs what the chip can issue (one instruction per wave per
             # ~4.5 cycles is the per-wave rate; the per-SIMD VALU rate is one wave64 instruction per 2 cycles)
             per_path = {k: {f: v[f] for f in ("valu_per_path", "salu_per_path", "vmem_per_path", "lds_per_path") if f in v} for k, v in pmc["kernels"].items()}
@@ -311,18 +399,16 @@ def main():
             if valu > 0:
                 chip_valu_per_s = 256 * 4 * 2.4e9 / 2.0     # 1024 SIMD-32 units, a wave64 VALU instruction every 2 cycles
                 roof["issue"] = {"wave_instructions_per_path": per_path, "valu_wave_instructions_per_path_both_kernels": round(valu, 1),
-                                 "valu_ceiling_Mpaths_per_s": round(chip_valu_per_s / valu / 1e6, 1), "frac": round(value * 1e6 * valu / chip_valu_per_s, 4),
-                                 "source": pmc["source"]}
+                                 "valu_ceiling_Mpaths_per_s": round(chip_valu_per_s / valu / 1e6, 1), "frac": round(value / world * 1e6 * valu / chip_valu_per_s, 4),
+                                 "source": pmc["source"], "stale": stale}
         out["roofline"] = roof
-        # The other kernel of the pair: per-path ISAAC-64 seeding.  Bound neither by HBM nor by MFMA but by how fast ONE wave can
-        # issue: the LDS holds 80 generator states per CU (2 KiB each), two consumer waves of 40 lanes run their rounds, and a
-        # lone wave issues one instruction per ~4.5 cycles (LDS reads ~8, LDS writes ~16: tools/issueprobe.hip).  Ceiling =
-        # 80 states / (256 round steps x ~101 cycles of issue + 11 init blocks x ~510 cycles at 2.4 GHz = 13.2 us) x 256 CUs.
+        # The other kernel of the pair: per-path ISAAC-64 seeding.  Bound neither by HBM nor by MFMA but by LDS capacity x the
+        # serial chain of ONE wave (SEED_CEILING_US_PER_GROUP above).
         seed_ms = st["seed_kernel_ms"] / max(1, st["seed_launches"])
         if seed_ms > 0:
             seed_rate = paths_per_launch / (seed_ms * 1e-3) / 1e6
-            ceiling = 80.0 / 13.2e-6 * 256 / 1e6
-            out["seed_kernel"] = {"kernel": "seed_seg_kernel", "bound": "lds_capacity_x_single_wave_issue_rate", "avg_launch_ms": round(seed_ms, 4),
+            ceiling = 80.0 / (SEED_CEILING_US_PER_GROUP * 1e-6) * 256 / 1e6
+            out["seed_kernel"] = {"kernel": "seed_seg_kernel", "bound": "lds_capacity_x_single_wave_serial_chain", "avg_launch_ms": round(seed_ms, 4),
                                   "achieved": round(seed_rate, 1), "peak": round(ceiling, 1), "unit": "Mpaths/s", "frac": round(seed_rate / ceiling, 4)}
 
         if world == 1 and not args.no_cpu_baseline:
@@ -352,6 +438,8 @@ def main():
                                              "BVHs; one thread: 240x135 x 1 sampling" %
                                              (args.scene, cw, ch, mult, cw * ch * 4 * mult, cores, hw_threads, ("%.0f CPUs" % quota) if quota else "none")}
         print(json.dumps(out), flush=True)
+    for r in rs:
+        r.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

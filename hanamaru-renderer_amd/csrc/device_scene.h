@@ -1,8 +1,9 @@
 // Device-side scene layout (fp32, SoA-ish, all in HBM; the geometry part is ~1 MB and lives in L2).
 //
-//   nodes[o][]   32 B   one AABB as near / far planes for octant o (see Node) + the two successors of the node for ray-direction octant o (stackless
-//                       threaded traversal, near child first by the sign of the ray direction on the split
-//                       axis).  One record = two 16-byte loads; the 8 octant copies (8 x ~350 KB) stay in L2.
+//   qnodes[o][]  16 B   the record the trace kernel walks (QNode below): six 16-bit grid planes + one link, one copy per ray-direction
+//                       octant o, each in its own near-first preorder; rtcamp6_v3_1: 8 x 13,950 x 16 B = 1.8 MB, L2-resident
+//   nodes[o][]   32 B   the same trees with fp32 near / far planes and explicit hit / miss links (Node below): debug kernels and the
+//                       quant_nodes = 0 variant of the trace kernel.  One record = two 16-byte loads
 //   tris[]       48 B   leaf-ordered: v0, e1 = v1-v0, e2 = v2-v0 (edges formed in f64, then rounded) + element id
 //   spheres[]    16 B   centre, radius            (+ sphere_elem[])
 //   cuboids[]    32 B   min, max                  (+ element id in .w of the first float4)
@@ -127,7 +128,7 @@ struct CameraF {
 };
 
 struct Scene {
-    const QNode *qnodes;     // [8][num_nodes + 1], octant-major; nullptr when the tree was built in another order (device LBVH)
+    const QNode *qnodes;     // [8][num_nodes + 1], octant-major (host- and device-built trees alike); nullptr with option quant_nodes = 0
     float qmin[3], qstep[3]; // the grid of the quantised planes
     const Node *nodes;       // [8][num_nodes], octant-major
     const Tri *tris;
@@ -154,6 +155,8 @@ struct RenderParams {
     uint32_t trace_boost;             // trace kernel: 1 = its box phase, 2 = box and leaf phases run at priority 1, above the seed kernel's producer waves (hr_api.hip sets it from measured kernel times)
     uint32_t node_unroll;             // trace kernel: node fetches per pass of the box-phase loop (1 or 2)
     uint32_t kchunk;                  // trace kernel: samplings per work unit (0 = 4)
+    uint32_t ovf_cap;                 // seed kernels: entries of each consumer wave's fix-up list (sized per launch by hr_api.hip)
+    uint32_t rr_start;                // trace kernel: Russian roulette from this iteration on (0 = off, the default: the reference has none)
 };
 
 // lane j of tile `tile` -> pixel and sub-sample (tile = 4x4 pixels x 4 sub-samples = 64 paths per sampling)

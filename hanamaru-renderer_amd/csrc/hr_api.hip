@@ -5,7 +5,8 @@
 //   trace_kernel.h   trace_kernel — the path-tracing megakernel: persistent waves pull 4x4-pixel tiles from a global
 //                    counter, one lane per path, stackless threaded-BVH traversal in box / leaf phases, finished lanes are
 //                    refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed kernel of the NEXT
-//                    batch (own stream) — plus intersect_debug_kernel and debug_render_kernel (renderer.rs:101-146)
+//                    batch (own stream) — plus trace_debug_kernel (the same traversal, for hr_debug_trace), intersect_debug_kernel
+//                    and debug_render_kernel (renderer.rs:101-146)
 //   post_kernels.h   tonemap_gamma_kernel, bilateral_quantise_kernel
 //   gpu_bvh.h        the device BVH builders' kernels (option bvh_builder = 1 LBVH, 2 PLOC)
 #include <hip/hip_runtime.h>
@@ -53,7 +54,7 @@ static int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------------------------------ context
 
-struct EventPair { hipEvent_t a, b; };
+struct EventPair { hipEvent_t a, b; int level; };   // level: the trace_boost level the launch ran at (priority governor)
 
 struct hr_ctx {
     int device = 0;
@@ -79,6 +80,7 @@ struct hr_ctx {
     // seed -> trace hand-off, double buffered (slot = batch & 1)
     float *recs[2] = {nullptr, nullptr};     // 128-byte record per path (device_scene.h)
     uint32_t *ovf = nullptr;                 // per consumer wave: list of the paths it re-derives at the end of a launch (seed_fixup_wave)
+    uint32_t ovf_cap = 0;                    // entries per consumer wave the list is allocated for (ensure_ovf)
     u64 *ovf_win = nullptr;                  // per consumer wave: raw-output window of that fix-up
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
     u64 *ring = nullptr;                     // seed kernels' hand-off ring (three-run kernel: 120 KiB per CU of 16-register states; ring kernel: <= 680 KiB per CU)
@@ -103,18 +105,19 @@ struct hr_ctx {
     size_t gov_next = 0;                     // first launch (index into seed_events / trace_events) the governor has not looked at
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     int max_leaf = 4;                        // BVH leaf size (next upload)
-    double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by > 30 %), 0 = off, > 0 = ratio
+    double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by more than 7 %), 0 = off, > 0 = ratio
     int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH, 2 = device PLOC (gpu_bvh.h); next upload
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
     int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
     bool seed_prof = false;                  // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
+    uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
-    std::vector<EventPair> seed_events, trace_events, post_events;
-    double seed_ms = 0, trace_ms = 0, post_ms = 0;
-    uint64_t seed_launches = 0, trace_launches = 0;
+    std::vector<EventPair> seed_events, trace_events, post_events, debug_events;
+    double seed_ms = 0, trace_ms = 0, post_ms = 0, debug_ms = 0;
+    uint64_t seed_launches = 0, trace_launches = 0, debug_launches = 0;
     uint64_t paths_rendered = 0;
     // hr_mark / hr_wait: markers on the main stream, oldest first
     std::vector<std::pair<uint64_t, hipEvent_t>> markers;
@@ -139,17 +142,25 @@ static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
 // Priority governor (see hr_render).  Three levels (trace kernel's box phase / box and leaf phases above the producer waves).
 // A finished launch says how long the slower of the two kernels took at the current level; an untried neighbouring level is tried
 // when the balance asks for it (trace kernel more than 3 % behind -> up, seed kernel -> down), otherwise the best level known wins.
-static void govern(hr_ctx *c, float seed_ms, float trace_ms) {
-    if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0)) return;
-    const int L = c->boost_now;
+// `level` is the level the measured launch RAN at (the host enqueues several launches ahead of the GPU, so it is not
+// necessarily the current one): its time is credited to that level, and only a launch that ran at the current level may move it.
+static void govern(hr_ctx *c, float seed_ms, float trace_ms, int level) {
+    if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0) || level < 0 || level > 2) return;
+    const int L = level;
     const float m = std::max(seed_ms, trace_ms);
     c->gov_known[L] = c->gov_known[L] > 0 ? 0.5f * (c->gov_known[L] + m) : m;
+    if (L != c->boost_now) return;   // a launch issued before the last change of level: noted, nothing decided from it
     if (trace_ms > 1.03f * seed_ms && L < 2 && c->gov_known[L + 1] == 0) { c->boost_now = L + 1; return; }
     if (seed_ms > 1.03f * trace_ms && L > 0 && c->gov_known[L - 1] == 0) { c->boost_now = L - 1; return; }
     int best = L;
     for (int k = 0; k < 3; k++)
         if (c->gov_known[k] > 0 && c->gov_known[k] < 0.995f * c->gov_known[best]) best = k;
     c->boost_now = best;
+}
+// the accumulator of `c` is about to change: totals that include it are stale — its own and, in a same-device group, its peers'
+static void invalidate_totals(hr_ctx *c) {
+    c->total_valid = false;
+    for (hr_ctx *p : c->same_device_peers) p->total_valid = false;
 }
 static void govern_reset(hr_ctx *c) { c->gov_known[0] = c->gov_known[1] = c->gov_known[2] = 0; if (c->trace_boost < 0) c->boost_now = 1; }
 static int drain_events(hr_ctx *c) {
@@ -159,7 +170,7 @@ static int drain_events(hr_ctx *c) {
         float sm = 0, tm = 0;
         if (n >= 3 && n - 2 >= c->gov_next && hipEventElapsedTime(&sm, c->seed_events[n - 2].a, c->seed_events[n - 2].b) == hipSuccess &&
             hipEventElapsedTime(&tm, c->trace_events[n - 2].a, c->trace_events[n - 2].b) == hipSuccess)
-            govern(c, sm, tm);
+            govern(c, sm, tm, c->trace_events[n - 2].level);
     }
     auto sum = [](std::vector<EventPair> &ev, double &acc) -> hipError_t {
         for (auto &e : ev) {
@@ -176,6 +187,7 @@ static int drain_events(hr_ctx *c) {
     HIP_TRY(sum(c->seed_events, c->seed_ms));
     HIP_TRY(sum(c->trace_events, c->trace_ms));
     HIP_TRY(sum(c->post_events, c->post_ms));
+    HIP_TRY(sum(c->debug_events, c->debug_ms));
     c->gov_next = 0;
     return HR_OK;
 }
@@ -251,7 +263,6 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
             if (fa.sharedSizeBytes != 0) return fail(HR_ERR_DEVICE, "build error: a trace kernel variant uses %zu bytes of LDS (it must use none to run beside the seed kernel)", (size_t)fa.sharedSizeBytes);
         }
     }
-    HIP_TRY(hipMalloc((void **)&c->ovf, (size_t)c->num_cus * 2 * SEED_OVF_CAP * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&c->ovf_win, (size_t)c->num_cus * 2 * SEED_WIN_WORDS * sizeof(u64)));
     return HR_OK;
 }
@@ -261,7 +272,7 @@ int hr_destroy(hr_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     free_scene(c);
-    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events})
+    for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events, &c->debug_events})
         for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &m : c->markers) (void)hipEventDestroy(m.second);
     if (c->accum_own) (void)hipFree(c->accum_own);
@@ -446,7 +457,7 @@ int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
     int rc = sync_all(c);
     if (rc) return rc;
     c->accum = device_rgb ? device_rgb : c->accum_own;
-    c->total_valid = false;
+    invalidate_totals(c);
     return HR_OK;
 }
 void *hr_accumulator_device_ptr(hr_ctx *c) { return c ? c->accum : nullptr; }
@@ -466,12 +477,12 @@ int hr_clear(hr_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
-    c->total_valid = false;
+    invalidate_totals(c);
     HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->seed_ms = c->trace_ms = c->post_ms = 0;
-    c->seed_launches = c->trace_launches = 0;
+    c->seed_ms = c->trace_ms = c->post_ms = c->debug_ms = 0;
+    c->seed_launches = c->trace_launches = c->debug_launches = 0;
     c->paths_rendered = 0;
     return HR_OK;
 }
@@ -489,10 +500,29 @@ static int ensure_draws(hr_ctx *c, size_t items) {
     return HR_OK;
 }
 
+// Fix-up lists of the seed kernel's consumer waves: a path whose lens rejection loop rejects its first LENS_FAST attempts (round
+// lens: (1 - pi/4)^5 = 4.6e-4 of the paths) is queued by the wave that seeded it.  The paths per wave grow with the launch and
+// shrink with the CU count, so the lists are sized per launch: 8 x the expected count (the count is Poisson: 8 x is > 30 sigma away
+// for any launch that matters), never below SEED_OVF_MIN.
+static int ensure_ovf(hr_ctx *c, uint64_t paths_per_launch) {
+    const uint64_t groups = (paths_per_launch + SEED_COLS - 1) / SEED_COLS;
+    const uint64_t waves = 2 * std::min<uint64_t>(std::max<uint64_t>(groups, 1), (uint64_t)c->num_cus);
+    const double expected = 4.7e-4 * (double)paths_per_launch / (double)waves;
+    const uint64_t want = std::max<uint64_t>(SEED_OVF_MIN, ((uint64_t)(8.0 * expected) + 64 + 255) / 256 * 256);
+    if (want <= c->ovf_cap) return HR_OK;
+    int rc = sync_all(c);   // a seed kernel in flight may still be writing its lists
+    if (rc) return rc;
+    if (c->ovf) { HIP_TRY(hipFree(c->ovf)); c->ovf = nullptr; }
+    c->ovf_cap = 0;
+    HIP_TRY(hipMalloc((void **)&c->ovf, (size_t)c->num_cus * 2 * want * sizeof(uint32_t)));
+    c->ovf_cap = (uint32_t)want;
+    return HR_OK;
+}
+
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
-    EventPair ev;
+    EventPair ev{nullptr, nullptr, (int)rp.trace_boost};
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
@@ -531,7 +561,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_render: hr_set_resolution not called");
     if (s_end <= s_begin) return HR_OK;
     HIP_TRY(hipSetDevice(c->device));
-    c->total_valid = false;
+    invalidate_totals(c);
     uint32_t total_k = (s_end - s_begin + stride - 1) / stride;
     RenderParams rp{};
     rp.width = c->W; rp.height = c->H;
@@ -556,6 +586,9 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     }
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
+    if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
+    rp.ovf_cap = c->ovf_cap;
+    rp.rr_start = c->rr_start;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
         rp.sampling_begin = s_begin + done * stride;
@@ -573,7 +606,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
                 float sm = 0, tm = 0;
                 if (hipEventElapsedTime(&sm, c->seed_events[j].a, c->seed_events[j].b) == hipSuccess &&
                     hipEventElapsedTime(&tm, c->trace_events[j].a, c->trace_events[j].b) == hipSuccess)
-                    govern(c, sm, tm);
+                    govern(c, sm, tm, c->trace_events[j].level);
                 c->gov_next = j + 1;
                 break;
             }
@@ -587,7 +620,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(c->seed_done[slot], sstream));
         c->seed_pending[slot] = true;
         HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
-        EventPair ev;
+        EventPair ev{nullptr, nullptr, (int)rp.trace_boost};
         HIP_TRY(hipEventCreate(&ev.a));
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, c->stream));
@@ -628,11 +661,28 @@ int hr_render_debug(hr_ctx *c, int mode) {
     if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_render_debug: no scene uploaded");
     if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_render_debug: hr_set_resolution not called");
     HIP_TRY(hipSetDevice(c->device));
-    c->total_valid = false;
+    invalidate_totals(c);
     RenderParams rp{};
     rp.width = c->W; rp.height = c->H;
-    hipLaunchKernelGGL(debug_render_kernel, dim3((c->W + 15) / 16, (c->H + 15) / 16), dim3(16, 16), 0, c->stream, c->dsc, rp, mode, c->accum);
+    rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
+    rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll;
+    EventPair ev{nullptr, nullptr, -1};
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, c->stream));
+    {
+        const uint32_t tiles = rp.tiles_x * rp.tiles_y;
+        dim3 g((tiles + TRACE_WAVES - 1) / TRACE_WAVES), b(64 * TRACE_WAVES);
+        const bool qn = c->dsc.qnodes != nullptr;
+#define HR_LAUNCH_DEBUG(C, Q) hipLaunchKernelGGL((debug_render_kernel<C, Q>), g, b, 0, c->stream, c->dsc, rp, mode, c->accum, c->d_counters)
+        if (c->counters) { if (qn) HR_LAUNCH_DEBUG(true, true); else HR_LAUNCH_DEBUG(true, false); }
+        else { if (qn) HR_LAUNCH_DEBUG(false, true); else HR_LAUNCH_DEBUG(false, false); }
+#undef HR_LAUNCH_DEBUG
+    }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, c->stream));
+    c->debug_events.push_back(ev);
+    c->debug_launches++;
     return HR_OK;
 }
 
@@ -685,7 +735,7 @@ int hr_write_accumulator(hr_ctx *c, const float *host) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
-    c->total_valid = false;
+    invalidate_totals(c);
     HIP_TRY(hipMemcpy(c->accum, host, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyHostToDevice));
     return HR_OK;
 }
@@ -697,7 +747,7 @@ int hr_resolve(hr_ctx *c, uint32_t samplings, uint8_t *host_rgb8) {
     if (rc) return rc;
     uint32_t n = c->W * c->H;
     float scale = 1.0f / (float)(samplings * 4u);
-    EventPair ev;
+    EventPair ev{nullptr, nullptr, -1};
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, c->stream));
@@ -802,16 +852,20 @@ static int allreduce_enqueue(hr_ctx *c) {
         for (size_t k = 1; k < c->same_device_peers.size(); k++)
             hipLaunchKernelGGL(add_accumulator_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->accum_total, c->same_device_peers[k]->accum, n);
         HIP_TRY(hipGetLastError());
+        // the adds read the PEERS' accumulators from this context's stream: they are finished before the call returns, so that a
+        // peer's next hr_render / hr_clear / hr_write_accumulator cannot race with them
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->total_valid = true;
         return HR_OK;
     }
     NCCL_TRY(hrcomm::api().AllReduce(c->accum, c->accum_total, n, hrcomm::kFloat, hrcomm::kSum, c->comm, c->stream));
-    c->total_valid = true;
-    return HR_OK;
+    return HR_OK;   // total_valid is set by the callers once the collective is known to be enqueued (group end)
 }
 int hr_allreduce_accumulator(hr_ctx *c) {
     if (!c) return fail(HR_ERR_INVALID, "hr_allreduce_accumulator: null ctx");
-    return allreduce_enqueue(c);
+    int rc = allreduce_enqueue(c);
+    if (rc == HR_OK) c->total_valid = true;
+    return rc;
 }
 int hr_allreduce_accumulators(hr_ctx **ctxs, int n) {
     if (!ctxs || n < 1) return fail(HR_ERR_INVALID, "hr_allreduce_accumulators: bad argument");
@@ -827,6 +881,7 @@ int hr_allreduce_accumulators(hr_ctx **ctxs, int n) {
     int r_ = hrcomm::api().GroupEnd();
     if (rc) return rc;
     if (r_ != 0) return fail(HR_ERR_DEVICE, "ncclGroupEnd failed: %s", hrcomm::api().GetErrorString(r_));
+    for (int i = 0; i < n; i++) ctxs[i]->total_valid = true;
     return HR_OK;
 }
 void *hr_total_device_ptr(hr_ctx *c) { return c && c->total_valid ? c->accum_total : nullptr; }
@@ -845,6 +900,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
     out->bvh_build_ms = c->bvh_build_ms;
+    out->debug_kernel_ms = c->debug_ms; out->debug_launches = c->debug_launches;
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
     for (int i = 0; i < 4; i++) out->phase_cycles[i] = h.phase_cycles[i];
@@ -865,9 +921,59 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->batch = (uint32_t)value;
         return HR_OK;
     }
+    if (k == "trace_boost") {
+        if (value != -1 && value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times), 0, 1 or 2");
+        c->trace_boost = (int)value;
+        govern_reset(c);
+        return HR_OK;
+    }
+    if (k == "quant_nodes") { c->quant_nodes = value != 0.0; return HR_OK; }
+    if (k == "max_tail_gib") {
+        if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
+        c->max_tail_bytes = (uint64_t)value << 30;
+        return HR_OK;
+    }
+    if (k == "split_ratio") {  // early split clipping of triangle references (-1 = automatic, 0 = off), next hr_upload_scene
+        if ((value < 0 && value != -1) || value > 1000) return fail(HR_ERR_INVALID, "split_ratio must be -1 (automatic), 0 (off) or in (0,1000]");
+        c->split_ratio = value;
+        return HR_OK;
+    }
+    if (k == "bvh_builder") {  // takes effect at the next hr_upload_scene
+        if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "bvh_builder must be 0 (host SAH), 1 (device LBVH) or 2 (device PLOC)");
+        c->bvh_builder = (int)value;
+        return HR_OK;
+    }
+    if (k == "max_leaf") {  // takes effect at the next hr_upload_scene
+        if (value < 1 || value > 15) return fail(HR_ERR_INVALID, "max_leaf must be in [1,15]");
+        c->max_leaf = (int)value;
+        return HR_OK;
+    }
+    if (k == "rng_window") {
+        if ((int)value != ISAAC_TAIL) return fail(HR_ERR_UNSUPPORTED, "rng_window is fixed at %d in this build", ISAAC_TAIL);
+        return HR_OK;
+    }
+    if (k == "russian_roulette") {  // NOT image-preserving (see the header): 0 = off, else the first path iteration that plays
+        if (value != 0 && (value < 2 || value > 9)) return fail(HR_ERR_INVALID, "russian_roulette must be 0 (off) or the first iteration that plays, in [2,9]");
+        c->rr_start = (uint32_t)value;
+        return HR_OK;
+    }
+    return fail(HR_ERR_INVALID, "unknown option '%s' (measurement knobs live behind hr_set_debug_option)", key);
+}
+
+// Measurement / experiment knobs.  Kept apart from hr_set_option on purpose: a host that only uses hr_set_option cannot change the
+// kernels' schedule, and cannot reach "debug_skip", which produces a garbage image.
+int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
+    if (!c || !key) return fail(HR_ERR_INVALID, "hr_set_debug_option: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::string k = key;
     if (k == "adv_den") {
         if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "adv_den must be in [1,64]");
         c->adv_den = (uint32_t)value;
+        return HR_OK;
+    }
+    if (k == "leaf_den") {
+        if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "leaf_den must be in [1,64]");
+        c->leaf_den = (uint32_t)value;
         return HR_OK;
     }
     if (k == "min_waves") {
@@ -875,18 +981,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->min_waves = (int)value;
         return HR_OK;
     }
-    if (k == "trace_boost") {
-        if (value != -1 && value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times), 0, 1 or 2");
-        c->trace_boost = (int)value;
-        govern_reset(c);
-        return HR_OK;
-    }
     if (k == "kchunk") {
         if (value < 0 || value > 64) return fail(HR_ERR_INVALID, "kchunk must be in [1,64], or 0 for the default");
         c->kchunk = (uint32_t)value;
         return HR_OK;
     }
-    if (k == "quant_nodes") { c->quant_nodes = value != 0.0; return HR_OK; }
     if (k == "node_unroll") {
         if (value != 1 && value != 2) return fail(HR_ERR_INVALID, "node_unroll must be 1 or 2");
         c->node_unroll = (uint32_t)value;
@@ -897,19 +996,9 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->trace_wgs = (uint32_t)value;
         return HR_OK;
     }
-    if (k == "max_tail_gib") {
-        if (value < 1 || value > 128) return fail(HR_ERR_INVALID, "max_tail_gib must be in [1,128]");
-        c->max_tail_bytes = (uint64_t)value << 30;
-        return HR_OK;
-    }
     if (k == "seed_prio") {
         if (value < 0 || value > 3) return fail(HR_ERR_INVALID, "seed_prio must be in [0,3]");
         c->seed_prio = (uint32_t)value;
-        return HR_OK;
-    }
-    if (k == "seed_split") {
-        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24 && value != 28) return fail(HR_ERR_INVALID, "seed_split must be 8, 12, 16, 20, 24 or 28");
-        c->seed_split = (int)value;
         return HR_OK;
     }
     if (k == "init_prio") {
@@ -917,8 +1006,11 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->init_prio = (uint32_t)value;
         return HR_OK;
     }
-    if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
-    if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
+    if (k == "seed_split") {
+        if (value != 8 && value != 12 && value != 16 && value != 20 && value != 24 && value != 28) return fail(HR_ERR_INVALID, "seed_split must be 8, 12, 16, 20, 24 or 28");
+        c->seed_split = (int)value;
+        return HR_OK;
+    }
     if (k == "seed_mode") {
         if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "seed_mode must be 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
         int rc = sync_all(c);
@@ -926,31 +1018,9 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         c->seed_mode = (int)value;
         return HR_OK;
     }
-    if (k == "split_ratio") {  // early split clipping of triangle references (-1 = automatic, 0 = off), next hr_upload_scene
-        if ((value < 0 && value != -1) || value > 1000) return fail(HR_ERR_INVALID, "split_ratio must be -1 (automatic), 0 (off) or in (0,1000]");
-        c->split_ratio = value;
-        return HR_OK;
-    }
-    if (k == "bvh_builder") {  // 0 = host binned SAH, 1 = device LBVH; takes effect at the next hr_upload_scene
-        if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "bvh_builder must be 0 (host SAH), 1 (device LBVH) or 2 (device PLOC)");
-        c->bvh_builder = (int)value;
-        return HR_OK;
-    }
-    if (k == "max_leaf") {  // takes effect at the next hr_upload_scene
-        if (value < 1 || value > 15) return fail(HR_ERR_INVALID, "max_leaf must be in [1,15]");
-        c->max_leaf = (int)value;
-        return HR_OK;
-    }
-    if (k == "leaf_den") {
-        if (value < 1 || value > 64) return fail(HR_ERR_INVALID, "leaf_den must be in [1,64]");
-        c->leaf_den = (uint32_t)value;
-        return HR_OK;
-    }
-    if (k == "rng_window") {
-        if ((int)value != ISAAC_TAIL) return fail(HR_ERR_UNSUPPORTED, "rng_window is fixed at %d in this build", ISAAC_TAIL);
-        return HR_OK;
-    }
-    return fail(HR_ERR_INVALID, "unknown option '%s'", key);
+    if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
+    if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
+    return fail(HR_ERR_INVALID, "unknown debug option '%s'", key);
 }
 
 int hr_debug_draws(hr_ctx *c, uint32_t sampling, uint32_t first_path, uint32_t num_paths, uint32_t window, uint64_t *host_out) {
@@ -985,6 +1055,8 @@ int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
     rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, tiles))) return rc;
+    if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u))) return rc;
+    rp.ovf_cap = c->ovf_cap;
     if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
     std::vector<float> h((size_t)tiles * REC_ITEM_FLOATS);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1024,6 +1096,34 @@ int hr_debug_intersect(hr_ctx *c, uint32_t n, const float *rays, float *out, int
     if (e == hipSuccess) e = hipMemcpy(out_element, d_el, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(d_el);
     if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_intersect: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_debug_trace(hr_ctx *c, uint32_t n, const float *rays, const float *shadow_len, float *out, int32_t *out_element) {
+    if (!c || !rays || !out || !out_element || !n) return fail(HR_ERR_INVALID, "hr_debug_trace: bad argument");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_debug_trace: no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_rays = nullptr, *d_out = nullptr, *d_sl = nullptr;
+    int32_t *d_el = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, (size_t)n * 6 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)n * 8 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_el, (size_t)n * 4);
+    if (e == hipSuccess && shadow_len) e = hipMalloc((void **)&d_sl, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && shadow_len) e = hipMemcpy(d_sl, shadow_len, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        RenderParams rp{};
+        rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll;
+        // the record format hr_render walks on this scene
+        if (c->dsc.qnodes) hipLaunchKernelGGL((trace_debug_kernel<true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
+        else hipLaunchKernelGGL((trace_debug_kernel<false>), dim3((n + 63) / 64), dim3(64), 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 8 * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_element, d_el, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(d_el); (void)hipFree(d_sl);
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_trace: %s", hipGetErrorString(e));
     return HR_OK;
 }
 

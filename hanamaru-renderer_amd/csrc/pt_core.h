@@ -567,38 +567,49 @@ HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *
 
 // ---------------------------------------------------------------------------------------------
 // DebugRenderer::calc_pixel (renderer.rs:116-139): pinhole ray (camera.rs:98-107), no RNG.
-// mode 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane.  Also serves as a traversal-only workload.
-template <bool CNT>
-HD V3f debug_pixel(const Scene &sc, const RenderParams &rp, uint32_t px, uint32_t py, uint32_t sub, int mode, LaneCounters *cn) {
+// mode 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane.  Also serves as a traversal-only workload (hr_render_debug walks the production
+// traversal: debug_render_kernel in trace_kernel.h).  In pieces, so that the kernel and the host emulation share everything but the walk.
+HD void debug_camera_ray(const Scene &sc, const RenderParams &rp, uint32_t px, uint32_t py, uint32_t sub, Ray &ray) {
     float fx = (float)px, fy = (float)(rp.height - py);
     float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
     float m = (float)(rp.width < rp.height ? rp.width : rp.height);
     float ncx = ((fx + ox) * 2.0f - (float)rp.width) * HR_RCP(m), ncy = ((fy + oy) * 2.0f - (float)rp.height) * HR_RCP(m);
     const CameraF &c = sc.cam;
-    Ray ray;
     ray_set(ray, v3(c.eye), normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward)));
+}
+// The primary ray's result.  Returns true when the pixel still needs the shadow ray `sh` of the Shading mode (renderer.rs:121-131):
+// the pixel is then val + lit * (shadow ray hit something ? 0.5 : 1); otherwise it is val.
+HD bool debug_primary(const Scene &sc, const Ray &ray, const TraceState &ts, int mode, V3f &val, V3f &lit, Ray &sh) {
+    if (ts.prim < 0) { val = sky_sample(sc, ray.d); return false; }
+    Surf s;
+    hit_surface(sc, ray, ts, material_needs_uv(sc, hit_element(sc, ts)), s);
+    if (mode == 1) { val = s.n; return false; }
+    if (mode == 2) { float v = 0.5f * ts.t * HR_RCP(sc.cam.focus_distance); val = v3(v, v, v); return false; }
+    if (mode == 3) { float v = fabsf(ts.t - sc.cam.focus_distance); val = v3(v, v, v); return false; }
+    PointMat pm;
+    material_at(sc, s.elem, s.u, s.v, pm);
+    const V3f light = normalize(v3(1.0f, 2.0f, -1.0f));
+    ray_set(sh, s.pos + s.n * OFFSET_F, light);
+    val = pm.emission;
+    lit = pm.albedo * fmaxf(dot(s.n, light), 0.0f);
+    return true;
+}
+// scalar form (host emulation): one node + its leaf per step
+template <bool CNT>
+HD V3f debug_pixel(const Scene &sc, const RenderParams &rp, uint32_t px, uint32_t py, uint32_t sub, int mode, LaneCounters *cn) {
+    Ray ray, sh;
+    debug_camera_ray(sc, rp, px, py, sub, ray);
     TraceState ts;
     trace_begin(ts, T_INF);
     while (ts.cur != NODE_END) trace_step<CNT>(sc, ray, ts, cn);
     if (CNT) cn->rays++;
-    if (ts.prim < 0) return sky_sample(sc, ray.d);
-    Surf s;
-    hit_surface(sc, ray, ts, material_needs_uv(sc, hit_element(sc, ts)), s);
-    if (mode == 1) return s.n;
-    if (mode == 2) { float v = 0.5f * ts.t * HR_RCP(c.focus_distance); return v3(v, v, v); }
-    if (mode == 3) { float v = fabsf(ts.t - c.focus_distance); return v3(v, v, v); }
-    PointMat pm;
-    material_at(sc, s.elem, s.u, s.v, pm);
-    const V3f light = normalize(v3(1.0f, 2.0f, -1.0f));
-    Ray sh;
-    ray_set(sh, s.pos + s.n * OFFSET_F, light);
+    V3f val, lit;
+    if (!debug_primary(sc, ray, ts, mode, val, lit, sh)) return val;
     TraceState st;
     trace_begin(st, T_INF);
     while (st.cur != NODE_END) trace_step<CNT>(sc, sh, st, cn);
     if (CNT) cn->rays++;
-    float shadow = st.prim >= 0 ? 0.5f : 1.0f;
-    float diffuse = fmaxf(dot(s.n, light), 0.0f);
-    return pm.emission + pm.albedo * (diffuse * shadow);
+    return val + lit * (st.prim >= 0 ? 0.5f : 1.0f);
 }
 
 }  // namespace hr

@@ -1,4 +1,5 @@
-// ISAAC-64 seeding kernels: seed_pc_kernel (producer / consumer waves, default), seed_isaac64_kernel (fused),
+// ISAAC-64 seeding kernels: seed_seg_kernel (three-run init, the default), seed_pc_kernel (producer / consumer waves
+// with a ring of generator words), seed_isaac64_kernel (fused),
 // seed_debug_kernel (raw outputs for the parity tests); the rare paths whose lens rejection loop runs past the hand-off record are
 // re-derived by the consumer waves themselves at the end of a launch (seed_fixup_wave) — included by hr_api.hip only (one translation unit: the kernels and the C ABI that launches them).
 #pragma once
@@ -44,16 +45,17 @@ static const uint32_t SEED_SPARE_ITEMS = 3;
 // the record rewritten rebased to a = 0 (record_from_window).  All bookkeeping is per wave: no atomics, no extra kernel, nothing
 // between the seed kernels on their stream.  A path that would need more than ISAAC_TAIL outputs (probability 4e-16), or a list
 // that overflows, is counted in rng_overflow and reported by hr_synchronize as HR_ERR_RNG_WINDOW instead of producing a wrong image.
-static const uint32_t SEED_OVF_CAP = 2048;                 // entries per consumer wave
+static const uint32_t SEED_OVF_MIN = 2048;                 // entries per consumer wave, at least; hr_api.hip sizes the lists per launch
+                                                           // from the paths a wave seeds (RenderParams::ovf_cap)
 static const uint32_t SEED_WIN_WORDS = ISAAC_TAIL * 40;   // u64 per consumer wave: [ISAAC_TAIL][40 lanes]
 __device__ __forceinline__ uint32_t wave_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-__device__ __forceinline__ void ovf_note(bool ov, uint64_t pid, uint32_t *list, uint32_t &count) {   // whole wave
+__device__ __forceinline__ void ovf_note(bool ov, uint64_t pid, uint32_t *list, uint32_t &count, uint32_t cap) {   // whole wave
     const unsigned long long m = __ballot(ov);
     if (!m) return;
     const uint32_t slot = count + wave_rank(m);
-    if (ov && slot < SEED_OVF_CAP) list[slot] = (uint32_t)pid;
+    if (ov && slot < cap) list[slot] = (uint32_t)pid;
     count += (uint32_t)__popcll(m);
 }
 struct GlobalWindow {
@@ -64,9 +66,9 @@ struct GlobalWindow {
 template <class Mem>
 __device__ __forceinline__ void seed_fixup_wave(const RenderParams &rp, int lens_shape, Mem m, uint32_t lane40, bool lane_on, const uint32_t *list, uint32_t count,
                                                 u64 *win, float *recs, Counters *cnt) {
-    if (count > SEED_OVF_CAP) {
-        if (lane40 == 0 && lane_on) atomicAdd(&cnt->rng_overflow, (unsigned long long)(count - SEED_OVF_CAP));
-        count = SEED_OVF_CAP;
+    if (count > rp.ovf_cap) {
+        if (lane40 == 0 && lane_on) atomicAdd(&cnt->rng_overflow, (unsigned long long)(count - rp.ovf_cap));
+        count = rp.ovf_cap;
     }
     const IsaacWarm warm = isaac_warm();
     for (uint32_t base = 0; base < count; base += 40u) {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool lane_on = lane < (uint32_t)SEED_LANES;
     const uint32_t col = wave * SEED_LANES + (lane_on ? lane : 0u);
-    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + wave) * SEED_OVF_CAP;
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + wave) * rp.ovf_cap;
     uint32_t ovf_count = 0;
     // latency-bound waves next to the trace kernel's waves: win issue arbitration (priority is a launch parameter)
     switch (rp.pad[0]) {
@@ -133,12 +135,12 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void seed_isaac64_kernel(RenderPar
             isaac_seed_round<REC_DRAWS>(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, lt);
             lt.finish();
         }
-        ovf_note(lane_on && valid && lt.overflow(), pid, ovf_list, ovf_count);
+        ovf_note(lane_on && valid && lt.overflow(), pid, ovf_list, ovf_count, rp.ovf_cap);
     }
     seed_fixup_wave(rp, lens_shape, LdsMem{mem + col}, lane_on ? lane : 0u, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + wave) * SEED_WIN_WORDS, recs, cnt);
 }
 
-// ---- producer / consumer seeding (option seed_mode = 1, the default) -----------------------------------------------------------
+// ---- producer / consumer seeding (debug option seed_mode = 1) -----------------------------------------------------------------
 // One workgroup per CU, four waves, a contiguous range of path groups (80 paths = one LDS fill) per workgroup.
 // Waves 2,3 (producers) run the scratch-free init of the paths AHEAD in registers, 64 lanes = one chunk of 64 consecutive
 // paths per pass, and scatter the states into a small ring of group buffers in global memory that belongs to this
@@ -250,7 +252,7 @@ template <int SEED_SPLIT, bool PROF>
 __device__ __forceinline__ void seed_pc_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
                                                  float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
     typedef PcLayout<SEED_SPLIT> L;
-    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * SEED_OVF_CAP;
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * rp.ovf_cap;
     uint32_t ovf_count = 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
 #define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
@@ -297,7 +299,7 @@ __device__ __forceinline__ void seed_pc_consumer(const RenderParams &rp, int len
             lt.finish();
         }
         HR_STAMP(4);
-        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count);
+        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count, rp.ovf_cap);
         HR_STAMP(5);
         if (PROF) pc[7]++;
         __syncthreads();   // A: group G0 + it is complete in the ring; the LDS and buffer (G0 + it - 1) & 3 are free again
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     else seed_pc_producer<SEED_SPLIT>(rp, r, smem, lane, half);
 }
 
-// ---- three-run seeding (option seed_mode = 2) ---------------------------------------------------------------------------------
+// ---- three-run seeding (the default; debug option seed_mode = 2) ---------------------------------------------------------------------------------
 // Same four waves, same LDS halves, same round — but NO generator words travel through memory.  The init sweep of a group is cut
 // into three runs of SEG_NBLK blocks (device_scene.h) that are computed at the same time, in the window in which the half's LDS is
 // free, by different LANES: the mix is the same instruction stream whatever block it works on, so one wave can advance 64
@@ -451,7 +453,7 @@ struct SegRegs {
 template <bool PROF>
 __device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
                                                   float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
-    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * SEED_OVF_CAP;
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * rp.ovf_cap;
     uint32_t ovf_count = 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
 #define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
@@ -487,7 +489,7 @@ __device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int le
             lt.finish();
         }
         HR_STAMP(4);
-        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count);
+        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count, rp.ovf_cap);
         HR_STAMP(5);
         if (PROF) pc[7]++;
         __syncthreads();   // A: the LDS is free again; the states of group G0 + it + 1 are in the ring

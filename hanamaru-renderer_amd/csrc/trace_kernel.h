@@ -21,9 +21,93 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 static const int TRACE_WAVES = 4;
 static const uint32_t TRACE_KCHUNK = 4;   // samplings per work unit (default of RenderParams::kchunk)
 
-// QN: the tree is walked on the 16-byte quantised nodes (host-built trees); false: on the 32-byte fp32 records (device LBVH, whose
-// records are not in the per-octant preorder the 16-byte format relies on).  A template parameter, not a branch: each form keeps
-// only its own per-ray constants in registers.
+// wave-uniform statistics of the counters build (phase invocations / lanes served, wave-cycles per phase)
+struct WaveStats {
+    uint32_t ph[7];
+    unsigned long long pc[4], tmark;
+};
+#define HR_PHASE_BEGIN(ws) do { if (CNT) (ws).tmark = __builtin_readcyclecounter(); } while (0)
+#define HR_PHASE_END(ws, i) do { if (CNT) (ws).pc[i] += __builtin_readcyclecounter() - (ws).tmark; } while (0)
+
+// Phase C of the megakernel — the production traversal — as one function, so that the unit-level entry point hr_debug_trace walks
+// exactly the code the renderer walks (trace_debug_kernel below).  Traversal as two well-filled phases.  Box phase: lanes walk
+// nodes until 1/leaf_den of the traversing lanes have parked a leaf; leaf phase: those lanes test their primitives together.
+// The whole of C is left as soon as 1/adv_den of the live lanes wait for phase A (adv_den = 0: only when no lane traverses).
+// QN: the tree is walked on the 16-byte quantised nodes (the default for host- and device-built trees); false: on the 32-byte
+// fp32 records of the same tree (option quant_nodes = 0).  A template parameter, not a branch: each form keeps only its own
+// per-ray constants in registers.
+template <bool CNT, bool QN>
+__device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParams &rp, Path &p, const bool active, const uint32_t n_active, const uint32_t adv_den,
+                                              const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws) {
+    for (;;) {
+        const bool trav = active && !trace_done(p.ts);
+        const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
+        if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
+        // lanes allowed to be still walking when the leaf phase starts
+        const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
+        const uint32_t walk_max = n_trav - park;
+        HR_PHASE_BEGIN(ws);
+        // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
+        // box pass is the trace kernel's critical loop.  Switched by the host from the measured times of the two kernels
+        // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
+        // and costs ~1 % when the seed kernel is.  Level 2 adds the leaf phase (another +1 - 2 % where the trace kernel is far behind).
+        if (rp.trace_boost) __builtin_amdgcn_s_setprio(1);
+        for (;;) {
+            // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
+            const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
+            const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
+            if (n_go <= walk_max) break;
+            if (CNT) { ws.ph[2]++; ws.ph[3] += n_go; }
+            if (go) {
+                if (QN) {
+                    trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
+                } else {
+                    trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                }
+            }
+        }
+        if (rp.trace_boost) __builtin_amdgcn_s_setprio(0);
+        HR_PHASE_END(ws, 2);
+        HR_PHASE_BEGIN(ws);
+        if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(1);   // level 2: the leaf phase too
+        if (CNT) {
+            uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
+            if (n) { ws.ph[4]++; ws.ph[5] += n; }
+        }
+        if (trav && p.ts.leaf != 0) {
+            trace_leaf<CNT>(sc, p.ray, p.ts, &lc);   // clears ts.leaf
+            p.ts.leaf = p.ts.leaf2;
+            p.ts.leaf2 = 0;
+            shadow_early_out(p);
+        }
+        if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(0);
+        HR_PHASE_END(ws, 3);
+    }
+}
+
+// one atomic per counter per wave
+template <bool CNT>
+__device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uint32_t npaths, const LaneCounters &lc, const WaveStats &ws) {
+    if (!CNT) return;
+    unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
+    for (int i = 0; i < 6; i++) {
+        unsigned long long x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        v[i] = x;
+    }
+    if (lane == 0) {
+        atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
+        atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
+        atomicAdd(&cnt->shade_calls, (unsigned long long)ws.ph[0]); atomicAdd(&cnt->shade_lanes, (unsigned long long)ws.ph[1]);
+        atomicAdd(&cnt->box_passes, (unsigned long long)ws.ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ws.ph[3]);
+        atomicAdd(&cnt->leaf_calls, (unsigned long long)ws.ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ws.ph[5]);
+        atomicAdd(&cnt->outer_iters, (unsigned long long)ws.ph[6]);
+        for (int i = 0; i < 4; i++) atomicAdd(&cnt->phase_cycles[i], ws.pc[i]);
+    }
+}
+
 template <bool CNT, int MINW, bool QN>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ recs,
                                                                        float *__restrict__ accum, Counters *cnt, uint32_t *tile_counter) {
@@ -31,10 +115,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     LaneCounters lc = {0, 0, 0, 0, 0};
     uint32_t npaths = 0;
-    uint32_t ph[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform phase statistics (counters build only)
-    unsigned long long pc[4] = {0, 0, 0, 0}, tmark = 0;   // wave-cycles per phase (counters build only)
-#define HR_PHASE_BEGIN() do { if (CNT) tmark = __builtin_readcyclecounter(); } while (0)
-#define HR_PHASE_END(i) do { if (CNT) pc[i] += __builtin_readcyclecounter() - tmark; } while (0)
+    WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t kchunk = rp.kchunk ? rp.kchunk : TRACE_KCHUNK;
     const uint32_t nchunks = (rp.num_k + kchunk - 1u) / kchunk, units = tiles * nchunks;
     uint32_t total = 0, cur_k0 = 0;          // wave-uniform: paths in the current unit (slot q = (k - cur_k0) * 64 + j), its first sampling
@@ -52,10 +133,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
         if (CNT) {
             uint32_t n = (uint32_t)__popcll(__ballot(p.q != PATH_IDLE && trace_done(p.ts)));
-            ph[6]++;
-            if (n) { ph[0]++; ph[1] += n; }
+            ws.ph[6]++;
+            if (n) { ws.ph[0]++; ws.ph[1] += n; }
         }
-        HR_PHASE_BEGIN();
+        HR_PHASE_BEGIN(ws);
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
             if (path_advance<CNT>(sc, p, recs + (size_t)p.tile * tile_stride, &lc)) {
                 // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
@@ -73,9 +154,9 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 p.q = PATH_IDLE;
             }
         }
-        HR_PHASE_END(0);
+        HR_PHASE_END(ws, 0);
         // ---- B: refill idle lanes (ballot + prefix rank = live-lane compaction); pull a new tile when the queue is dry
-        HR_PHASE_BEGIN();
+        HR_PHASE_BEGIN(ws);
         unsigned long long idle = __ballot(p.q == PATH_IDLE);
         if (idle) {
             if (next >= total && !exhausted) {
@@ -105,83 +186,55 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 next += (uint32_t)__popcll(idle);
             }
         }
-        HR_PHASE_END(1);
+        HR_PHASE_END(ws, 1);
         const bool active = p.q != PATH_IDLE;
         const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
         if (!n_active) {
             if (exhausted) break;
             continue;
         }
-        // ---- C: traversal as two well-filled phases.  Box phase: lanes walk nodes until 1/leaf_den of the
-        //         traversing lanes have parked a leaf; leaf phase: those lanes test their primitives together.
-        //         The whole of C is left as soon as 1/adv_den of the live lanes wait for phase A.
-        for (;;) {
-            const bool trav = active && !trace_done(p.ts);
-            const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
-            if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
-            // lanes allowed to be still walking when the leaf phase starts
-            const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
-            const uint32_t walk_max = n_trav - park;
-            HR_PHASE_BEGIN();
-            // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
-            // box pass is the trace kernel's critical loop.  Switched by the host from the measured times of the two kernels
-            // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
-            // and costs ~1 % when the seed kernel is.  Level 2 adds the leaf phase (another +1 - 2 % where the trace kernel is far behind).
-            if (rp.trace_boost) __builtin_amdgcn_s_setprio(1);
-            for (;;) {
-                // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
-                const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
-                const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
-                if (n_go <= walk_max) break;
-                if (CNT) { ph[2]++; ph[3] += n_go; }
-                if (go) {
-                    if (QN) {
-                        trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
-                        if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
-                    } else {
-                        trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                        if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                    }
-                }
-            }
-            if (rp.trace_boost) __builtin_amdgcn_s_setprio(0);
-            HR_PHASE_END(2);
-            HR_PHASE_BEGIN();
-            if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(1);   // level 2: the leaf phase too
-            if (CNT) {
-                uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
-                if (n) { ph[4]++; ph[5] += n; }
-            }
-            if (trav && p.ts.leaf != 0) {
-                trace_leaf<CNT>(sc, p.ray, p.ts, &lc);   // clears ts.leaf
-                p.ts.leaf = p.ts.leaf2;
-                p.ts.leaf2 = 0;
-                shadow_early_out(p);
-            }
-            if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(0);
-            HR_PHASE_END(3);
-        }
+        // ---- C: traversal
+        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, adv_den, leaf_den, lc, ws);
     }
-#undef HR_PHASE_BEGIN
-#undef HR_PHASE_END
-    if (CNT) {
-        // wave reduction, one atomic per counter per wave
-        unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
-        for (int i = 0; i < 6; i++) {
-            unsigned long long x = v[i];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            v[i] = x;
-        }
-        if (lane == 0) {
-            atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
-            atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
-            atomicAdd(&cnt->shade_calls, (unsigned long long)ph[0]); atomicAdd(&cnt->shade_lanes, (unsigned long long)ph[1]);
-            atomicAdd(&cnt->box_passes, (unsigned long long)ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ph[3]);
-            atomicAdd(&cnt->leaf_calls, (unsigned long long)ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ph[5]);
-            atomicAdd(&cnt->outer_iters, (unsigned long long)ph[6]);
-            for (int i = 0; i < 4; i++) atomicAdd(&cnt->phase_cycles[i], pc[i]);
-        }
+    flush_counters<CNT>(cnt, lane, npaths, lc, ws);
+}
+
+// hr_debug_trace: closest-hit / shadow queries through the PRODUCTION traversal — traverse_wave on the record format the renderer
+// walks, box and leaf phases, two parked leaves, closest-hit culling, and for shadow queries (shadow_len > 0) the search limit of
+// nee_setup and shadow_early_out.  One wave = 64 rays; lanes whose walk is done idle, as lanes waiting for phase A do in the megakernel.
+template <bool QN>
+__global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams rp, uint32_t n, const float *__restrict__ rays, const float *__restrict__ shadow_len,
+                                                         float *__restrict__ out, int32_t *__restrict__ out_elem) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t j = active ? i : 0u;
+    Path p;
+    p.q = active ? 0u : PATH_IDLE;
+    p.tile = 0; p.st = 1u;
+    ray_set(p.ray, v3(rays[j * 6], rays[j * 6 + 1], rays[j * 6 + 2]), v3(rays[j * 6 + 3], rays[j * 6 + 4], rays[j * 6 + 5]));
+    ray_quantise(sc, p.ray);
+    const float sl = shadow_len ? shadow_len[j] : 0.0f;
+    p.shadow_len = sl;
+    if (sl > 0.0f) { trace_begin(p.ts, sl + 0.03f); p.st |= 16u; }   // nee_setup's search limit, shadow phase
+    else trace_begin(p.ts, T_INF);
+    if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
+    LaneCounters lc = {0, 0, 0, 0, 0};
+    WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+    const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+    traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws);
+    if (!active) return;
+    float *o = out + (size_t)i * 8;
+    int32_t elem = -1;
+    if (p.ts.prim >= 0) {
+        Surf s;
+        hit_surface(sc, p.ray, p.ts, true, s);
+        elem = s.elem;
+        o[0] = 1.0f; o[1] = p.ts.t; o[2] = s.pos.x; o[3] = s.pos.y; o[4] = s.pos.z; o[5] = s.n.x; o[6] = s.n.y; o[7] = s.n.z;
+    } else {
+        o[0] = 0.0f; o[1] = p.ts.t;
+        for (int k = 2; k < 8; k++) o[k] = 0.0f;
     }
+    out_elem[i] = elem;
 }
 
 __global__ void intersect_debug_kernel(Scene sc, uint32_t n, const float *__restrict__ rays, float *__restrict__ out, int32_t *__restrict__ out_elem) {
@@ -207,13 +260,47 @@ __global__ void intersect_debug_kernel(Scene sc, uint32_t n, const float *__rest
     out_elem[i] = elem;
 }
 
-// DebugRenderer (renderer.rs:101-146): one thread per pixel, 2x2 sub-samples, pinhole rays
-__global__ void debug_render_kernel(Scene sc, RenderParams rp, int mode, float *__restrict__ accum) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= rp.width || y >= rp.height) return;
-    LaneCounters lc;
-    V3f sum = v3(0, 0, 0);
-    for (uint32_t sub = 0; sub < 4; sub++) sum = sum + debug_pixel<false>(sc, rp, x, y, sub, mode, &lc);
-    float *o = accum + ((size_t)y * rp.width + x) * 3;
-    o[0] += sum.x; o[1] += sum.y; o[2] += sum.z;
+// DebugRenderer (renderer.rs:101-146) through the production traversal: one wave per 4x4-pixel tile, one lane per (pixel, sub-sample)
+// as in the megakernel, pinhole rays, no RNG, no seed kernel next to it.  Depth mode (2) is the traversal-only workload of bench.py:
+// camera rays, closest hits, nothing shaded.  The four sub-samples of a pixel sit in neighbouring lanes and are summed with two
+// lane exchanges (renderer.rs:48-60 adds them in order; the fp32 sum differs from that order by an ulp at most).
+template <bool CNT, bool QN>
+__global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc, RenderParams rp, int mode, float *__restrict__ accum, Counters *cnt) {
+    const uint32_t lane = threadIdx.x & 63u, tile = blockIdx.x * TRACE_WAVES + (threadIdx.x >> 6);
+    if (tile >= rp.tiles_x * rp.tiles_y) return;
+    uint32_t px, py, sub;
+    tile_lane_pixel(rp, tile, lane, px, py, sub);
+    const bool active = px < rp.width && py < rp.height;
+    LaneCounters lc = {0, 0, 0, 0, 0};
+    WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+    Path p;
+    p.q = active ? lane : PATH_IDLE;
+    p.tile = tile; p.st = 1u; p.shadow_len = 0.0f;
+    debug_camera_ray(sc, rp, active ? px : 0u, active ? py : 0u, sub, p.ray);
+    ray_quantise(sc, p.ray);
+    trace_begin(p.ts, T_INF);
+    if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
+    const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+    const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
+    traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, leaf_den, lc, ws);
+    if (CNT && active) lc.rays++;
+    V3f val = v3(0, 0, 0), lit = v3(0, 0, 0);
+    Ray sh = p.ray;
+    const bool more = active && debug_primary(sc, p.ray, p.ts, mode, val, lit, sh);
+    if (__ballot(more)) {   // Shading mode: the shadow ray towards the fixed light, any closest hit darkens
+        p.ray = sh;
+        ray_quantise(sc, p.ray);
+        trace_begin(p.ts, T_INF);
+        if (!more) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
+        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(__ballot(more)), 0u, leaf_den, lc, ws);
+        if (CNT && more) lc.rays++;
+        if (more) val = val + lit * (p.ts.prim >= 0 ? 0.5f : 1.0f);
+    }
+    val.x += __shfl_xor(val.x, 1); val.y += __shfl_xor(val.y, 1); val.z += __shfl_xor(val.z, 1);
+    val.x += __shfl_xor(val.x, 2); val.y += __shfl_xor(val.y, 2); val.z += __shfl_xor(val.z, 2);
+    if (active && sub == 0u) {
+        float *o = accum + ((size_t)py * rp.width + px) * 3;
+        o[0] += val.x; o[1] += val.y; o[2] += val.z;
+    }
+    flush_counters<CNT>(cnt, lane, (uint32_t)active, lc, ws);
 }

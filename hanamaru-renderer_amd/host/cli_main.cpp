@@ -130,8 +130,34 @@ int main(int argc, char **argv) {
     // The image needs the sum of all devices' accumulators: ONE all-reduce over RCCL (hr_allreduce_accumulators — the sum lands
     // in a separate buffer per device, so every device keeps accumulating its own samplings afterwards); hr_resolve /
     // hr_read_accumulator on device 0 then see the total (renderer.rs:64-90 runs after the sum).
-    if (ndev > 1) CHECK_HR(hr_comm_init_local(ctxs.data(), (int)ndev));
-    auto combine = [&]() -> int { return ndev == 1 ? 0 : (hr_allreduce_accumulators(ctxs.data(), (int)ndev) != 0); };
+    // A multi-GPU box whose RCCL cannot be loaded (hr_comm_init_local: HR_ERR_UNSUPPORTED) still renders: the host then sums the
+    // devices' accumulators itself when an image or a checkpoint is written (`sum_acc` below) — slower, same result.
+    bool host_sum = false;
+    if (ndev > 1) {
+        int rc = hr_comm_init_local(ctxs.data(), (int)ndev);
+        if (rc == HR_ERR_UNSUPPORTED) { host_sum = true; tee("no RCCL (%s): accumulators are summed on the host.", hr_last_error()); }
+        else if (rc != 0) { fprintf(stderr, "hr_comm_init_local: %s\n", hr_last_error()); return 1; }
+    }
+    std::vector<float> sum_acc, part;
+    auto combine = [&]() -> int {
+        if (ndev == 1) return 0;
+        if (!host_sum) return hr_allreduce_accumulators(ctxs.data(), (int)ndev) != 0;
+        sum_acc.resize((size_t)width * height * 3);
+        part.resize(sum_acc.size());
+        if (hr_read_accumulator(ctxs[0], sum_acc.data()) != 0) return 1;
+        for (uint32_t r = 1; r < ndev; r++) {
+            if (hr_read_accumulator(ctxs[r], part.data()) != 0) return 1;
+            for (size_t i = 0; i < sum_acc.size(); i++) sum_acc[i] += part[i];
+        }
+        return 0;
+    };
+    // host-side sum: device 0 resolves the total from its accumulator, then gets its own partial sums back
+    auto resolve = [&](uint32_t s, uint8_t *out) -> int {
+        if (!host_sum) return hr_resolve(ctx, s, out);
+        if (hr_read_accumulator(ctx, part.data()) != 0 || hr_write_accumulator(ctx, sum_acc.data()) != 0) return 1;
+        int rc = hr_resolve(ctx, s, out);
+        return hr_write_accumulator(ctx, part.data()) != 0 ? 1 : rc;
+    };
 
     // Renderer::render + report_progress (renderer.rs:25-46, 205-251) at batch granularity
     std::vector<uint8_t> rgb((size_t)width * height * 3);
@@ -141,7 +167,7 @@ int main(int argc, char **argv) {
         char path[32];
         snprintf(path, sizeof path, "%03u.png", counter);
         double t0 = now_sec();
-        if (combine() || hr_resolve(ctx, s, rgb.data()) != 0) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
+        if (combine() || resolve(s, rgb.data()) != 0) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
         printf("update_imgbuf: %.3f sec\n", now_sec() - t0);
         return hh_write_png_rgb8(path, rgb.data(), width, height);
     };
@@ -229,7 +255,8 @@ int main(int argc, char **argv) {
     if (!ckpt_out.empty()) {
         std::vector<float> acc((size_t)width * height * 3);
         if (combine()) { fprintf(stderr, "checkpoint: %s\n", hr_last_error()); return 1; }
-        CHECK_HR(hr_read_accumulator(ctx, acc.data()));
+        if (host_sum) acc = sum_acc;
+        else CHECK_HR(hr_read_accumulator(ctx, acc.data()));
         uint32_t hdr[5] = {CKPT_MAGIC, width, height, sampled, scene_hash};
         FILE *f = fopen(ckpt_out.c_str(), "wb");
         bool ok = f && fwrite(hdr, 4, 5, f) == 5 && fwrite(acc.data(), sizeof(float), acc.size(), f) == acc.size();

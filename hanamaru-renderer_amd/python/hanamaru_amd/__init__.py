@@ -78,7 +78,8 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("triangles", C.c_uint64), ("spheres", C.c_uint64), ("cuboids", C.c_uint64),
                 ("shade_calls", C.c_uint64), ("shade_lanes", C.c_uint64), ("box_passes", C.c_uint64), ("box_lanes", C.c_uint64),
                 ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
-                ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8)]
+                ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8),
+                ("debug_kernel_ms", C.c_double), ("debug_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}
@@ -138,6 +139,8 @@ def hip_lib():
         L.hr_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.hr_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.hr_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.hr_set_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.hr_debug_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hr_debug_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.hr_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hr_comm_get_unique_id.argtypes = [C.c_void_p]
@@ -298,6 +301,10 @@ class Renderer:
     def set_option(self, key, value):
         self._check(self.L.hr_set_option(self._h, key.encode(), float(value)))
 
+    def set_debug_option(self, key, value):
+        """Measurement knobs (include/hanamaru_hip.h: hr_set_debug_option) — not for product code."""
+        self._check(self.L.hr_set_debug_option(self._h, key.encode(), float(value)))
+
     def clear(self):
         self._check(self.L.hr_clear(self._h))
 
@@ -362,4 +369,16 @@ class Renderer:
         out = np.empty((r.shape[0], 8), dtype=np.float32)
         el = np.empty((r.shape[0],), dtype=np.int32)
         self._check(self.L.hr_debug_intersect(self._h, r.shape[0], r.ctypes.data, out.ctypes.data, el.ctypes.data))
+        return out, el
+
+    def debug_trace(self, rays, shadow_len=None):
+        """hr_debug_trace: the same queries through the render kernel's traversal; shadow_len > 0 marks shadow rays."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.empty((r.shape[0], 8), dtype=np.float32)
+        el = np.empty((r.shape[0],), dtype=np.int32)
+        sl = None
+        if shadow_len is not None:
+            sl = np.ascontiguousarray(shadow_len, dtype=np.float32).reshape(-1)
+            assert sl.shape[0] == r.shape[0]
+        self._check(self.L.hr_debug_trace(self._h, r.shape[0], r.ctypes.data, sl.ctypes.data if sl is not None else None, out.ctypes.data, el.ctypes.data))
         return out, el

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 2
+#define HR_ABI_VERSION 3
 
 typedef enum hr_status {
     HR_OK = 0,
@@ -121,7 +121,9 @@ typedef struct hr_stats {
     uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
     uint64_t phase_cycles[4];  /* counters build: wave-cycles in A shade, B refill, C box phase, C leaf phase */
     double bvh_build_ms;       /* device BVH build of the last hr_upload_scene (option bvh_builder = 1 | 2), else 0 */
-    uint64_t seed_phase_cycles[8]; /* option seed_prof: consumer-wave cycles per phase of the seed kernel, [7] = groups */
+    uint64_t seed_phase_cycles[8]; /* debug option seed_prof: consumer-wave cycles per phase of the seed kernel, [7] = groups */
+    double debug_kernel_ms;    /* sum of HIP-event durations of the hr_render_debug launches (the traversal-only workload) */
+    uint64_t debug_launches;
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;
@@ -160,7 +162,9 @@ int hr_wait(hr_ctx *ctx, uint64_t ticket);
 
 /* DebugRenderer (renderer.rs:101-146, max_sampling = 1): adds ONE sampling of the chosen visualiser to the
  * accumulator — pinhole rays, no RNG.  mode: 0 Shading, 1 Normal, 2 Depth, 3 FocalPlane (renderer.rs:102-107;
- * the reference's -d flag selects FocalPlane, main.rs:1280).  Resolve with samplings_done = 1. */
+ * the reference's -d flag selects FocalPlane, main.rs:1280).  Resolve with samplings_done = 1.
+ * The rays go through the render kernel's traversal (same records, same box / leaf phases): Depth mode doubles as the
+ * traversal-only workload of bench.py (hr_stats.debug_kernel_ms; with option "counters" the node / primitive test counts). */
 int hr_render_debug(hr_ctx *ctx, int mode);
 
 int hr_read_accumulator(hr_ctx *ctx, float *host_rgb);        /* W*H*3, row-major, top row first */
@@ -179,7 +183,8 @@ int hr_resolve(hr_ctx *ctx, uint32_t samplings_done, uint8_t *host_rgb8);
  *   one process per GPU:   rank 0: hr_comm_get_unique_id -> share the HR_COMM_ID_BYTES with the other ranks (any transport)
  *                          every rank: hr_comm_init_rank, ..., hr_allreduce_accumulator
  *   one process, N GPUs:   hr_comm_init_local(ctxs, N), ..., hr_allreduce_accumulators(ctxs, N)   (one RCCL group call)
- * RCCL is loaded on first use; without it these return HR_ERR_UNSUPPORTED (there is no host-side fallback sum).  RCCL wants one
+ * RCCL is loaded on first use; without it these return HR_ERR_UNSUPPORTED (the library has no host-side sum; a host that must run
+ * on such a box sums hr_read_accumulator results itself, as the hanamaru-hip CLI does).  RCCL wants one
  * rank per device: hr_comm_init_local over contexts that all share ONE device (a single-GPU box) sums them with a kernel on
  * that device instead; a mix of shared and distinct devices is rejected. */
 #define HR_COMM_ID_BYTES 128
@@ -192,20 +197,34 @@ int hr_allreduce_accumulators(hr_ctx **ctxs, int n);
 void *hr_total_device_ptr(hr_ctx *ctx);   /* device pointer of the all-reduced accumulator, NULL when not valid */
 
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
-/* keys: "quant_nodes" (1 = the trace kernel walks the 16-byte quantised nodes of host-built trees, default; next upload),
- * "counters" (0/1), "batch" (samplings per launch: 1..64, default 0 = automatic — about 33 M paths per launch, i.e. 4 at 1080p, up to 64 for small images), "adv_den" / "leaf_den" (trace-kernel phase
- * thresholds), "min_waves" (4..6, occupancy variant of the trace kernel), "max_leaf" (BVH leaf size, next upload),
- * "seed_mode" (2 = three-run seed kernel, default: the ISAAC-64 init sweep as three runs computed side by side from states the producer
- * waves compute ahead in registers; 1 = producer / consumer kernel with a ring of generator words; 0 = fused seed kernel), "seed_split" (seed_mode 1 only; 8 | 12 | 16 | 20 | 24 | 28: how many
- * of the 32 ISAAC-64 init blocks the producer waves compute and hand over through the ring, default 16),
- * "bvh_builder" (0 = host binned-SAH build, default; 1 = LBVH, 2 = PLOC (agglomerative, tree quality of the host build) built on
- * the device — replaces the reference's CPU build of bvh.rs:107-211, next upload), "max_tail_gib" (cap of each raw-draw hand-off buffer), "rng_window" (fixed: 64); "split_ratio" (early split clipping of long thin triangles in the host builder: -1 = automatic, kept when it
- * cuts the SAH cost by more than 7 %, default; 0 = off; > 0 = always, with that box / triangle area ratio); measurement knobs: "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves),
- * "node_unroll" (1 | 2 node visits per pass of the box phase),
- * "trace_boost" (-1 = the library decides from the measured kernel times whether the trace kernel's box phase runs above the seed kernel's
- * producer waves, and whether its leaf phase does too, default; 0 / 1 / 2 = fixed level), "trace_wgs" (trace-kernel workgroups per CU), "seed_prof" (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles),
- * "debug_skip" (bit mask that drops parts of the pipeline for timing experiments — the image is garbage) */
+/* Options that leave the image as the reference computes it (the summation order of the accumulator aside):
+ *   "counters"      0 / 1: instrumented build of the trace kernel (fills the counter fields of hr_stats)
+ *   "batch"         samplings per launch, 1..64; 0 = automatic (about 33 M paths per launch: 4 at 1080p, up to 64 for small images)
+ *   "trace_boost"   -1 = the library decides from the measured kernel times whether the trace kernel's box phase (and its leaf
+ *                   phase) run above the seed kernel's producer waves (default); 0 / 1 / 2 = fixed level
+ *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
+ *   "rng_window"    fixed: 64
+ *   next hr_upload_scene:
+ *   "bvh_builder"   0 = host binned-SAH build (default), 1 = LBVH, 2 = PLOC built on the device — replaces bvh.rs:107-211
+ *   "max_leaf"      BVH leaf size, 1..15 (default 4)
+ *   "split_ratio"   early split clipping of long thin triangles in the host builder: -1 = automatic (kept when it cuts the SAH
+ *                   cost by more than 7 %, default), 0 = off, > 0 = always, with that box / triangle area ratio
+ *   "quant_nodes"   1 = the trace kernel walks the 16-byte quantised node records (default), 0 = the 32-byte fp32 records of the
+ *                   same tree (identical hits)
+ * One option that does NOT preserve the image (off by default; every parity test runs with it off):
+ *   "russian_roulette"  0 = off.  k in 2..9: from path iteration k on a path survives with probability q = max(reflectance),
+ *                   quantised up to a multiple of 1/16, and its reflectance is divided by q.  The reference has no Russian
+ *                   roulette (renderer.rs:174-200 runs every path to the bounce limit); the estimator stays unbiased (the
+ *                   decisions use bits of the path's ISAAC-64 outputs that nothing else consumes), its noise changes. */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
+/* Measurement / experiment knobs, kept out of hr_set_option so that a host cannot change the kernels' schedule — or produce a
+ * garbage image — by a key string meant for a product option: "adv_den" / "leaf_den" (trace-kernel phase thresholds), "min_waves"
+ * (4..6, occupancy variant of the trace kernel; only with quant_nodes = 1), "kchunk", "node_unroll" (1 | 2), "trace_wgs",
+ * "seed_mode" (2 = three-run seed kernel, default; 1 = producer / consumer kernel with a ring of generator words; 0 = fused),
+ * "seed_split" (seed_mode 1), "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves), "seed_prof"
+ * (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles), "debug_skip" (bit mask that drops parts of the pipeline
+ * for timing experiments: THE IMAGE IS GARBAGE). */
+int hr_set_debug_option(hr_ctx *ctx, const char *key, double value);
 
 /* ---- unit-level entry points used by the parity tests (same kernels' device functions) ---- */
 
@@ -224,6 +243,14 @@ int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
  * rays: n * 6 floats (origin, direction).  out per ray: 8 floats
  * { hit(0/1), distance, pos.x, pos.y, pos.z, n.x, n.y, n.z }, plus element index in out_element. */
 int hr_debug_intersect(hr_ctx *ctx, uint32_t n, const float *rays, float *out, int32_t *out_element);
+
+/* The same query through the PRODUCTION traversal of hr_render (scalar walk above: one node + its leaf per step on the 32-byte
+ * records): 64 rays per wave through the render kernel's box / leaf phases on the record format it walks for this scene, with
+ * parked leaves and closest-hit culling.  shadow_len == NULL or shadow_len[i] <= 0: closest hit (bvh.rs:213-290 + scene.rs:385-401).
+ * shadow_len[i] > 0: ray i is a shadow ray towards a light sample at that distance (renderer.rs:276-282) — the search is limited to
+ * the sample distance + 0.03 and stops at the first hit more than 0.02 in front of the sample, exactly as in the render kernel;
+ * the visibility verdict of renderer.rs:280 is then  hit && (distance - shadow_len)^2 < 4e-4. */
+int hr_debug_trace(hr_ctx *ctx, uint32_t n, const float *rays, const float *shadow_len, float *out, int32_t *out_element);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,89 @@ def test_closest_hit_matches_oracle(gpu, scenes, name):
     assert np.median(nerr) < (1e-5 if name == "rtcamp6_v3_1" else 1e-4) and np.quantile(nerr, 0.999) < 2e-3
 
 
+def _query_rays(sc, n, seed):
+    rng = np.random.default_rng(seed)
+    eye = np.array(sc.desc.camera.eye.tuple())
+    org = eye + rng.normal(size=(n, 3)) * 0.3
+    tgt = rng.uniform(-2.5, 2.5, size=(n, 3)) * np.array([1.0, 0.6, 1.0]) + np.array([0, 0.8, 0])
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([org, d], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,builder,quant", [("rtcamp6_v3_1", 0, 1), ("rtcamp6_v3_1", 0, 0), ("rtcamp6_v3_1", 2, 1), ("rtcamp6_dodeca", 0, 1),
+                                                ("cornell_mini", 0, 1), ("spheres", 0, 1), ("spheres", 1, 1)])
+def test_production_traversal_closest_hit_matches_oracle(gpu, scenes, name, builder, quant):
+    """hr_debug_trace = the render kernel's own traversal (traverse_wave: 16-byte quantised records, box / leaf phases, two parked
+    leaves, closest-hit culling) as a query.  Against the oracle's closest hit (bvh.rs:213-290 + scene.rs:385-401) with the
+    tolerances of test_closest_hit_matches_oracle, and BIT-identical to the scalar walk of hr_debug_intersect: the order in which
+    a wave visits nodes and tests leaves must not change what a ray hits."""
+    sc, o = scenes(name)
+    gpu.set_option("bvh_builder", builder)
+    gpu.set_option("quant_nodes", quant)
+    try:
+        gpu.upload_scene(sc)
+        n = 6000 + 37   # not a multiple of 64: the last wave is ragged
+        rays32 = _query_rays(sc, n, 11)
+        got, gel = gpu.debug_trace(rays32)
+        scalar, sel = gpu.debug_intersect(rays32)
+    finally:
+        gpu.set_option("bvh_builder", 0)
+        gpu.set_option("quant_nodes", 1)
+    assert np.array_equal(gel, sel)
+    assert np.array_equal(got.view(np.uint32), scalar.view(np.uint32))
+    ref, rel = o.intersect(rays32.astype(np.float64))
+    same_hit = got[:, 0] == ref[:, 0]
+    assert same_hit.mean() > 0.999
+    both = same_hit & (ref[:, 0] == 1)
+    assert (gel[both] == rel[both]).mean() > 0.998
+    ok = both & (gel == rel)
+    terr = np.abs(got[ok, 1] - ref[ok, 1]) / np.maximum(1.0, ref[ok, 1])
+    assert np.quantile(terr, 0.99) < 2e-5 and terr.max() < 1e-3, (np.quantile(terr, 0.99), terr.max())
+
+
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_v2", "tbf3"])
+def test_production_traversal_shadow_rays_match_oracle(gpu, scenes, name):
+    """Shadow rays through the render kernel's traversal WITH its two exact work savers (search limited to the sample distance
+    + 0.03, stop at the first hit more than 0.02 in front of the sample): the visibility verdict must be the one of
+    renderer.rs:280 — the reference's unbounded closest hit lies within |dp|^2 < 4e-4 of the light sample (vector.rs:89-91)."""
+    sc, o = scenes(name)
+    gpu.upload_scene(sc)
+    els = [sc.desc.elements[i] for i in range(sc.desc.num_elements)]
+    lights = [e for e in els if e.kind == 0 and max(e.material.emission.color.tuple()) > 0]
+    assert lights
+    rays32 = _query_rays(sc, 5000, 5)
+    prim, _ = o.intersect(rays32.astype(np.float64))
+    hit = prim[:, 0] == 1
+    pos, nrm = prim[hit, 2:5], prim[hit, 5:8]
+    rng = np.random.default_rng(3)
+    origin = pos + 1e-4 * nrm                                  # material.rs: ray origin offset along the normal
+    lt = lights[0]
+    u = rng.normal(size=origin.shape)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    sample = np.array(lt.center.tuple()) + (lt.radius + 1e-4) * u   # scene.rs:92-101: a point on the sphere of radius r + OFFSET
+    sv = sample - origin
+    sl = np.linalg.norm(sv, axis=1)
+    srays = np.concatenate([origin, sv / sl[:, None]], axis=1).astype(np.float32)
+    # both sides see the fp32 ray; the sample point of that ray at the fp32 distance
+    sl32 = sl.astype(np.float32)
+    got, _ = gpu.debug_trace(srays, sl32)
+    ref, _ = o.intersect(srays.astype(np.float64))
+    d64 = srays[:, 3:6].astype(np.float64)
+    sample32 = srays[:, 0:3].astype(np.float64) + d64 * sl32[:, None].astype(np.float64)
+    ref_visible = (ref[:, 0] == 1) & (((ref[:, 2:5] - sample32) ** 2).sum(axis=1) < 4e-4)
+    gpu_visible = (got[:, 0] == 1) & ((got[:, 1].astype(np.float64) - sl32) ** 2 < 4e-4)
+    # a hit whose distance to the sample is within fp32 rounding of the 0.02 threshold may land on either side
+    margin = np.abs(np.sqrt(((ref[:, 2:5] - sample32) ** 2).sum(axis=1)) - 0.02) < 1e-4
+    agree = (ref_visible == gpu_visible) | margin
+    assert ref_visible.sum() > 100 and (~ref_visible).sum() > 100      # the sample exercises both verdicts
+    assert agree.mean() > 0.9995, (agree.mean(), int((~agree).sum()))
+    vis = ref_visible & gpu_visible
+    terr = np.abs(got[vis, 1] - ref[vis, 1]) / np.maximum(1.0, ref[vis, 1])
+    # the light is a sphere and most of its samples are seen at a grazing angle (t = -b - sqrt(d), d -> 0): bulk tight, tail loose
+    assert np.quantile(terr, 0.99) < 2e-5 and terr.max() < 1e-3, (np.quantile(terr, 0.99), terr.max())
+
+
 @pytest.mark.parametrize("name,w,h,s", [("rtcamp6_v3_1", 320, 180, 4), ("cornell_mini", 96, 64, 4), ("cornell_mini", 320, 200, 8), ("spheres", 256, 144, 2),
                                          ("rtcamp6_dodeca", 195, 111, 2), ("rtcamp6_v3", 256, 144, 3), ("simple", 256, 144, 3),
                                          ("material_examples", 256, 144, 3), ("rtcamp6_v1", 256, 144, 2), ("rtcamp6_v2", 192, 108, 1),
@@ -244,9 +327,16 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 65), ("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("max_leaf", 0), ("seed_mode", 3), ("seed_split", 10), ("bvh_builder", 3), ("rng_window", 32)]:
+    for key, bad in [("batch", 65), ("max_leaf", 0), ("bvh_builder", 3), ("rng_window", 32), ("russian_roulette", 1), ("trace_boost", 3)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
+    for key, bad in [("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("seed_mode", 3), ("seed_split", 10), ("nonsense", 1)]:
+        with pytest.raises(ha.HipError):
+            r.set_debug_option(key, bad)
+    # the measurement knobs are not reachable through the product call: a host cannot ship a garbage image by key string
+    for key in ("debug_skip", "seed_prof", "seed_mode", "seed_split", "seed_prio", "init_prio", "adv_den", "kchunk", "trace_wgs", "node_unroll"):
+        with pytest.raises(ha.HipError):
+            r.set_option(key, 1)
     with pytest.raises(ha.HipError):
         r.render_debug(7)
     with pytest.raises(ha.HipError):
@@ -358,8 +448,8 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
             gpu.set_resolution(w, h)
             ref = None
             for mode, head in [(0, 16), (1, 16), (1, 8), (1, 12), (1, 24), (2, 16)]:   # 2: the three-run kernel (no state ring)
-                gpu.set_option("seed_mode", mode)
-                gpu.set_option("seed_split", head)
+                gpu.set_debug_option("seed_mode", mode)
+                gpu.set_debug_option("seed_split", head)
                 gpu.clear()
                 gpu.render(1, s + 1)
                 acc = gpu.read_accumulator().astype(np.float64)
@@ -369,8 +459,8 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
                 else:
                     assert np.abs(ref - acc).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (w, h, mode, head)
     finally:
-        gpu.set_option("seed_mode", 2)
-        gpu.set_option("seed_split", 16)
+        gpu.set_debug_option("seed_mode", 2)
+        gpu.set_debug_option("seed_split", 16)
 
 
 def test_priority_governor_does_not_change_results(gpu, scenes):
@@ -395,31 +485,61 @@ def test_priority_governor_does_not_change_results(gpu, scenes):
         assert np.abs(outs[0] - o).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max())
 
 
-def test_bench_multirank_path_on_one_gpu(tmp_path):
-    """bench.py's N > 1 code path (sharding by sampling index, accumulate into a torch tensor, one all-reduce) run as two
-    ranks on ONE GPU (HR_BENCH_ONE_DEVICE: gloo on a host copy, RCCL refuses two ranks per device): the summed accumulator
-    must equal a single-rank run over the same sampling indices."""
-    import json
+def _run_bench(extra, env=None, launcher_ranks=0, port=29541):
     import os
-    import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--warmup", "0", "--spp-per-step", "2", "--width", "160", "--height", "90", "--no-cpu-baseline", "--no-counters"]
-    env = dict(os.environ, HR_BENCH_CHECKSUM="1")
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4"] + common, env=env, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-2000:]
-    env2 = dict(env, HR_BENCH_ONE_DEVICE="1")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"] + common, env=env2,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert two.returncode == 0, two.stderr[-2000:]
-    m1 = float(re.search(r"accumulator mean after all-reduce: ([0-9.eE+-]+)", one.stderr).group(1))
-    m2 = float(re.search(r"accumulator mean after all-reduce: ([0-9.eE+-]+)", two.stderr).group(1))
+    common = ["--warmup", "0", "--spp-per-step", "2", "--width", "160", "--height", "90", "--no-cpu-baseline"]
+    cmd = [sys.executable]
+    if launcher_ranks:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(root, "bench.py")] + extra + common
+    e = dict(os.environ, HR_BENCH_CHECKSUM="1")
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+
+
+def _bench_line(proc):
+    import json
+    import re
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    mean = float(re.search(r"accumulator mean after all-reduce: ([0-9.eE+-]+)", proc.stderr).group(1))
+    return json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]), mean
+
+
+def test_bench_gpus_n_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` exactly as the driver runs N = 1 — no torch.distributed.run: ONE process drives two contexts,
+    hr_comm_init_local + hr_allreduce_accumulators.  On this 1-GPU box both contexts share device 0 (the library's same-device
+    sum, labelled FALLBACK in config.parallelism); with two GPUs the same calls are one RCCL group all-reduce.  The summed
+    accumulator must equal a single-rank run over the same sampling indices (samplings 1..8 either way)."""
+    j1, m1 = _bench_line(_run_bench(["--steps", "4"]))
+    j2, m2 = _bench_line(_run_bench(["--gpus", "2", "--steps", "2"]))
+    assert abs(m1 - m2) <= 1e-6 * m1, (m1, m2)
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0
+    import torch
+    par = j2["config"]["parallelism"]
+    assert "spp-sharded x2" in par and ("RCCL group all-reduce" in par if torch.cuda.device_count() >= 2 else "FALLBACK" in par), par
+    # the bench line's roofline: loaded bytes can not exceed the §8(d) booking, nothing above 1, and the traversal-only workload is there
+    r = j1["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and 0 < r["frac_alone"] < 1 and r["frac"] <= r["survey_8d"]["frac"]
+    assert 0 < r["traversal_section"]["share_of_wave_cycles"] < 1 and r["traversal_only"]["Mrays_per_s"] > 0 and 0 < r["traversal_only"]["frac"] < 1
+    assert "cpu_baseline" not in j1 and j1["config"]["estimator"].startswith("reference")
+    # three contexts, odd step count
+    j3, m3 = _bench_line(_run_bench(["--gpus", "3", "--steps", "1", "--no-counters"]))
+    _, m3ref = _bench_line(_run_bench(["--steps", "3", "--no-counters"]))
+    assert j3["n_gpus"] == 3 and abs(m3 - m3ref) <= 1e-6 * m3ref
+
+
+def test_bench_multirank_path_on_one_gpu(tmp_path):
+    """bench.py's launcher path (one process per rank under torch.distributed.run: sharding by sampling index, one all-reduce) run
+    as two ranks on ONE GPU (HR_BENCH_ONE_DEVICE: gloo on a host copy, RCCL refuses two ranks per device): the summed accumulator
+    must equal a single-rank run over the same sampling indices."""
+    j1, m1 = _bench_line(_run_bench(["--steps", "4", "--no-counters"]))
+    j2, m2 = _bench_line(_run_bench(["--gpus", "2", "--steps", "2", "--no-counters"], env={"HR_BENCH_ONE_DEVICE": "1"}, launcher_ranks=2))
     assert abs(m1 - m2) <= 1e-6 * m1
-    j = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "roofline" in j
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0 and "roofline" in j2
 
 
 def test_config5_4k_crops(gpu, scenes):
@@ -582,7 +702,7 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
             gpu.set_resolution(w, h)
             outs = []
             for mode in (0, 1, 2):
-                gpu.set_option("seed_mode", mode)
+                gpu.set_debug_option("seed_mode", mode)
                 gpu.clear()
                 gpu.render(begin, end, stride)
                 outs.append(gpu.read_accumulator().astype(np.float64))
@@ -590,7 +710,7 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
                 assert np.isfinite(o).all()
                 assert np.abs(outs[0] - o).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max()), (w, h, begin, end, stride)
     finally:
-        gpu.set_option("seed_mode", 2)
+        gpu.set_debug_option("seed_mode", 2)
 
 
 def test_cli_multi_device_in_one_process(tmp_path):

@@ -5,7 +5,7 @@
 #   usage: tools/prof_pmc.sh [outdir] [round-tag]      e.g. tools/prof_pmc.sh gpurun_out/pmc_r02 r02
 set -u
 OUT=${1:-gpurun_out/pmc}
-TAG=${2:-r02}
+TAG=${2:-r03}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CMD="python bench.py --steps 1 --warmup 0 --spp-per-step 4 --no-counters --no-cpu-baseline ${BENCH_ARGS:-}"
@@ -55,9 +55,15 @@ with open(out + "/summary.txt", "w") as o:
             if c in per: e[key] = per[c] / PATHS
         if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per: e["l2_hit_rate"] = per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
         if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per: e["valu_lane_utilisation"] = per["SQ_THREAD_CYCLES_VALU"] / max(1.0, per["SQ_ACTIVE_INST_VALU"] * 64)
+        # texture addresser busy: TA_TA_BUSY_sum counts busy cycles over all CUs; GRBM_GUI_ACTIVE = the kernel's cycles (kernels run serialised under PMC)
+        if "TA_TA_BUSY_sum" in per and "GRBM_GUI_ACTIVE" in per: e["ta_busy_frac"] = per["TA_TA_BUSY_sum"] / max(1.0, 256.0 * per["GRBM_GUI_ACTIVE"])
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in per: e["l1_line_accesses_per_path"] = per["TCP_TOTAL_CACHE_ACCESSES_sum"] / PATHS
+        if "TCP_TCC_READ_REQ_sum" in per: e["l1_to_l2_requests_per_path"] = per["TCP_TCC_READ_REQ_sum"] / PATHS
         if name in kernels: continue
         kernels[name] = e
-json.dump({"paths_per_launch": PATHS, "kernels": kernels,
+sys.path.insert(0, ".")
+from bench import kernel_source_sha
+json.dump({"paths_per_launch": PATHS, "kernels": kernels, "csrc_sha": kernel_source_sha(),
            "source": "profiles/%s_pmc_summary.txt (tools/prof_pmc.sh: separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction; kernels run serialised under PMC)" % tag},
           open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())

@@ -13,16 +13,16 @@ sc = ha.Scene("rtcamp6_v3_1")
 r = ha.Renderer(0)
 r.upload_scene(sc)
 r.set_resolution(1920, 1080)
-r.set_option("seed_split", split)
-r.set_option("seed_mode", mode)
+r.set_debug_option("seed_split", split)
+r.set_debug_option("seed_mode", mode)
 for label, skip in (("seed kernel alone", 16), ("next to the trace kernel", 0)):
-    r.set_option("seed_prof", 0)
-    r.set_option("debug_skip", 0)
+    r.set_debug_option("seed_prof", 0)
+    r.set_debug_option("debug_skip", 0)
     r.render(1, 9)
     r.synchronize()
     r.clear()
-    r.set_option("seed_prof", 1)
-    r.set_option("debug_skip", skip)
+    r.set_debug_option("seed_prof", 1)
+    r.set_debug_option("debug_skip", skip)
     r.render(1, 33)
     r.synchronize()
     st = r.stats()
