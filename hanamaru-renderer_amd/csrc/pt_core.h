@@ -117,18 +117,43 @@ HD void tri_test(const Tri &tr, const Ray &r, TraceState &ts, int32_t index, Lan
     if (!(t >= 0.0f && t <= ts.t)) return;
     ts.t = t; ts.prim = index; ts.type = 0; ts.u = u; ts.v = v;
 }
-// scene.rs:58-78 (outer root only).  Same roots as the reference's b^2 - c form, but the discriminant is
-// taken from the perpendicular offset of the centre (r^2 - |a - b d|^2), which does not cancel in fp32
-// when the origin is many radii away (the f64 reference does not need this).
+// scene.rs:58-78 (outer root only), in f64 on the fp32 ray and sphere.  Same roots as the reference's b^2 - c form, with the
+// discriminant taken from the perpendicular offset of the centre (r^2 - |a - b d|^2: no cancellation when the origin is many radii
+// away).  Two things make this the one primitive test that is not fp32:
+//   * the fp32 direction is a unit vector only to ~2e-7 (v_rsq_f32, v_sin / v_cos), and unlike the triangle and slab tests — exact
+//     for any direction length — the quadratic takes |d| = 1 for granted: the hit distance would be off by (|d|^2 - 1) t, ten times the
+//     rounding of the position itself, with a bias that showed in the image MEAN of sphere scenes (4e-5).  The roots are therefore
+//     those of |a + t d|^2 = r^2 with dd = |d|^2 divided out (1 / dd = 2 - dd to 1e-14);
+//   * the hit / miss decision at a silhouette and the distance of a grazing hit (t = -b - sqrt(disc), disc -> 0) lose most of their
+//     fp32 digits; in f64 the only error left is the fp32 ray's own.
+// Measured on the sphere-only scene (256x144x2 against the f64 oracle): channels within 1e-3 0.9907 -> 0.9958, image mean
+// 3.437471 -> 3.437606 (oracle 3.437607).  sqrt: v_rsq_f32 seed + one Newton step in f64 (1e-14), no f64 division or square root.
+HD double hr_sqrt_f64(double x) {
+    const double y0 = (double)HR_RSQ(fmaxf((float)x, 1e-30f));
+    const double y1 = y0 * fma(-0.5 * x, y0 * y0, 1.5);
+    return x * y1;
+}
+// returns the hit distance, or a negative value for a miss.  NOT inlined on the device: its ~20 live f64 values would otherwise
+// raise the register pressure of the whole leaf phase (measured: 8 -> 27 spilled VGPRs, trace kernel +7.8 %)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline))
+#else
+inline
+#endif
+float sphere_root(float sx, float sy, float sz, float sw, float ox, float oy, float oz, float ddx, float ddy, float ddz) {
+    const double ax = (double)ox - (double)sx, ay = (double)oy - (double)sy, az = (double)oz - (double)sz;
+    const double dx = ddx, dy = ddy, dz = ddz;
+    const double idd = 2.0 - fma(dx, dx, fma(dy, dy, dz * dz));
+    const double b = fma(ax, dx, fma(ay, dy, az * dz)) * idd;
+    const double px = fma(-b, dx, ax), py = fma(-b, dy, ay), pz = fma(-b, dz, az);
+    const double d = fma((double)sw, (double)sw, -fma(px, px, fma(py, py, pz * pz))) * idd;
+    if (!(d > 0.0)) return -1.0f;
+    return (float)(-b - hr_sqrt_f64(d));
+}
 template <bool CNT>
 HD void sphere_test(const f4 &s, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
     if (CNT) cn->sphere_tests++;
-    V3f a = r.o - v3(s.x, s.y, s.z);
-    float b = dot(a, r.d);
-    V3f perp = a - b * r.d;
-    float d = s.w * s.w - dot(perp, perp);
-    if (!(d > 0.0f)) return;
-    float t = -b - HR_SQRT(d);
+    const float t = sphere_root(s.x, s.y, s.z, s.w, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
     if (t > 0.0f && t < ts.t) { ts.t = t; ts.prim = index; ts.type = 1; }
 }
 // bvh.rs:20-39 + scene.rs:152-158 (hit part): slab test of the cuboid itself; the reference's `distance` is tmin if
@@ -247,8 +272,16 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         s.elem = tr.element;
     } else if (ts.type == 1) {
         const f4 sp = sc.spheres[ts.prim];
-        s.n = normalize(s.pos - v3(sp.x, sp.y, sp.z));
         s.elem = sc.sphere_elem[ts.prim];
+        {   // the normal from the f64 offset of the hit from the centre (as sphere_test: o - c is exact in f64, and a small sphere far
+            // from the origin would otherwise divide the fp32 rounding of the position, ~|o| 6e-8, by its radius)
+            const double t = ts.t;
+            const double nx = ((double)r.o.x - (double)sp.x) + t * (double)r.d.x, ny = ((double)r.o.y - (double)sp.y) + t * (double)r.d.y, nz = ((double)r.o.z - (double)sp.z) + t * (double)r.d.z;
+            const double l2 = fma(nx, nx, fma(ny, ny, nz * nz));
+            const double y0 = (double)HR_RSQ(fmaxf((float)l2, 1e-30f));
+            const double il = y0 * fma(-0.5 * l2, y0 * y0, 1.5);
+            s.n = v3((float)(nx * il), (float)(ny * il), (float)(nz * il));
+        }
         if (want_uv) {  // scene.rs:67-71
             s.v = 1.0f - acosf(fminf(fmaxf(s.n.y, -1.0f), 1.0f)) * (1.0f / PI_F);
             float sg = signbit(s.n.z) ? -1.0f : 1.0f;
@@ -362,8 +395,12 @@ HD V3f sample_ggx_half(float r0, float r1, V3f n, float alpha2) {  // material.r
     tangent_basis(n, t, b);
     float sn, cs;
     HR_SINCOS_2PI(r0, sn, cs);
-    float cos_theta = HR_SQRT((1.0f - r1) * HR_RCP(1.0f + (alpha2 - 1.0f) * r1));
-    float sin_theta = HR_SQRT(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));   // 1-ulp rcp/sqrt can push cos_theta past 1
+    // cos^2 = (1 - r1) / den, and sin^2 = 1 - cos^2 = alpha2 r1 / den taken from the same quotient instead of by subtraction: for a
+    // near-mirror GGX (alpha2 -> 0) cos^2 is 1 - O(alpha2), and 1 - cos^2 in fp32 would be rounding noise of ~1e-7, i.e. a half
+    // vector tilted by ~4e-4 where the f64 reference (material.rs:260-269, sqrt(1 - cos^2) with 1e-16 noise) tilts it by 1e-8
+    const float iden = HR_RCP(1.0f + (alpha2 - 1.0f) * r1);
+    float cos_theta = HR_SQRT(fmaxf((1.0f - r1) * iden, 0.0f));
+    float sin_theta = HR_SQRT(fmaxf(alpha2 * r1 * iden, 0.0f));
     return t * (sin_theta * cs) + b * (sin_theta * sn) + n * cos_theta;
 }
 HD float smith_lambda(float xn, float alpha2) { float a = HR_RCP(xn * xn) - 1.0f; return 0.5f * HR_SQRT(1.0f + alpha2 * a) - 0.5f; }

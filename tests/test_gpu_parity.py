@@ -6,7 +6,7 @@ Tolerances (stated once, used everywhere):
   * fp32 draws handed to the trace kernel: equal to the oracle's f64 draws rounded once to fp32.
   * closest-hit queries: same element; |t_gpu - t_ref| <= 2e-5 * max(1, t_ref) for 99 % (max 1e-3: grazing spheres); normals: median error < 1e-5 (meshes) /
     1e-4 (r = 0.1 spheres five units away: fp32 position error over the radius), 99.9 % < 2e-3.
-  * radiance accumulator, per channel: |gpu - oracle| <= 1e-2 * max(1, |oracle|) and <= 1e-3 * max(1, |oracle|) for the
+  * radiance accumulator, per channel (GATES; round 3 raised them after the f64 sphere test and the GGX half-vector fix): |gpu - oracle| <= 1e-2 * max(1, |oracle|) and <= 1e-3 * max(1, |oracle|) for the
     fractions of GATES below — per scene, set just under what is measured (an fp32 rounding difference can flip a
     branch — Fresnel coin, hit/miss at a silhouette, a grazing sphere hit — and then that one path decorrelates
     completely, SURVEY.md §7.5-3: scenes full of small spheres or refracting diamonds have more such paths than the
@@ -21,11 +21,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ATOL_REL = 1e-2
-# scene -> (least fraction of channels within 1e-2, within 1e-3); measured values in profiles/r02_parity_report.json
+# scene -> (least fraction of channels within 1e-2, within 1e-3); measured values in profiles/r03_parity_report.json and
+# profiles/r03_parity_lines.txt.  Round 3 (f64 sphere test and normal, cancellation-free GGX half vector) moved the three hard
+# scenes: spheres 0.9898 -> 0.9955 at this size, rtcamp5 0.9881 -> 0.9980, rtcamp6_v2 0.9947 -> 0.9974.  What is left in the
+# sphere scenes are mirror spheres of radius 0.1: a reflection multiplies the fp32 rounding of the incoming ray (6e-8) by
+# ~2 x distance / radius = 100, so a path that meets two of them looks up the sky a fraction of a texel away from where the f64
+# reference does — a property of fp32 rays, not of a test; the more samplings a pixel holds, the likelier it holds such a path
+# (64 samplings at full size: 0.991, hence the crop gate below).
 GATES = {
-    "rtcamp6_v3_1": (0.9995, 0.9990), "rtcamp6_dodeca": (0.9995, 0.9985), "rtcamp6_v3": (0.9995, 0.9985), "rtcamp6_v1": (0.9995, 0.9985),
-    "material_examples": (0.9995, 0.9970), "simple": (0.9995, 0.9970), "cornell_mini": (0.9990, 0.9975), "tbf3": (0.9990, 0.9950),
-    "rtcamp6_v2": (0.9975, 0.9900), "spheres": (0.9975, 0.9800), "rtcamp5": (0.9965, 0.9800),
+    "rtcamp6_v3_1": (0.9998, 0.9995), "rtcamp6_dodeca": (0.9996, 0.9990), "rtcamp6_v3": (0.9998, 0.9995), "rtcamp6_v1": (0.9996, 0.9994),
+    "material_examples": (0.9997, 0.9985), "simple": (0.9998, 0.9995), "cornell_mini": (0.9997, 0.9995), "tbf3": (0.9995, 0.9975),
+    "rtcamp6_v2": (0.9990, 0.9955), "spheres": (0.9990, 0.9950), "rtcamp5": (0.9990, 0.9965),
 }
 CROP_SLACK = (0.0015, 0.006)
 FRAC_OK = 0.9995   # the headline scene's gate, for the tests that render rtcamp6_v3_1
@@ -576,7 +582,7 @@ def test_config2_spheres_full_size_crops(gpu, scenes):
     gpu.set_option("counters", 1)
     # 64 samplings = 256 paths per pixel: a pixel is off by more than 1e-3 as soon as ONE of them took another branch (grazing
     # sphere rims), so the 1e-3 fraction falls with the sampling count while the 1e-2 fraction rises — gates for this count
-    _crop_parity(gpu, o, "spheres", 1920, 1080, 64, [(900, 190), (400, 160), (1150, 590), (0, 1016), (760, 900)], gates=(0.9990, 0.975), crop_slack=(0.0015, 0.02))
+    _crop_parity(gpu, o, "spheres", 1920, 1080, 64, [(900, 190), (400, 160), (1150, 590), (0, 1016), (760, 900)], gates=(0.9992, 0.9890), crop_slack=(0.0015, 0.016))
     st = gpu.stats()
     gpu.set_option("counters", 0)
     assert st["paths"] == 1920 * 1080 * 4 * 64 and st["rng_overflow"] == 0 and st["tri_tests"] == 0 and st["sphere_tests"] > 0
@@ -757,7 +763,10 @@ def test_cuboid_far_from_the_origin_stays_finite(gpu, ha, orc):
     acc = gpu.read_accumulator()
     assert np.isfinite(acc).all() and (acc >= 0).all()
     ref, _ = o.render(160, 90, 1, 5, threads=0)
-    assert abs(acc.mean() - ref.mean()) <= 0.03 * ref.mean(), (acc.mean(), ref.mean())
+    assert abs(acc.mean() - ref.mean()) <= 0.002 * ref.mean(), (acc.mean(), ref.mean())
+    f2, f3 = _fractions(acc, ref)
+    print("simple + 2000 units: within 1e-2 %.4f, within 1e-3 %.4f, mean gpu %.6g oracle %.6g" % (f2, f3, acc.mean(), ref.mean()))
+    assert f2 >= 0.99 and f3 >= 0.95, (f2, f3)      # fp32 resolves 1.2e-4 at 2000 units: the ray offsets of 1e-4 are at the rounding limit
 
 
 def test_rccl_allreduce_of_the_accumulator(gpu, scenes, ha):
