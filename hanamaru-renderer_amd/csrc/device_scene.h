@@ -41,8 +41,10 @@ HD void node_set_box(Node &n, const float *mn, const float *mx, int octant) {
     n.neary = (octant & 2) ? mx[1] : mn[1]; n.fary = (octant & 2) ? mn[1] : mx[1];
     n.nearz = (octant & 4) ? mx[2] : mn[2]; n.farz = (octant & 4) ? mn[2] : mx[2];
 }
-HD bool node_word_is_leaf(uint32_t a) { return (a >> 28) != 0u && a != 0xffffffffu; }
-static const uint32_t NODE_END = 0xffffffffu;
+// links: node indices are below 2^28 - 1, NODE_END = 2^28 - 1 ends the walk, everything from 2^28 up is a leaf word — one compare
+// tells a leaf word from a successor
+static const uint32_t NODE_END = 0x0fffffffu;
+HD bool node_word_is_leaf(uint32_t a) { return a >= 0x10000000u; }
 
 // The trace kernel's node: 16 bytes, ONE load per visit.  The six planes are 16-bit coordinates on a grid over the scene's box
 // (plane = qmin + q * qstep per axis), rounded outward by at least one step — a box that only grows can add node visits, never

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(PLOC_THREADS) void ploc_kernel(int n, Work w, uint3
         next_node -= total_made;
         uint32_t *t = cur; cur = nxt; nxt = t;
     }
-    if (tid == 0) w.parent[0] = NODE_END;
+    if (tid == 0) w.parent[0] = NO_PARENT;
 }
 
 // one thread per leaf walks up; the second arrival at a node fits it (its two subtrees are then complete)
@@ -86,7 +86,7 @@ __global__ void fit_kernel(int n, uint32_t max_leaf, Work w) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n || n == 1) return;
     uint32_t cur = w.parent[n - 1 + k];
-    while (cur != NODE_END) {
+    while (cur != NO_PARENT) {
         __threadfence();
         if (atomicAdd(&w.flags[cur], 1u) == 0u) return;
         __threadfence();

@@ -29,6 +29,8 @@
 namespace hr {
 namespace lbvh {
 
+static const uint32_t NO_PARENT = 0xffffffffu;   // parent[] of the root (the arrays are preset with bytes of 0xff)
+
 typedef unsigned long long mkey_t;
 typedef unsigned long long u64t;
 static const int KEY_INDEX_BITS = 20;   // flatten_scene admits < 2^20 primitives
@@ -134,7 +136,7 @@ HD void hierarchy_node(const mkey_t *keys, int n, int i, const Work &w) {
     uint32_t rc = (hi == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
     w.left[i] = lc; w.right[i] = rc;
     w.parent[lc] = (uint32_t)i; w.parent[rc] = (uint32_t)i;
-    if (i == 0) w.parent[0] = NODE_END;
+    if (i == 0) w.parent[0] = NO_PARENT;
 }
 
 // ---- leaf node of sorted position k: box, type, counts
@@ -212,13 +214,13 @@ HD bool is_collapsed(const Work &w, uint32_t node) { return (w.info[node] & INFO
 HD bool is_leaf_top(const Work &w, uint32_t node) {
     if (!is_collapsed(w, node)) return false;
     uint32_t par = w.parent[node];
-    return par == NODE_END || !is_collapsed(w, par);
+    return par == NO_PARENT || !is_collapsed(w, par);
 }
 HD bool is_emitted(const Work &w, uint32_t node) { return !is_collapsed(w, node) || is_leaf_top(w, node); }
 // primitives of type t that precede the subtree of `node` in left-first depth-first order
 HD uint32_t type_rank(const Work &w, uint32_t node, uint32_t t) {
     uint32_t r = 0, c = node;
-    for (uint32_t par = w.parent[c]; par != NODE_END; c = par, par = w.parent[c])
+    for (uint32_t par = w.parent[c]; par != NO_PARENT; c = par, par = w.parent[c])
         if (c == w.right[par]) r += tc_of(w.tc[w.left[par]], t);
     return r;
 }
@@ -230,7 +232,7 @@ HD bool near_is_right(const Work &w, uint32_t inner, int o) {
 // index of an emitted node in octant o's near-first preorder
 HD uint32_t preorder_index(const Work &w, uint32_t node, int o) {
     uint32_t idx = 0, c = node;
-    for (uint32_t par = w.parent[c]; par != NODE_END; c = par, par = w.parent[c]) {
+    for (uint32_t par = w.parent[c]; par != NO_PARENT; c = par, par = w.parent[c]) {
         uint32_t nearc = near_is_right(w, par, o) ? w.right[par] : w.left[par];
         idx += (c == nearc) ? 1u : 1u + w.size[nearc];
     }

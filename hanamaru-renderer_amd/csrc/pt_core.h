@@ -193,24 +193,33 @@ HD bool node_hit(const Node &nd, const Ray &r, float tbest) {
     const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
     return tmin <= tmax && !signbit(tmax) && tmin <= tbest;
 }
+// What a visit does to the walk.  `link` is the record's link word (inner: miss successor, leaf: leaf word), `next` the successor
+// in preorder (inner: the near child, leaf: the node behind it).  Written for the instruction count of the box phase's loop: one
+// compare for leaf-ness, one select for the walk, two for the parked leaves.
+// SPEC (trace kernel): a lane walks on with ONE leaf parked and stops at the second.  The two slots are a shift register — the
+// newest leaf in ts.leaf, the one before it in ts.leaf2 — so that parking is two selects on one mask; the leaf phase tests the OLDER
+// one first (trace_leaf_next): leaves are tested in walk order.
 template <bool SPEC>
-HD void node_advance(TraceState &ts, bool hit, uint32_t a, uint32_t b) {
-    const bool leaf = node_word_is_leaf(a);
-    ts.cur = (hit && !leaf) ? a : b;
+HD void node_advance(TraceState &ts, bool hit, uint32_t link, uint32_t next) {
+    const bool leaf = node_word_is_leaf(link);
+    ts.cur = (leaf || hit) ? next : link;
+    const bool found = leaf && hit;
     if (SPEC) {
-        const uint32_t found = (hit && leaf) ? a : 0u;
-        const bool first = ts.leaf == 0u;
-        ts.leaf2 = first ? 0u : found;
-        ts.leaf = first ? found : ts.leaf;
+        ts.leaf2 = found ? ts.leaf : ts.leaf2;
+        ts.leaf = found ? link : ts.leaf;
     } else {
-        ts.leaf = (hit && leaf) ? a : 0u;
+        ts.leaf = found ? link : 0u;
     }
 }
+// SPEC walk: may this lane take another node?  (not finished, and at most one leaf parked)
+HD bool trace_can_walk(const TraceState &ts) { return ts.leaf2 == 0u && ts.cur != NODE_END; }
 template <bool CNT, bool SPEC = false>
 HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
     const Node nd = sc.nodes[(size_t)r.oct * sc.num_nodes + ts.cur];
     if (CNT) cn->node_tests++;
-    node_advance<SPEC>(ts, node_hit(nd, r, ts.t), nd.a, nd.b);
+    // 32-byte records carry both successors: a = hit (inner: near child; leaf: leaf word), b = miss / leaf done
+    const bool leaf = node_word_is_leaf(nd.a);
+    node_advance<SPEC>(ts, node_hit(nd, r, ts.t), leaf ? nd.a : nd.b, leaf ? nd.b : nd.a);
 }
 // One visit on the 16-byte nodes: a single 16-byte load; the six planes are grid coordinates, exact in fp32, and the box test is
 // six FMAs on the ray's precomputed (qinv, qc).  The grid planes lie at least one step outside the true box and the fp32 error
@@ -227,8 +236,7 @@ HD void trace_qnode(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters 
     const float tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
     const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
     const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
-    const bool leaf = node_word_is_leaf(nd.link);
-    node_advance<SPEC>(ts, hit, leaf ? nd.link : ts.cur + 1u, leaf ? ts.cur + 1u : nd.link);
+    node_advance<SPEC>(ts, hit, nd.link, ts.cur + 1u);
 }
 template <bool CNT>
 HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
@@ -249,6 +257,16 @@ HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *
         for (uint32_t k = 0; k < count; k++)
             cuboid_test<CNT>(sc.cuboids[2 * (first + k)], sc.cuboids[2 * (first + k) + 1], r, ts, (int32_t)(first + k), cn);
     }
+}
+// SPEC walk: test the OLDER of the parked leaves (ts.leaf2 when two are parked, else ts.leaf) and free its slot
+template <bool CNT>
+HD void trace_leaf_next(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
+    const bool two = ts.leaf2 != 0u;
+    const uint32_t newest = ts.leaf;
+    ts.leaf = two ? ts.leaf2 : ts.leaf;
+    trace_leaf<CNT>(sc, r, ts, cn);          // tests ts.leaf, clears it
+    ts.leaf = two ? newest : 0u;
+    ts.leaf2 = 0u;
 }
 // scalar convenience (host emulation, debug kernel): one visit = node + its leaf
 template <bool CNT>

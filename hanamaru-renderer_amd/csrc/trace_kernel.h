@@ -8,6 +8,8 @@
 
 using namespace hr;
 
+// ballot of a bool without HIP's int round trip (__ballot(int) compiles to v_cndmask 0/1 + v_cmp_ne; this is the lane mask itself)
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -41,10 +43,10 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
                                               const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws) {
     for (;;) {
         const bool trav = active && !trace_done(p.ts);
-        const uint32_t n_trav = (uint32_t)__popcll(__ballot(trav));
+        const uint32_t n_trav = (uint32_t)__popcll(wave_ballot(trav));
         if (!n_trav || (n_active - n_trav) * adv_den >= n_active) break;
         // lanes allowed to be still walking when the leaf phase starts
-        const uint32_t park = (n_trav + leaf_den - 1u) / leaf_den;
+        const uint32_t park = leaf_den == 2u ? (n_trav + 1u) >> 1 : (n_trav + leaf_den - 1u) / leaf_den;   // (no scalar division for the default)
         const uint32_t walk_max = n_trav - park;
         HR_PHASE_BEGIN(ws);
         // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
@@ -52,34 +54,35 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
         // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
         // and costs ~1 % when the seed kernel is.  Level 2 adds the leaf phase (another +1 - 2 % where the trace kernel is far behind).
         if (rp.trace_boost) __builtin_amdgcn_s_setprio(1);
-        for (;;) {
-            // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second
-            const bool go = trav && p.ts.leaf2 == 0 && p.ts.cur != NODE_END;
-            const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
-            if (n_go <= walk_max) break;
+        // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second.  The loop is written with its
+        // wave-uniform test at the bottom: as `for (;;) { if (n_go <= walk_max) break; if (go) ... }` the compiler folds the exit
+        // into the lane mask of `if (go)` and copies the live-out walk state every pass.
+        bool go = trav && trace_can_walk(p.ts);
+        uint32_t n_go = (uint32_t)__popcll(wave_ballot(go));
+        while (n_go > walk_max) {
             if (CNT) { ws.ph[2]++; ws.ph[3] += n_go; }
             if (go) {
                 if (QN) {
                     trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
-                    if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (rp.node_unroll > 1u && trace_can_walk(p.ts)) trace_qnode<CNT, true>(sc, p.ray, p.ts, &lc);
                 } else {
                     trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
-                    if (rp.node_unroll > 1u && p.ts.leaf2 == 0 && p.ts.cur != NODE_END) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
+                    if (rp.node_unroll > 1u && trace_can_walk(p.ts)) trace_node<CNT, true>(sc, p.ray, p.ts, &lc);
                 }
             }
+            go = go && trace_can_walk(p.ts);
+            n_go = (uint32_t)__popcll(wave_ballot(go));
         }
         if (rp.trace_boost) __builtin_amdgcn_s_setprio(0);
         HR_PHASE_END(ws, 2);
         HR_PHASE_BEGIN(ws);
         if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(1);   // level 2: the leaf phase too
         if (CNT) {
-            uint32_t n = (uint32_t)__popcll(__ballot(trav && p.ts.leaf != 0));
+            uint32_t n = (uint32_t)__popcll(wave_ballot(trav && p.ts.leaf != 0));
             if (n) { ws.ph[4]++; ws.ph[5] += n; }
         }
         if (trav && p.ts.leaf != 0) {
-            trace_leaf<CNT>(sc, p.ray, p.ts, &lc);   // clears ts.leaf
-            p.ts.leaf = p.ts.leaf2;
-            p.ts.leaf2 = 0;
+            trace_leaf_next<CNT>(sc, p.ray, p.ts, &lc);   // the older parked leaf; the newer one (if any) moves up
             shadow_early_out(p);
         }
         if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(0);
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     for (;;) {
         // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
         if (CNT) {
-            uint32_t n = (uint32_t)__popcll(__ballot(p.q != PATH_IDLE && trace_done(p.ts)));
+            uint32_t n = (uint32_t)__popcll(wave_ballot(p.q != PATH_IDLE && trace_done(p.ts)));
             ws.ph[6]++;
             if (n) { ws.ph[0]++; ws.ph[1] += n; }
         }
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         HR_PHASE_END(ws, 0);
         // ---- B: refill idle lanes (ballot + prefix rank = live-lane compaction); pull a new tile when the queue is dry
         HR_PHASE_BEGIN(ws);
-        unsigned long long idle = __ballot(p.q == PATH_IDLE);
+        unsigned long long idle = wave_ballot(p.q == PATH_IDLE);
         if (idle) {
             if (next >= total && !exhausted) {
                 uint32_t t = 0;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         }
         HR_PHASE_END(ws, 1);
         const bool active = p.q != PATH_IDLE;
-        const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+        const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
         if (!n_active) {
             if (exhausted) break;
             continue;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams 
     if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
     LaneCounters lc = {0, 0, 0, 0, 0};
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
-    const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+    const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws);
     if (!active) return;
     float *o = out + (size_t)i * 8;
@@ -280,19 +283,19 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
     ray_quantise(sc, p.ray);
     trace_begin(p.ts, T_INF);
     if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
-    const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
+    const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
     traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, leaf_den, lc, ws);
     if (CNT && active) lc.rays++;
     V3f val = v3(0, 0, 0), lit = v3(0, 0, 0);
     Ray sh = p.ray;
     const bool more = active && debug_primary(sc, p.ray, p.ts, mode, val, lit, sh);
-    if (__ballot(more)) {   // Shading mode: the shadow ray towards the fixed light, any closest hit darkens
+    if (wave_ballot(more)) {   // Shading mode: the shadow ray towards the fixed light, any closest hit darkens
         p.ray = sh;
         ray_quantise(sc, p.ray);
         trace_begin(p.ts, T_INF);
         if (!more) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
-        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(__ballot(more)), 0u, leaf_den, lc, ws);
+        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(wave_ballot(more)), 0u, leaf_den, lc, ws);
         if (CNT && more) lc.rays++;
         if (more) val = val + lit * (p.ts.prim >= 0 ? 0.5f : 1.0f);
     }

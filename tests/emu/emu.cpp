@@ -142,7 +142,7 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder) {
     std::vector<mkey_t> keys(n);
     for (int i = 0; i < n; i++) keys[i] = prim_key(p, (uint32_t)i);
     std::sort(keys.begin(), keys.end());
-    std::vector<uint32_t> parent(N, NODE_END), left(n), right(n), flags(n, 0), info(N, 0), size(N, 0), axis_low(n, 0), word(N, 0), prim_pos(n, 0);
+    std::vector<uint32_t> parent(N, NO_PARENT), left(n), right(n), flags(n, 0), info(N, 0), size(N, 0), axis_low(n, 0), word(N, 0), prim_pos(n, 0);
     std::vector<u64t> tc(N, 0);
     std::vector<float> bmin(3 * (size_t)N), bmax(3 * (size_t)N);
     Work w{parent.data(), left.data(), right.data(), flags.data(), bmin.data(), bmax.data(), info.data(), tc.data(), size.data(), axis_low.data(), word.data()};
@@ -166,11 +166,11 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder) {
             m = pos;
             cl.swap(nxt);
         }
-        parent[0] = NODE_END;
+        parent[0] = NO_PARENT;
     }
     for (int k = 0; k < n && n > 1; k++) {   // bottom-up fit: the second arrival at a node fits it
         uint32_t cur = parent[n - 1 + k];
-        while (cur != NODE_END) {
+        while (cur != NO_PARENT) {
             if (flags[cur]++ == 0) break;
             fit_inner(n, cur, (uint32_t)max_leaf, w);
             cur = parent[cur];
@@ -363,7 +363,7 @@ int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out,
             while (!trace_done(ts)) {
                 if (g_walk_mode == 2) while (ts.cur != NODE_END && ts.leaf2 == 0) trace_qnode<true, true>(sc, r, ts, &lc);
                 else while (ts.cur != NODE_END && ts.leaf2 == 0) trace_node<true, true>(sc, r, ts, &lc);
-                if (ts.leaf) { trace_leaf<true>(sc, r, ts, &lc); ts.leaf = ts.leaf2; ts.leaf2 = 0; }
+                if (ts.leaf) trace_leaf_next<true>(sc, r, ts, &lc);
             }
         }
         g_node_tests += lc.node_tests;
