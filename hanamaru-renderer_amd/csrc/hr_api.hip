@@ -256,7 +256,9 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     // with it — the two would silently run one after the other, 40 % slower.  Refuse to start in that state.
     {
         const void *trace_variants[] = {(const void *)trace_kernel<false, 5, true>, (const void *)trace_kernel<false, 5, false>, (const void *)trace_kernel<false, 4, true>,
-                                        (const void *)trace_kernel<false, 6, true>, (const void *)trace_kernel<true, 3, true>, (const void *)trace_kernel<true, 3, false>};
+                                        (const void *)trace_kernel<false, 6, true>, (const void *)trace_kernel<true, 3, true>, (const void *)trace_kernel<true, 3, false>,
+                                        (const void *)trace_kernel<false, 5, true, true>, (const void *)trace_kernel<false, 5, false, true>,
+                                        (const void *)trace_kernel<true, 3, true, true>, (const void *)trace_kernel<true, 3, false, true>};
         for (const void *f : trace_variants) {
             hipFuncAttributes fa;
             HIP_TRY(hipFuncGetAttributes(&fa, f));
@@ -634,13 +636,19 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
             dim3 g(grid), b(64 * TRACE_WAVES);
 #define HR_LAUNCH_TRACE(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
             const bool qn = c->dsc.qnodes != nullptr;
+#define HR_LAUNCH_TRACE_RR(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
             if (c->debug_skip & 16) {
+            } else if (c->rr_start) {   // the non-parity estimator has its own instantiations (one occupancy variant)
+                if (c->counters) { if (qn) HR_LAUNCH_TRACE_RR(true, 3, true); else HR_LAUNCH_TRACE_RR(true, 3, false); }
+                else if (qn) HR_LAUNCH_TRACE_RR(false, 5, true);
+                else HR_LAUNCH_TRACE_RR(false, 5, false);
             } else if (c->counters) { if (qn) HR_LAUNCH_TRACE(true, 3, true); else HR_LAUNCH_TRACE(true, 3, false); }
             else if (!qn) HR_LAUNCH_TRACE(false, 5, false);
             else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4, true);
             else if (c->min_waves == 6) HR_LAUNCH_TRACE(false, 6, true);
             else HR_LAUNCH_TRACE(false, 5, true);
 #undef HR_LAUNCH_TRACE
+#undef HR_LAUNCH_TRACE_RR
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, c->stream));

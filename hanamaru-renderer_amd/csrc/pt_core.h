@@ -561,8 +561,19 @@ HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
 }
 
 // returns true when the path is finished (accum final)
-template <bool CNT>
-HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *cn) {
+// RR / rr_start: Russian roulette from that iteration on (off = the reference's estimator: renderer.rs:174-200 has none).  A template
+// parameter: the roulette's few instructions in the default kernel cost it 2 % next to the seed kernel (measured), so the default
+// instantiation does not contain them.
+// The roulette's uniform variates come from an integer hash of (tile, lane, sampling, iteration) — NOT from the path's ISAAC-64
+// stream, whose draws the reference estimator has all spoken for (and whose seed kernel is not to be touched: a spare word in the
+// hand-off record was tried and cost the hand-scheduled consumer wave 1 % by its changed register allocation).
+HD float rr_uniform(uint32_t tile, uint32_t q, uint32_t salt, uint32_t iter) {
+    uint32_t x = tile * 0x9E3779B1u ^ (q & 0xfffu) * 0x85EBCA77u ^ salt * 0xC2B2AE3Du ^ iter * 0x27D4EB2Fu;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+template <bool CNT, bool RR = false>
+HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *cn, uint32_t rr_start = 0u, uint32_t rr_salt = 0u) {
     if (CNT) cn->rays++;
     const bool hit = p.ts.prim >= 0;
     if (!path_in_shadow_phase(p)) {
@@ -613,6 +624,13 @@ HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *
     // renderer.rs:197-199 (a miss returned above)
     p.refl = p.refl * p.cur_refl;
     if (is_zero(p.refl) || path_iter(p) >= 9u) return true;
+    if (RR && path_iter(p) + 1u >= rr_start) {
+        // NOT the reference's estimator (option "russian_roulette", off by default).  The path enters iteration i + 1 with probability
+        // q = max(reflectance), capped at 1, and its reflectance is divided by q: E[weight] = 1 whatever the path did so far.
+        const float q = fminf(fmaxf(fmaxf(p.refl.x, p.refl.y), p.refl.z), 1.0f);
+        if (!(rr_uniform(p.tile, p.q, rr_salt, path_iter(p)) < q)) return true;
+        p.refl = p.refl * HR_RCP(q);
+    }
     p.st++;
     ray_set(p.ray, p.next_o, p.next_d);
     ray_quantise(sc, p.ray);

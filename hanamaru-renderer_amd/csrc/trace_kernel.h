@@ -111,7 +111,7 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uin
     }
 }
 
-template <bool CNT, int MINW, bool QN>
+template <bool CNT, int MINW, bool QN, bool RR = false>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ recs,
                                                                        float *__restrict__ accum, Counters *cnt, uint32_t *tile_counter) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         }
         HR_PHASE_BEGIN(ws);
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
-            if (path_advance<CNT>(sc, p, recs + (size_t)p.tile * tile_stride, &lc)) {
+            if (path_advance<CNT, RR>(sc, p, recs + (size_t)p.tile * tile_stride, &lc, rp.rr_start, rp.sampling_begin * 64u + rp.stride)) {
                 // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
                 // path adds its radiance straight into the accumulator.  A work unit is one tile x up to TRACE_KCHUNK
                 // samplings, so with more than TRACE_KCHUNK samplings per launch several waves — in other workgroups,

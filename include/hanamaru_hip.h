@@ -212,10 +212,11 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *   "quant_nodes"   1 = the trace kernel walks the 16-byte quantised node records (default), 0 = the 32-byte fp32 records of the
  *                   same tree (identical hits)
  * One option that does NOT preserve the image (off by default; every parity test runs with it off):
- *   "russian_roulette"  0 = off.  k in 2..9: from path iteration k on a path survives with probability q = max(reflectance),
- *                   quantised up to a multiple of 1/16, and its reflectance is divided by q.  The reference has no Russian
- *                   roulette (renderer.rs:174-200 runs every path to the bounce limit); the estimator stays unbiased (the
- *                   decisions use bits of the path's ISAAC-64 outputs that nothing else consumes), its noise changes. */
+ *   "russian_roulette"  0 = off.  k in 2..9: from path iteration k on a path survives with probability q = min(1, max(reflectance))
+ *                   and its reflectance is divided by q.  The reference has no Russian roulette (renderer.rs:174-200 runs every
+ *                   path to the bounce limit); the estimator stays unbiased (the decisions come from a hash of the path's
+ *                   indices, not from its ISAAC-64 stream, whose draws the reference estimator has all spoken for); its noise
+ *                   changes, it traces ~10 % fewer rays. */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
 /* Measurement / experiment knobs, kept out of hr_set_option so that a host cannot change the kernels' schedule — or produce a
  * garbage image — by a key string meant for a product option: "adv_den" / "leaf_den" (trace-kernel phase thresholds), "min_waves"

@@ -742,6 +742,46 @@ def test_cli_multi_device_in_one_process(tmp_path):
     assert diff.max() <= 1 and (diff == 0).mean() > 0.999
 
 
+def test_russian_roulette_is_unbiased_and_off_by_default(gpu, scenes):
+    """Option "russian_roulette" (north_star names it; the reference has none, renderer.rs:174-200, so it is off by default and
+    every parity test runs without it).  On: paths die with probability 1 - q from the chosen iteration on and survivors are
+    re-weighted by 1 / q — fewer rays per path, more noise, the SAME expectation: the image mean over 128 samplings agrees with the
+    reference estimator's (GPU without roulette, itself parity-checked) and with the f64 oracle's, block means show no drift."""
+    sc, o = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    w, h, S = 160, 90, 128
+    gpu.set_resolution(w, h)
+
+    def render(rr):
+        gpu.set_option("russian_roulette", rr)
+        gpu.set_option("counters", 1)
+        gpu.clear()
+        gpu.render(1, S + 1)
+        acc = gpu.read_accumulator().astype(np.float64)
+        st = gpu.stats()
+        gpu.set_option("counters", 0)
+        gpu.set_option("russian_roulette", 0)
+        return acc, st["rays"] / st["paths"]
+
+    ref, rays_ref = render(0)
+    again, _ = render(0)
+    assert np.abs(ref - again).max() <= 1e-4 * max(1.0, np.abs(ref).max())      # off means off: only the summation order varies
+    for start in (2, 4):
+        rr, rays_rr = render(start)
+        assert np.isfinite(rr).all() and (rr >= 0).all()
+        assert rays_rr < (0.9 if start == 2 else 0.97) * rays_ref, (start, rays_rr, rays_ref)
+        assert abs(rr.mean() - ref.mean()) <= 4e-3 * ref.mean(), (start, rr.mean(), ref.mean())
+        # 10 x 10-pixel blocks: relative differences scatter around zero (no region is systematically darker or brighter)
+        bl = lambda a: a[:h // 10 * 10, :w // 10 * 10].reshape(h // 10, 10, w // 10, 10, 3).sum(axis=(1, 3, 4))
+        rel = (bl(rr) - bl(ref)) / bl(ref)
+        assert abs(rel.mean()) < 5e-3 and np.median(np.abs(rel)) < 0.03 and np.abs(rel).max() < 0.6, (start, rel.mean(), np.median(np.abs(rel)), np.abs(rel).max())
+        print("russian roulette from iteration %d: rays per path %.3f -> %.3f, image mean %.6g vs %.6g, block drift %.2e" % (start, rays_ref, rays_rr, rr.mean(), ref.mean(), rel.mean()))
+    # and against the f64 oracle itself, same 128 samplings (the roulette adds variance: at 16 samplings the means differ by 1.5 %)
+    orc_acc, _ = o.render(w, h, 1, S + 1, threads=0)
+    rr3, _ = render(3)
+    assert abs(rr3.mean() - orc_acc.mean()) <= 4e-3 * orc_acc.mean(), (rr3.mean(), orc_acc.mean())
+
+
 def test_cuboid_far_from_the_origin_stays_finite(gpu, ha, orc):
     """The cuboid face cascade compares the hit position with the face planes at an absolute EPS of 1e-4 (scene.rs:160-182); in
     fp32 a position 2000 units from the origin is off by more than that, no face matches, and a zero normal would put NaNs
