@@ -81,6 +81,51 @@ __global__ __launch_bounds__(PLOC_THREADS) void ploc_kernel(int n, Work w, uint3
     if (tid == 0) w.parent[0] = NO_PARENT;
 }
 
+// PLOC over several workgroups (scenes beyond what one workgroup iterates in reasonable time: the single-workgroup kernel above takes
+// 3 - 5 ms at 10^4 primitives and would take seconds at 10^6).  One iteration = four launches on the build stream:
+//   ploc_nn_kernel     every cluster's nearest neighbour within +-PLOC_RADIUS (reads the boxes the previous iteration's merges wrote)
+//   ploc_role_kernel   role per cluster -> packed counters {keeps a slot, makes a node}
+//   hipcub ExclusiveSum over the packed counters: the position of every survivor and the rank of every merge, in Morton order
+//   ploc_merge_kernel  merges + compaction into the other cluster array; the last cluster's thread writes the next iteration's
+//                      {cluster count, next free node id} into the OTHER half of a two-slot state (no kernel reads what it writes)
+// The cluster count lives on the device; the host reads it back every few iterations only to stop and to shrink the grids.
+struct PlocState { uint32_t m, next_node; };
+__global__ void ploc_init_kernel(int n, uint32_t *cl, PlocState *st) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < (uint32_t)n) cl[k] = (uint32_t)(n - 1) + k;
+    if (k == 0) { st[0].m = (uint32_t)n; st[0].next_node = (uint32_t)(n - 1); st[1] = st[0]; }
+}
+__global__ void ploc_nn_kernel(Work w, const uint32_t *cur, uint32_t *nn, const PlocState *st) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, m = st->m;
+    if (i < m && m > 1u) nn[i] = ploc_nearest(w, cur, m, i);
+}
+__global__ void ploc_role_kernel(const uint32_t *nn, u64t *flags, uint32_t count, const PlocState *st) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, m = st->m;
+    if (i >= count) return;
+    u64t f = 0;
+    if (i < m && m > 1u) {
+        const int role = ploc_role(nn, i);
+        f = (u64t)(role != 2) | ((u64t)(role == 1) << 32);
+    }
+    flags[i] = f;
+}
+__global__ void ploc_merge_kernel(Work w, const uint32_t *cur, uint32_t *nxt, const uint32_t *nn, const u64t *flags, const u64t *pos, const PlocState *st, PlocState *st_next) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, m = st->m;
+    if (m <= 1u) { if (i == 0) *st_next = *st; return; }
+    if (i >= m) return;
+    const u64t f = flags[i], p = pos[i];
+    const uint32_t slot = (uint32_t)p, mrank = (uint32_t)(p >> 32);
+    if ((uint32_t)f) {
+        if (f >> 32) {
+            const uint32_t id = st->next_node - 1u - mrank;
+            ploc_make_node(w, id, cur[i], cur[nn[i]]);
+            nxt[slot] = id;
+        } else nxt[slot] = cur[i];
+    }
+    if (i == m - 1u) { st_next->m = slot + (uint32_t)f; st_next->next_node = st->next_node - (mrank + (uint32_t)(f >> 32)); }
+}
+__global__ void ploc_root_kernel(Work w) { if (blockIdx.x == 0 && threadIdx.x == 0) w.parent[0] = NO_PARENT; }
+
 // one thread per leaf walks up; the second arrival at a node fits it (its two subtrees are then complete)
 __global__ void fit_kernel(int n, uint32_t max_leaf, Work w) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;

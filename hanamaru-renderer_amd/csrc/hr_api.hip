@@ -347,6 +347,17 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys, n, 0, 64, c->stream);
     if (e != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "hipcub sort (size query): %s", hipGetErrorString(e)); }
     LBVH_ALLOC(sort_tmp, unsigned char, sort_bytes, false)
+    // multi-workgroup PLOC: packed role counters, their scan, the two-slot iteration state
+    const bool ploc_multi = c->bvh_builder == 2 && n > PLOC_THREADS;
+    size_t scan_bytes = 0;
+    if (ploc_multi) {
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (u64t *)nullptr, (u64t *)nullptr, n, c->stream);
+        if (e != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "hipcub scan (size query): %s", hipGetErrorString(e)); }
+    }
+    LBVH_ALLOC(ploc_flags, u64t, ploc_multi ? n : 1, false)
+    LBVH_ALLOC(ploc_pos, u64t, ploc_multi ? n : 1, false)
+    LBVH_ALLOC(scan_tmp, unsigned char, scan_bytes, false)
+    LBVH_ALLOC(ploc_state, PlocState, 2, false)
 #undef LBVH_ALLOC
     hipEvent_t ea = nullptr, eb = nullptr;
     (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
@@ -362,7 +373,29 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     if (e == hipSuccess) {
         leaf_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, w);
         if (n > 1 && c->bvh_builder == 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
-        if (n > 1 && c->bvh_builder == 2) ploc_kernel<<<1, PLOC_THREADS, 0, st>>>(n, w, cl_a, cl_b, nn);
+        if (n > 1 && c->bvh_builder == 2 && !ploc_multi) ploc_kernel<<<1, PLOC_THREADS, 0, st>>>(n, w, cl_a, cl_b, nn);
+        if (ploc_multi) {
+            ploc_init_kernel<<<(n + T - 1) / T, T, 0, st>>>(n, cl_a, ploc_state);
+            uint32_t *cur = cl_a, *nxt = cl_b;
+            uint32_t m_known = (uint32_t)n;   // the host's upper bound of the cluster count (refreshed every few iterations)
+            for (int it = 0; it < 4096 && m_known > 1u && e == hipSuccess; it++) {
+                const uint32_t g = (m_known + T - 1) / T;
+                const PlocState *sin = ploc_state + (it & 1);
+                ploc_nn_kernel<<<g, T, 0, st>>>(w, cur, nn, sin);
+                ploc_role_kernel<<<g, T, 0, st>>>(nn, ploc_flags, m_known, sin);
+                e = hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, ploc_flags, ploc_pos, (int)m_known, st);
+                ploc_merge_kernel<<<g, T, 0, st>>>(w, cur, nxt, nn, ploc_flags, ploc_pos, sin, ploc_state + ((it + 1) & 1));
+                std::swap(cur, nxt);
+                if ((it & 3) == 3 || m_known <= 64u) {   // every fourth iteration (and every one at the very end): how many are left?
+                    PlocState hs{};
+                    if (e == hipSuccess) e = hipMemcpyAsync(&hs, ploc_state + ((it + 1) & 1), sizeof hs, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    if (e == hipSuccess) m_known = hs.m;
+                }
+            }
+            ploc_root_kernel<<<1, 64, 0, st>>>(w);
+            if (e == hipSuccess && m_known > 1u) e = hipErrorUnknown;   // did not converge (cannot happen: every iteration merges at least one pair)
+        }
         fit_kernel<<<(n + T - 1) / T, T, 0, st>>>(n, (uint32_t)c->max_leaf, w);
         finish_kernel<<<(N + T - 1) / T, T, 0, st>>>(p, n, w, prim_pos);
         frame_kernel<<<1, 64, 0, st>>>(w, frame);

