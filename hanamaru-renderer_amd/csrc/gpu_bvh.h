@@ -15,6 +15,18 @@ __global__ void key_kernel(Prims p, int n, mkey_t *keys) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = prim_key(p, (uint32_t)i);
 }
+// early split clipping: pieces per triangle, then (after an exclusive scan of the counts) their boxes and owners
+__global__ void split_count_kernel(const Tri *tris, uint32_t num_tris, SplitParams sp, uint32_t *counts) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < num_tris) counts[i] = split_tri(tris[i], sp, nullptr);
+}
+__global__ void split_emit_kernel(const Tri *tris, uint32_t num_tris, SplitParams sp, const uint32_t *offsets, uint32_t *ref_tri, float *ref_box) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_tris) return;
+    const uint32_t first = offsets[i];
+    const uint32_t cnt = split_tri(tris[i], sp, ref_box + 6 * (size_t)first);
+    for (uint32_t k = 0; k < cnt; k++) ref_tri[first + k] = i;
+}
 __global__ void leaf_kernel(Prims p, const mkey_t *keys, int n, Work w) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) fit_leaf(p, keys, n, k, w);
@@ -168,7 +180,7 @@ __global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t i = key_index(keys[k]), d = prim_pos[k];
-    if (i < p.num_tris) tris[d] = p.tris[i];
+    if (i < p.num_tris) tris[d] = p.tris[p.ref_tri ? p.ref_tri[i] : i];
     else if (i < p.num_tris + p.num_spheres) {
         uint32_t l = i - p.num_tris;
         d -= p.num_tris;

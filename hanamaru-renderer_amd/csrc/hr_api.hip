@@ -304,17 +304,27 @@ int hr_destroy(hr_ctx *c) {
 static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     using namespace lbvh;
     Scene &d = c->dsc;
-    const int n = (int)(d.num_tris + d.num_spheres + d.num_cuboids);
-    const int N = 2 * n - 1;
     Prims p{};
     p.tris = d.tris; p.num_tris = d.num_tris; p.spheres = d.spheres; p.num_spheres = d.num_spheres; p.cuboids = d.cuboids; p.num_cuboids = d.num_cuboids;
+    p.ref_tri = nullptr; p.ref_box = nullptr;
+    double scene_sa = 0.0;
     for (int a = 0; a < 3; a++) {
         double ext = hs.scene_max[a] - hs.scene_min[a];
         p.smin[a] = (float)hs.scene_min[a];
         p.sinv[a] = ext > 0 ? (float)(1.0 / ext) : 0.0f;
     }
+    {
+        const double e0 = hs.scene_max[0] - hs.scene_min[0], e1 = hs.scene_max[1] - hs.scene_min[1], e2 = hs.scene_max[2] - hs.scene_min[2];
+        if (e0 >= 0 && e1 >= 0 && e2 >= 0) scene_sa = 2.0 * (e0 * e1 + e1 * e2 + e2 * e0);
+    }
     std::vector<void *> scratch;
-    auto cleanup = [&]() { for (void *q : scratch) (void)hipFree(q); };
+    hipEvent_t ea = nullptr, eb = nullptr;   // around everything the build puts on the stream
+    auto cleanup = [&]() {
+        for (void *q : scratch) (void)hipFree(q);
+        scratch.clear();
+        if (ea) { (void)hipEventDestroy(ea); ea = nullptr; }
+        if (eb) { (void)hipEventDestroy(eb); eb = nullptr; }
+    };
     auto alloc = [&](size_t bytes, bool keep) -> void * {
         void *q = nullptr;
         if (hipMalloc(&q, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
@@ -324,6 +334,36 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
 #define LBVH_ALLOC(var, type, count, keep)                                                                        \
     type *var = (type *)alloc(sizeof(type) * (size_t)(count), keep);                                                \
     if (!var) { cleanup(); return fail(HR_ERR_DEVICE, "hr_upload_scene: out of device memory in the BVH build"); }
+    (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+    (void)hipEventRecord(ea, c->stream);
+    // Early split clipping on the device (option split_ratio: -1 = on with the host builder's automatic ratio of 2, 0 = off, > 0 = that
+    // ratio; the host builder's automatic mode also builds the unsplit tree and keeps the better one, the device always keeps the split):
+    // pieces per triangle, a scan, then the pieces' boxes and owners.  The builders below then see one primitive per piece.
+    if (c->split_ratio != 0.0 && d.num_tris > 0) {
+        SplitParams sp{c->split_ratio < 0 ? 2.0 : c->split_ratio, 1e-4 * scene_sa, SPLIT_MAX_DEPTH};
+        const uint32_t nt = d.num_tris;
+        LBVH_ALLOC(split_counts, uint32_t, nt, false)
+        LBVH_ALLOC(split_offsets, uint32_t, nt, false)
+        size_t sbytes = 0;
+        hipError_t se = hipcub::DeviceScan::ExclusiveSum(nullptr, sbytes, split_counts, split_offsets, (int)nt, c->stream);
+        LBVH_ALLOC(split_tmp, unsigned char, sbytes, false)
+        split_count_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(d.tris, nt, sp, split_counts);
+        if (se == hipSuccess) se = hipcub::DeviceScan::ExclusiveSum(split_tmp, sbytes, split_counts, split_offsets, (int)nt, c->stream);
+        uint32_t last[2] = {0, 0};
+        if (se == hipSuccess) se = hipMemcpyAsync(&last[0], split_offsets + (nt - 1), 4, hipMemcpyDeviceToHost, c->stream);
+        if (se == hipSuccess) se = hipMemcpyAsync(&last[1], split_counts + (nt - 1), 4, hipMemcpyDeviceToHost, c->stream);
+        if (se == hipSuccess) se = hipStreamSynchronize(c->stream);
+        if (se != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "device split clipping: %s", hipGetErrorString(se)); }
+        const uint64_t refs = (uint64_t)last[0] + last[1];
+        if (refs > nt && refs + d.num_spheres + d.num_cuboids < (1ull << KEY_INDEX_BITS)) {
+            LBVH_ALLOC(ref_tri, uint32_t, refs, false)
+            LBVH_ALLOC(ref_box, float, 6 * refs, false)
+            split_emit_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(d.tris, nt, sp, split_offsets, ref_tri, ref_box);
+            p.ref_tri = ref_tri; p.ref_box = ref_box; p.num_tris = (uint32_t)refs;
+        }
+    }
+    const int n = (int)(p.num_tris + p.num_spheres + p.num_cuboids);
+    const int N = 2 * n - 1;
     LBVH_ALLOC(keys_in, mkey_t, n, false)
     LBVH_ALLOC(keys, mkey_t, n, false)
     Work w{};
@@ -339,7 +379,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     // the emitted tree has size[root] <= 2n-1 records per octant (collapsed subtrees are one record): sized for the worst case
     LBVH_ALLOC(nodes, Node, 8 * (size_t)N + 1, true)
     LBVH_ALLOC(qnodes, QNode, 8 * ((size_t)N + 1), true)
-    LBVH_ALLOC(tris, Tri, d.num_tris, true)
+    LBVH_ALLOC(tris, Tri, p.num_tris, true)
     LBVH_ALLOC(spheres, f4, d.num_spheres, true)
     LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
     LBVH_ALLOC(cuboids, f4, 2 * (size_t)d.num_cuboids, true)
@@ -359,11 +399,8 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     LBVH_ALLOC(scan_tmp, unsigned char, scan_bytes, false)
     LBVH_ALLOC(ploc_state, PlocState, 2, false)
 #undef LBVH_ALLOC
-    hipEvent_t ea = nullptr, eb = nullptr;
-    (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
     const int T = 256;
     hipStream_t st = c->stream;
-    (void)hipEventRecord(ea, st);
     e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, st);
     if (e == hipSuccess) e = hipMemsetAsync(parent, 0xff, sizeof(uint32_t) * (size_t)N, st);   // n == 1: the lone leaf is the root
     if (e == hipSuccess) {
@@ -409,7 +446,6 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     float ms = 0;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ea, eb);
-    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     cleanup();
     if (e != hipSuccess) return fail(HR_ERR_DEVICE, "device BVH build: %s", hipGetErrorString(e));
     uint32_t total = 0;
@@ -421,6 +457,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     for (int a = 0; a < 3; a++) { d.qmin[a] = hframe[a]; d.qstep[a] = hframe[3 + a]; }
 
     d.tris = tris; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
+    d.num_tris = p.num_tris;   // leaf-ordered records: one per reference (a split triangle appears once per piece)
     return HR_OK;
 }
 

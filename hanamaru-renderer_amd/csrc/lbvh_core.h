@@ -35,10 +35,12 @@ typedef unsigned long long mkey_t;
 typedef unsigned long long u64t;
 static const int KEY_INDEX_BITS = 20;   // flatten_scene admits < 2^20 primitives
 static const int KEY_AXIS_BITS = 14;    // 42-bit Morton code
-static const int PLOC_RADIUS = 8;       // nearest-neighbour search window: +-8 positions
+static const int PLOC_RADIUS = 16;      // nearest-neighbour search window: +-16 positions (8: 1 % more node tests per ray, 0.4 ms less build time at 15 k primitives)
 
-struct Prims {   // input order: triangles, then spheres, then cuboids
-    const Tri *tris; uint32_t num_tris;
+struct Prims {   // input order: triangles (or their split references), then spheres, then cuboids
+    const Tri *tris; uint32_t num_tris;   // num_tris = triangle-type primitives the builder sees (= references when ref_tri is set)
+    const uint32_t *ref_tri;              // early split clipping: reference i is (part of) triangle ref_tri[i] with the box ref_box[6 i ..]; nullptr = none
+    const float *ref_box;
     const f4 *spheres; uint32_t num_spheres;
     const f4 *cuboids; uint32_t num_cuboids;
     float smin[3], sinv[3];  // scene bounds -> [0,1)^3
@@ -64,7 +66,10 @@ HD uint32_t info_type(uint32_t info) { return (info >> 28) & 3u; }
 HD uint32_t tc_of(u64t tc, uint32_t t) { return (uint32_t)(tc >> (20u * t)) & 0xfffffu; }
 
 HD void prim_box(const Prims &p, uint32_t i, float *mn, float *mx, uint32_t &type) {
-    if (i < p.num_tris) {
+    if (i < p.num_tris && p.ref_box) {
+        type = 0;
+        for (int a = 0; a < 3; a++) { mn[a] = p.ref_box[6 * (size_t)i + a]; mx[a] = p.ref_box[6 * (size_t)i + 3 + a]; }
+    } else if (i < p.num_tris) {
         type = 0;
         const Tri t = p.tris[i];
         float v1[3] = {t.v0[0] + t.e1x, t.v0[1] + t.e1y, t.v0[2] + t.e1z}, v2[3] = {t.v0[0] + t.e2x, t.v0[1] + t.e2y, t.v0[2] + t.e2z};
@@ -139,6 +144,71 @@ HD void hierarchy_node(const mkey_t *keys, int n, int i, const Work &w) {
     if (i == 0) w.parent[0] = NO_PARENT;
 }
 
+// ---- early split clipping on the device (Ernst & Greiner 2007; the host builder's form is flatten.cpp split_refs): a long thin
+// triangle whose box is much bigger than the part of the triangle inside it is cut at the middle of the box's longest extent, the
+// triangle clipped to each half, until the boxes fit (or `depth` cuts).  The builders then see one primitive per piece; a leaf holds
+// the whole triangle's record for each of its pieces (closest hits do not change: the same triangle tested twice gives the same t).
+// The recursion is an explicit stack of polygons; arithmetic in f64 on the fp32 triangle the kernel tests (v0, v0 + e1, v0 + e2),
+// boxes rounded outward to fp32.  Two passes over the same code: out == nullptr counts the pieces, else writes their boxes.
+struct SplitParams { double ratio_max, min_sa; int depth; };
+static const int SPLIT_MAX_VERTS = 12, SPLIT_MAX_DEPTH = 6;
+struct SplitPoly { double v[SPLIT_MAX_VERTS][3]; int n, depth; };
+HD void split_clip(const SplitPoly &in, int axis, double pos, bool keep_low, SplitPoly &out) {
+    out.n = 0;
+    for (int i = 0; i < in.n; i++) {
+        const double *a = in.v[i], *b = in.v[(i + 1) % in.n];
+        const bool ia = keep_low ? a[axis] <= pos : a[axis] >= pos, ib = keep_low ? b[axis] <= pos : b[axis] >= pos;
+        if (ia && out.n < SPLIT_MAX_VERTS) { for (int k = 0; k < 3; k++) out.v[out.n][k] = a[k]; out.n++; }
+        if (ia != ib && out.n < SPLIT_MAX_VERTS) {
+            const double t = (pos - a[axis]) / (b[axis] - a[axis]);
+            for (int k = 0; k < 3; k++) out.v[out.n][k] = a[k] + t * (b[k] - a[k]);
+            out.v[out.n][axis] = pos;
+            out.n++;
+        }
+    }
+}
+HD float f32_below(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
+HD float f32_above(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
+HD uint32_t split_tri(const Tri &t, const SplitParams &sp, float *out) {
+    SplitPoly stack[SPLIT_MAX_DEPTH + 2];
+    int top = 0;
+    SplitPoly &r = stack[0];
+    r.n = 3; r.depth = sp.depth < SPLIT_MAX_DEPTH ? sp.depth : SPLIT_MAX_DEPTH;
+    for (int k = 0; k < 3; k++) r.v[0][k] = (double)t.v0[k];
+    r.v[1][0] = (double)t.v0[0] + (double)t.e1x; r.v[1][1] = (double)t.v0[1] + (double)t.e1y; r.v[1][2] = (double)t.v0[2] + (double)t.e1z;
+    r.v[2][0] = (double)t.v0[0] + (double)t.e2x; r.v[2][1] = (double)t.v0[1] + (double)t.e2y; r.v[2][2] = (double)t.v0[2] + (double)t.e2z;
+    top = 1;
+    uint32_t count = 0;
+    while (top > 0) {
+        const SplitPoly cur = stack[--top];
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < cur.n; i++) for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], cur.v[i][a]); mx[a] = fmax(mx[a], cur.v[i][a]); }
+        const double d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        const double sa = 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+        double ax = 0, ay = 0, az = 0;
+        for (int i = 1; i + 1 < cur.n; i++) {
+            double e1[3], e2[3];
+            for (int a = 0; a < 3; a++) { e1[a] = cur.v[i][a] - cur.v[0][a]; e2[a] = cur.v[i + 1][a] - cur.v[0][a]; }
+            ax += e1[1] * e2[2] - e1[2] * e2[1]; ay += e1[2] * e2[0] - e1[0] * e2[2]; az += e1[0] * e2[1] - e1[1] * e2[0];
+        }
+        const double area = 0.5 * sqrt(ax * ax + ay * ay + az * az);
+        const int axis = d[0] > d[1] ? (d[0] > d[2] ? 0 : 2) : (d[1] > d[2] ? 1 : 2);
+        if (cur.depth <= 0 || cur.n < 3 || !(sa > sp.ratio_max * 4.0 * area) || !(sa > sp.min_sa) || !(d[axis] > 1e-6)) {
+            if (out) for (int a = 0; a < 3; a++) { out[6 * (size_t)count + a] = f32_below(mn[a]); out[6 * (size_t)count + 3 + a] = f32_above(mx[a]); }
+            count++;
+            continue;
+        }
+        const double pos = 0.5 * (mn[axis] + mx[axis]);
+        SplitPoly lo, hi;
+        split_clip(cur, axis, pos, true, lo);
+        split_clip(cur, axis, pos, false, hi);
+        lo.depth = hi.depth = cur.depth - 1;
+        if (hi.n >= 3) stack[top++] = hi;     // the low part is taken up first (the order of the host's recursion)
+        if (lo.n >= 3) stack[top++] = lo;
+    }
+    return count;
+}
+
 // ---- leaf node of sorted position k: box, type, counts
 HD void fit_leaf(const Prims &p, const mkey_t *keys, int n, int k, const Work &w) {
     float mn[3], mx[3];
@@ -170,6 +240,9 @@ HD void fit_inner(int n, uint32_t cur, uint32_t max_leaf, const Work &w) {
     const uint32_t il = LBVH_LD(&w.info[l]), ir = LBVH_LD(&w.info[r]);
     const uint32_t cnt = (il & INFO_COUNT) + (ir & INFO_COUNT);
     const bool uniform = (il & INFO_UNIFORM) && (ir & INFO_UNIFORM) && info_type(il) == info_type(ir);
+    // (a leaf wherever <= max_leaf primitives of one type meet; pricing the collapse like the host builder's leaf rule — one leaf of n
+    // primitives against a node visit plus two child leaves — was measured on both device builders: fewer triangle tests, more node
+    // tests, 0 to -1.3 % in Mpaths/s)
     const bool collapsed = uniform && cnt <= max_leaf;
     LBVH_ST(&w.info[cur], (collapsed ? INFO_COLLAPSED : 0u) | (uniform ? INFO_UNIFORM : 0u) | (info_type(il) << 28) | cnt);
     LBVH_ST(&w.tc[cur], LBVH_LD(&w.tc[l]) + LBVH_LD(&w.tc[r]));
@@ -206,6 +279,20 @@ HD void ploc_make_node(const Work &w, uint32_t id, uint32_t l, uint32_t r) {
         w.bmin[id * 3 + a] = fminf(w.bmin[l * 3 + a], w.bmin[r * 3 + a]);
         w.bmax[id * 3 + a] = fmaxf(w.bmax[l * 3 + a], w.bmax[r * 3 + a]);
     }
+}
+
+// SAH cost of the emitted tree as the host builder prices it (bvh_build.cpp): every emitted node pays its box area, a leaf 1.5 more
+// per primitive; relative to the root's area.  One node's share (0 for nodes inside a collapsed subtree).
+HD bool is_collapsed(const Work &w, uint32_t node);
+HD bool is_emitted(const Work &w, uint32_t node);
+HD bool is_leaf_top(const Work &w, uint32_t node);
+HD float node_area(const Work &w, uint32_t node) {
+    const float dx = w.bmax[node * 3] - w.bmin[node * 3], dy = w.bmax[node * 3 + 1] - w.bmin[node * 3 + 1], dz = w.bmax[node * 3 + 2] - w.bmin[node * 3 + 2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+HD float sah_share(const Work &w, uint32_t node) {
+    if (!is_emitted(w, node)) return 0.0f;
+    return node_area(w, node) * (1.0f + (is_leaf_top(w, node) ? 1.5f * (float)(w.info[node] & INFO_COUNT) : 0.0f));
 }
 
 // ---- finish: every node finds its own place by walking up

@@ -127,10 +127,29 @@ void emu_set_builder(int builder) { g_builder = builder; }
 
 // what build_bvh_on_device (hr_api.hip) does, with std::sort for the radix sort and loops for the kernels.
 // builder 1 = LBVH hierarchy (Karras), 2 = PLOC (the single-workgroup kernel's phases, run by one "thread")
-static void device_build_host(HostScene &hs, int max_leaf, int builder) {
+static void device_build_host(HostScene &hs, int max_leaf, int builder, double split_ratio) {
     using namespace lbvh;
     Prims p{};
     p.tris = hs.tris.data(); p.num_tris = (uint32_t)hs.tris.size();
+    // early split clipping as build_bvh_on_device does it: count, scan, emit
+    std::vector<uint32_t> ref_tri;
+    std::vector<float> ref_box;
+    if (split_ratio != 0.0 && !hs.tris.empty()) {
+        const double e0 = hs.scene_max[0] - hs.scene_min[0], e1 = hs.scene_max[1] - hs.scene_min[1], e2 = hs.scene_max[2] - hs.scene_min[2];
+        const double scene_sa = (e0 >= 0 && e1 >= 0 && e2 >= 0) ? 2.0 * (e0 * e1 + e1 * e2 + e2 * e0) : 0.0;
+        SplitParams sp{split_ratio < 0 ? 2.0 : split_ratio, 1e-4 * scene_sa, SPLIT_MAX_DEPTH};
+        std::vector<uint32_t> offsets(hs.tris.size() + 1, 0);
+        for (size_t i = 0; i < hs.tris.size(); i++) offsets[i + 1] = offsets[i] + split_tri(hs.tris[i], sp, nullptr);
+        const uint64_t refs = offsets.back();
+        if (refs > hs.tris.size() && refs + hs.spheres.size() + hs.cuboids.size() / 2 < (1ull << KEY_INDEX_BITS)) {
+            ref_tri.resize(refs); ref_box.resize(6 * refs);
+            for (size_t i = 0; i < hs.tris.size(); i++) {
+                uint32_t cnt = split_tri(hs.tris[i], sp, ref_box.data() + 6 * (size_t)offsets[i]);
+                for (uint32_t k = 0; k < cnt; k++) ref_tri[offsets[i] + k] = (uint32_t)i;
+            }
+            p.ref_tri = ref_tri.data(); p.ref_box = ref_box.data(); p.num_tris = (uint32_t)refs;
+        }
+    }
     p.spheres = hs.spheres.data(); p.num_spheres = (uint32_t)hs.spheres.size();
     p.cuboids = hs.cuboids.data(); p.num_cuboids = (uint32_t)(hs.cuboids.size() / 2);
     for (int a = 0; a < 3; a++) {
@@ -177,6 +196,11 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder) {
         }
     }
     for (int i = 0; i < N; i++) finish_node(p, n, (uint32_t)i, w, prim_pos.data());
+    {
+        double cost = 0;
+        for (int i = 0; i < N; i++) cost += sah_share(w, (uint32_t)i);
+        hs.bvh_sah_cost = cost / node_area(w, 0);
+    }
     const uint32_t total = size[0];
     float rmn[3], rmx[3];
     for (int a = 0; a < 3; a++) { rmn[a] = pad_down(bmin[a]); rmx[a] = pad_up(bmax[a]); }
@@ -188,12 +212,12 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder) {
         hs.qnodes[(size_t)o * (total + 1) + total] = qnode_sentinel(o);
     }
     hs.num_nodes = total;
-    std::vector<Tri> tris(hs.tris.size());
+    std::vector<Tri> tris(p.num_tris);
     std::vector<f4> spheres(hs.spheres.size()), cuboids(hs.cuboids.size());
     std::vector<int32_t> sphere_elem(hs.sphere_elem.size());
     for (int k = 0; k < n; k++) {
         uint32_t i = key_index(keys[k]), d = prim_pos[k];
-        if (i < p.num_tris) tris[d] = hs.tris[i];
+        if (i < p.num_tris) tris[d] = hs.tris[p.ref_tri ? p.ref_tri[i] : i];
         else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris; d -= p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; }
         else { uint32_t l = i - p.num_tris - p.num_spheres; d -= p.num_tris + p.num_spheres; cuboids[2 * d] = hs.cuboids[2 * l]; cuboids[2 * d + 1] = hs.cuboids[2 * l + 1]; }
     }
@@ -215,7 +239,7 @@ int emu_scene_create(const hr_scene_desc *sd, emu_scene **out) {
     std::string err;
     int rc = flatten_scene(sd, e->hs, err, g_max_leaf, g_builder ? 0.0 : g_split_ratio, g_builder == 0);
     if (rc) { fprintf(stderr, "emu: %s\n", err.c_str()); delete e; return rc; }
-    if (g_builder) device_build_host(e->hs, g_max_leaf, g_builder);
+    if (g_builder) device_build_host(e->hs, g_max_leaf, g_builder, g_split_ratio);
     e->view = e->hs.view();
     *out = e;
     return 0;
