@@ -247,7 +247,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
             for (int a = 0; a < 3; a++) { mn[a] = round_down(bn.box.mn[a], 2); mx[a] = round_up(bn.box.mx[a], 2); }
             node_set_box(n, mn, mx, o);
             n.b = after;
-            out.qnodes[(size_t)o * (N + 1) + newid[id]] = qnode_make(mn, mx, o, out.qmin, out.qstep, bn.left < 0 ? leaf_word[id] : after);
+            out.qnodes[(size_t)o * (N + 1) + newid[id]] = qnode_make(mn, mx, o, out.qmin, out.qstep, bn.left < 0 ? leaf_word[id] : qnode_link(o, (uint32_t)(N + 1), after));
             if (bn.left < 0) { n.a = leaf_word[id]; continue; }
             bool neg = (o >> bn.axis) & 1;
             int nearc = neg ? bn.right : bn.left, farc = neg ? bn.left : bn.right;

@@ -50,13 +50,21 @@ HD bool node_word_is_leaf(uint32_t a) { return a >= 0x10000000u; }
 // (plane = qmin + q * qstep per axis), rounded outward by at least one step — a box that only grows can add node visits, never
 // lose a hit.  The links are implicit in the layout: every octant's copy is stored in its own near-first preorder, so an inner
 // node's near child is record cur + 1 and `link` is its miss successor; a leaf's `link` is the leaf word and its successor is
-// cur + 1.  Record N of every copy is a sentinel that nothing hits and whose miss successor is NODE_END.
+// cur + 1 (as byte offsets: + 16).  Record N of every copy is a sentinel that nothing hits and whose miss successor is NODE_END.
 struct alignas(16) QNode {
     uint32_t xy_near;   // near.x | near.y << 16
     uint32_t xy_far;    // far.x  | far.y  << 16
     uint32_t z_nf;      // near.z | far.z  << 16
-    uint32_t link;      // inner: successor when the box is missed (or NODE_END); leaf: (type+1) << 28 | count << 20 | first
+    uint32_t link;      // inner: successor when the box is missed, as its BYTE OFFSET in qnodes[] (or NODE_END); leaf: (type+1) << 28 | count << 20 | first
 };
+// The walk's position on the 16-byte records is a byte offset into the whole qnodes[8][N + 1] array (octant copy included): a visit's
+// address is base + offset with no arithmetic, the near child / the node behind a leaf is offset + 16, and a miss takes `link` as
+// it stands.  Offsets stay below 2^28 (leaf words start there): N + 1 <= 2^21 records per octant copy (flatten / the device builders
+// produce < 2^21 nodes: < 2^20 primitives).
+HD uint32_t qnode_offset(int octant, uint32_t records_per_copy, uint32_t index) { return ((uint32_t)octant * records_per_copy + index) * 16u; }
+HD uint32_t qnode_link(int octant, uint32_t records_per_copy, uint32_t successor_index) {
+    return successor_index == NODE_END ? NODE_END : qnode_offset(octant, records_per_copy, successor_index);
+}
 // grid of the 16-bit planes: the root box, a little enlarged, in 65,532 steps.  Outward rounding leaves a margin for the kernel's
 // fp32 arithmetic: distance = q * (qstep * inv) + (qmin - o) * inv carries three roundings of ~6e-8 relative on values up to
 // 65,535 steps — 0.004 step each; QMARGIN = 0.05 step covers them with room.

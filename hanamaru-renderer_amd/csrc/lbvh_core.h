@@ -349,7 +349,7 @@ HD void emit_node(uint32_t node, int o, const Work &w, const float *qmin, const 
     nd.a = leaf ? w.word[node] : idx + 1u;
     nd.b = after;
     nodes[(size_t)o * total + idx] = nd;
-    qnodes[(size_t)o * (total + 1u) + idx] = qnode_make(mn, mx, o, qmin, qstep, leaf ? w.word[node] : after);
+    qnodes[(size_t)o * (total + 1u) + idx] = qnode_make(mn, mx, o, qmin, qstep, leaf ? w.word[node] : qnode_link(o, total + 1u, after));
 }
 
 }  // namespace lbvh

@@ -62,6 +62,7 @@ typedef float f2v __attribute__((vector_size(8)));   // one packed-fp32 operand 
 struct Ray {
     V3f o, d, inv;
     uint32_t oct;     // direction octant (bit k set = component k negative)
+    uint32_t start;   // where a walk of this ray begins: byte offset of its octant's copy in qnodes[] (walks on the 16-byte records), else 0
     // for the quantised nodes (device_scene.h QNode): distance to grid plane q = q * qinv + qc  (qinv = qstep * inv, qc = (qmin - o) * inv)
     V3f qinv, qc;
 };
@@ -78,6 +79,7 @@ HD void ray_set(Ray &r, V3f o, V3f d) {
 // FMA keeps the sign of (plane - origin) down to differences of ~2e-6, far below the half step the planes are padded by.
 HD float clamp_inv(float v) { return fminf(fmaxf(v, -1e30f), 1e30f); }
 HD void ray_quantise(const Scene &sc, Ray &r) {
+    r.start = sc.qnodes ? qnode_offset((int)r.oct, sc.num_nodes + 1u, 0u) : 0u;
     const V3f inv = v3(clamp_inv(r.inv.x), clamp_inv(r.inv.y), clamp_inv(r.inv.z));
     r.qinv = v3(sc.qstep[0] * inv.x, sc.qstep[1] * inv.y, sc.qstep[2] * inv.z);
     r.qc = v3((sc.qmin[0] - r.o.x) * inv.x, (sc.qmin[1] - r.o.y) * inv.y, (sc.qmin[2] - r.o.z) * inv.z);
@@ -92,7 +94,8 @@ struct TraceState {
     uint32_t leaf;    // pending leaf word (node visited, primitives not yet tested), 0 = none
     uint32_t leaf2;   // a second pending leaf, found while `leaf` was still waiting for the leaf phase (trace kernel only)
 };
-HD void trace_begin(TraceState &ts, float tmax) { ts.cur = 0; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; ts.leaf = 0; ts.leaf2 = 0; }
+// start: 0 for walks on the 32-byte records (node index), Ray::start for walks on the 16-byte records (byte offset)
+HD void trace_begin(TraceState &ts, float tmax, uint32_t start = 0u) { ts.cur = start; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; ts.leaf = 0; ts.leaf2 = 0; }
 HD bool trace_done(const TraceState &ts) { return ts.cur == NODE_END && ts.leaf == 0; }
 
 struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests; };
@@ -227,7 +230,7 @@ HD void trace_node(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *
 // trace_node() on the 32-byte records of the same tree, plus the few extra ones the fatter boxes let through.
 template <bool CNT, bool SPEC = false>
 HD void trace_qnode(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
-    const QNode nd = sc.qnodes[(size_t)r.oct * (sc.num_nodes + 1u) + ts.cur];
+    const QNode nd = *reinterpret_cast<const QNode *>(reinterpret_cast<const char *>(sc.qnodes) + ts.cur);   // ts.cur: byte offset, octant copy included
     if (CNT) cn->node_tests++;
     const f2v nxy = {(float)(nd.xy_near & 0xffffu), (float)(nd.xy_near >> 16)}, fxy = {(float)(nd.xy_far & 0xffffu), (float)(nd.xy_far >> 16)};
     const f2v zz = {(float)(nd.z_nf & 0xffffu), (float)(nd.z_nf >> 16)};
@@ -236,7 +239,7 @@ HD void trace_qnode(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters 
     const float tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
     const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
     const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
-    node_advance<SPEC>(ts, hit, nd.link, ts.cur + 1u);
+    node_advance<SPEC>(ts, hit, nd.link, ts.cur + 16u);
 }
 template <bool CNT>
 HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
@@ -526,7 +529,7 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
     ray_quantise(sc, p.ray);
     p.st = 1u;            // iteration 1, main ray
     p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
-    trace_begin(p.ts, T_INF);
+    trace_begin(p.ts, T_INF, p.ray.start);
 }
 
 // scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter path_emitter(p)
@@ -545,7 +548,7 @@ HD void nee_setup(const Scene &sc, Path &p) {
     ray_quantise(sc, p.ray);
     // a closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4),
     // so the search is limited to the sample distance + 0.03 (the reference does an unbounded closest-hit query)
-    trace_begin(p.ts, p.shadow_len + 0.03f);
+    trace_begin(p.ts, p.shadow_len + 0.03f, p.ray.start);
     p.st |= 16u;
 }
 
@@ -634,7 +637,7 @@ HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *
     p.st++;
     ray_set(p.ray, p.next_o, p.next_d);
     ray_quantise(sc, p.ray);
-    trace_begin(p.ts, T_INF);
+    trace_begin(p.ts, T_INF, p.ray.start);
     return false;
 }
 

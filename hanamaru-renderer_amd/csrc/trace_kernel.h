@@ -218,8 +218,8 @@ __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams 
     ray_quantise(sc, p.ray);
     const float sl = shadow_len ? shadow_len[j] : 0.0f;
     p.shadow_len = sl;
-    if (sl > 0.0f) { trace_begin(p.ts, sl + 0.03f); p.st |= 16u; }   // nee_setup's search limit, shadow phase
-    else trace_begin(p.ts, T_INF);
+    if (sl > 0.0f) { trace_begin(p.ts, sl + 0.03f, p.ray.start); p.st |= 16u; }   // nee_setup's search limit, shadow phase
+    else trace_begin(p.ts, T_INF, p.ray.start);
     if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
     LaneCounters lc = {0, 0, 0, 0, 0};
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
     p.tile = tile; p.st = 1u; p.shadow_len = 0.0f;
     debug_camera_ray(sc, rp, active ? px : 0u, active ? py : 0u, sub, p.ray);
     ray_quantise(sc, p.ray);
-    trace_begin(p.ts, T_INF);
+    trace_begin(p.ts, T_INF, p.ray.start);
     if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
     if (wave_ballot(more)) {   // Shading mode: the shadow ray towards the fixed light, any closest hit darkens
         p.ray = sh;
         ray_quantise(sc, p.ray);
-        trace_begin(p.ts, T_INF);
+        trace_begin(p.ts, T_INF, p.ray.start);
         if (!more) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
         traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(wave_ballot(more)), 0u, leaf_den, lc, ws);
         if (CNT && more) lc.rays++;

@@ -43,7 +43,9 @@ extern "C" {
     pub fn hr_resolve(ctx: *mut HrCtx, samplings_done: u32, host_rgb8: *mut u8) -> c_int;
     pub fn hr_bind_accumulator(ctx: *mut HrCtx, device_rgb: *mut f32) -> c_int;
     pub fn hr_accumulator_device_ptr(ctx: *mut HrCtx) -> *mut c_void;
-    /// e.g. ("bvh_builder", 1.0) = build the BVH on the GPU, ("batch", 4.0) = samplings per launch; see hanamaru_hip.h
+    /// e.g. ("bvh_builder", 1.0) = build the BVH on the GPU, ("batch", 4.0) = samplings per launch; see hanamaru_hip.h.  Every key this
+    /// call accepts leaves the image as the reference computes it, except the documented opt-in "russian_roulette" (off by default).
+    /// (The library's measurement knobs sit behind hr_set_debug_option, deliberately not bound here.)
     pub fn hr_set_option(ctx: *mut HrCtx, key: *const c_char, value: f64) -> c_int;
     // multi-GPU: one ncclAllReduce of the accumulators, issued by the library (include/hanamaru_hip.h; RCCL is dlopen'ed on first use)
     pub fn hr_comm_get_unique_id(id_out: *mut u8 /* HR_COMM_ID_BYTES = 128 */) -> c_int;

@@ -306,7 +306,8 @@ int emu_raw_draws_seg(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t
 // counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests
 int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc,
                uint64_t *counters) {
-    const Scene &sc = e->view;
+    Scene sc = e->view;
+    sc.qnodes = nullptr;   // the emulated render walks the 32-byte records (node indices): every ray's walk starts at 0
     RenderParams rp{};
     rp.width = W; rp.height = H;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
@@ -379,7 +380,7 @@ int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out,
         ray_set(r, v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
         ray_quantise(sc, r);
         TraceState ts;
-        trace_begin(ts, T_INF);
+        trace_begin(ts, T_INF, g_walk_mode == 2 ? r.start : 0u);   // 16-byte records: byte offset of the octant's copy; 32-byte records: node index
         LaneCounters lc = {0, 0, 0, 0, 0};
         if (g_walk_mode == 0) {
             while (ts.cur != NODE_END) trace_step<true>(sc, r, ts, &lc);

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r02
-TAG=${1:-r02}
+# Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r03
+TAG=${1:-r03}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,14 +13,19 @@ python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_kernel_stats.md "rocprof
 python bench.py > $OUT/${TAG}_bench_full_unprofiled.json.log 2>> $OUT/bench_full.err
 # other BASELINE configurations on one GPU
 python bench.py --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres.json.log 2>> $OUT/bench_full.err
-python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --steps 8 --warmup 1 --spp-per-step 4 --no-cpu-baseline > $OUT/${TAG}_bench_c5_4k_dodeca.json.log 2>> $OUT/bench_full.err
+python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --steps 32 --warmup 1 --spp-per-step 4 --no-cpu-baseline > $OUT/${TAG}_bench_c5_4k_dodeca.json.log 2>> $OUT/bench_full.err
 python bench.py --bvh-builder 1 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_lbvh.json.log 2>> $OUT/bench_full.err
 python bench.py --bvh-builder 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
+# N > 1 exactly as the driver runs N = 1 (no launcher): one process, two contexts; on this 1-GPU box both share device 0
+python bench.py --gpus 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_gpus2_one_device.json.log 2>> $OUT/bench_full.err
+python bench.py --russian-roulette 3 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_russian_roulette_nonparity.json.log 2>> $OUT/bench_full.err
+python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian" 2>&1 | grep -E "^\.?parity|simple \+|device builder|russian roulette|passed|failed" > $OUT/${TAG}_parity_lines.txt
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
 tools/bin/issueprobe > $OUT/${TAG}_issueprobe.txt 2>&1
 tools/bin/roundprobe2 > $OUT/${TAG}_roundprobe2.txt 2>&1
 tools/bin/roundprobe3 > $OUT/${TAG}_roundprobe3.txt 2>&1
+tools/bin/roundprobe4 > $OUT/${TAG}_roundprobe4_raw.txt 2>&1
 tools/bin/simdprobe > $OUT/${TAG}_simdprobe.txt 2>&1
 tools/prof_pmc.sh $OUT/pmc $TAG > $OUT/pmc.log 2>&1
 cp $OUT/pmc/summary.txt $OUT/${TAG}_pmc_summary.txt; cp $OUT/pmc/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json

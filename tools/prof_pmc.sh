@@ -56,7 +56,7 @@ with open(out + "/summary.txt", "w") as o:
         if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per: e["l2_hit_rate"] = per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
         if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per: e["valu_lane_utilisation"] = per["SQ_THREAD_CYCLES_VALU"] / max(1.0, per["SQ_ACTIVE_INST_VALU"] * 64)
         # texture addresser busy: TA_TA_BUSY_sum counts busy cycles over all CUs; GRBM_GUI_ACTIVE = the kernel's cycles (kernels run serialised under PMC)
-        if "TA_TA_BUSY_sum" in per and "GRBM_GUI_ACTIVE" in per: e["ta_busy_frac"] = per["TA_TA_BUSY_sum"] / max(1.0, 256.0 * per["GRBM_GUI_ACTIVE"])
+        if "TA_TA_BUSY_sum" in per and "GRBM_GUI_ACTIVE" in per: e["ta_busy_frac"] = per["TA_TA_BUSY_sum"] / max(1.0, 256.0 * per["GRBM_GUI_ACTIVE"] / 8.0)   # GRBM_GUI_ACTIVE comes summed over the 8 XCDs
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in per: e["l1_line_accesses_per_path"] = per["TCP_TOTAL_CACHE_ACCESSES_sum"] / PATHS
         if "TCP_TCC_READ_REQ_sum" in per: e["l1_to_l2_requests_per_path"] = per["TCP_TCC_READ_REQ_sum"] / PATHS
         if name in kernels: continue
