@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH, 2 = device PLOC")
     ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
-    ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 / 1 / 2 = fixed level")
+    ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 .. 5 = fixed level")
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
     ap.add_argument("--quant-nodes", type=int, default=-1)
     ap.add_argument("--russian-roulette", type=int, default=0, help="NOT the reference's estimator: first iteration that plays (0 = off, default)")

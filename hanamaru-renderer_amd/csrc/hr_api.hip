@@ -99,9 +99,9 @@ struct hr_ctx {
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
-    int trace_boost = -1;                    // trace-kernel phases above the producer waves: -1 = governed by the measured kernel times (default), 0 / 1 (box phase) / 2 (box and leaf phases) = fixed
-    int boost_now = 1;                       // the governor's current level
-    float gov_known[3] = {0, 0, 0};          // per level: smoothed max(seed, trace) ms of the launches measured at it (0 = not tried on this scene / size)
+    int trace_boost = -1;                    // trace-kernel phases above the producer waves: -1 = governed by the measured kernel times (default), 0 .. 4 = fixed level (GOV_MASK)
+    int boost_now = 2;                       // the governor's current level
+    float gov_known[5] = {0, 0, 0, 0, 0};    // per level: smoothed max(seed, trace) ms of the launches measured at it (0 = not tried on this scene / size)
     size_t gov_next = 0;                     // first launch (index into seed_events / trace_events) the governor has not looked at
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     int max_leaf = 4;                        // BVH leaf size (next upload)
@@ -144,16 +144,24 @@ static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
 // when the balance asks for it (trace kernel more than 3 % behind -> up, seed kernel -> down), otherwise the best level known wins.
 // `level` is the level the measured launch RAN at (the host enqueues several launches ahead of the GPU, so it is not
 // necessarily the current one): its time is credited to that level, and only a launch that ran at the current level may move it.
+// Levels, from "the seed kernel's producer waves first" to "the trace kernel first":
+//   0  producers at init_prio (1), trace kernel at 0          3  producers at 0, the trace kernel's box phases at 1
+//   1  producers alternate between init_prio and 0 per group   4  ... box and leaf phases at 1
+//   2  producers at 0, trace kernel at 0
+// RenderParams::trace_boost carries the trace kernel's mask (bits 0-3: the box phases of a period of four, bit 4: the leaf phase),
+// pad[1] the producers' priority for even (bits 0-1) and odd (bits 2-3) groups.
+static const int GOV_LEVELS = 5;
+static const uint32_t GOV_MASK[GOV_LEVELS] = {0x0u, 0x0u, 0x0u, 0xfu, 0x1fu};
 static void govern(hr_ctx *c, float seed_ms, float trace_ms, int level) {
-    if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0) || level < 0 || level > 2) return;
+    if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0) || level < 0 || level >= GOV_LEVELS) return;
     const int L = level;
     const float m = std::max(seed_ms, trace_ms);
     c->gov_known[L] = c->gov_known[L] > 0 ? 0.5f * (c->gov_known[L] + m) : m;
     if (L != c->boost_now) return;   // a launch issued before the last change of level: noted, nothing decided from it
-    if (trace_ms > 1.03f * seed_ms && L < 2 && c->gov_known[L + 1] == 0) { c->boost_now = L + 1; return; }
-    if (seed_ms > 1.03f * trace_ms && L > 0 && c->gov_known[L - 1] == 0) { c->boost_now = L - 1; return; }
+    if (trace_ms > 1.015f * seed_ms && L < GOV_LEVELS - 1 && c->gov_known[L + 1] == 0) { c->boost_now = L + 1; return; }
+    if (seed_ms > 1.015f * trace_ms && L > 0 && c->gov_known[L - 1] == 0) { c->boost_now = L - 1; return; }
     int best = L;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < GOV_LEVELS; k++)
         if (c->gov_known[k] > 0 && c->gov_known[k] < 0.995f * c->gov_known[best]) best = k;
     c->boost_now = best;
 }
@@ -162,7 +170,7 @@ static void invalidate_totals(hr_ctx *c) {
     c->total_valid = false;
     for (hr_ctx *p : c->same_device_peers) p->total_valid = false;
 }
-static void govern_reset(hr_ctx *c) { c->gov_known[0] = c->gov_known[1] = c->gov_known[2] = 0; if (c->trace_boost < 0) c->boost_now = 1; }
+static void govern_reset(hr_ctx *c) { for (float &g : c->gov_known) g = 0; if (c->trace_boost < 0) c->boost_now = 2; }
 static int drain_events(hr_ctx *c) {
     {   // the lists about to be emptied still have something to tell the governor: the launch before the last one (the last trace
         // kernel had the chip to itself, the first seed kernel too)
@@ -594,7 +602,7 @@ static int ensure_ovf(hr_ctx *c, uint64_t paths_per_launch) {
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
-    EventPair ev{nullptr, nullptr, (int)rp.trace_boost};
+    EventPair ev{nullptr, nullptr, c->boost_now};
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
@@ -683,8 +691,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
                 break;
             }
         } else c->boost_now = c->trace_boost;
-        rp.trace_boost = (uint32_t)c->boost_now;
-        rp.pad[1] = c->boost_now ? 0u : c->init_prio;   // the producer waves step below the boosted phases
+        rp.trace_boost = GOV_MASK[c->boost_now];
+        rp.pad[1] = c->boost_now == 0 ? (c->init_prio | c->init_prio << 2) : c->boost_now == 1 ? c->init_prio : 0u;   // the producer waves' priority: even | odd groups
         hipStream_t sstream = c->seed_stream;  // (alternating two seed streams to overlap kernel tails was measured: no gain)
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(sstream, c->trace_done[slot], 0));
@@ -692,7 +700,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(c->seed_done[slot], sstream));
         c->seed_pending[slot] = true;
         HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
-        EventPair ev{nullptr, nullptr, (int)rp.trace_boost};
+        EventPair ev{nullptr, nullptr, c->boost_now};
         HIP_TRY(hipEventCreate(&ev.a));
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, c->stream));
@@ -1000,7 +1008,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "trace_boost") {
-        if (value != -1 && value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times), 0, 1 or 2");
+        if (value != -1 && !(value >= 0 && value <= 4 && value == (int)value)) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times) or a level 0 .. 4");
         c->trace_boost = (int)value;
         govern_reset(c);
         return HR_OK;

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
     const bool consumer = wave < 2u;
-    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1];
+    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1] & 3u;
     switch (prio) {  // s_setprio takes an immediate
         case 0: break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -539,6 +539,12 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
         regs.run(lds_half, sl);          // the window
         __syncthreads();   // B
         if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);   // for the next window; complete in the ring since the last barrier A
+        // the ahead pass's priority may alternate between groups (rp.pad[1] bits 2-3: the priority of the odd groups): the host's
+        // priority governor balances the two kernels with it, and the balance point usually lies between two whole levels
+        if (((rp.pad[1] >> 2) & 3u) != (rp.pad[1] & 3u)) {
+            const uint32_t pr = (it & 1u) ? (rp.pad[1] >> 2) & 3u : rp.pad[1] & 3u;
+            if (pr == 0u) __builtin_amdgcn_s_setprio(0); else if (pr == 1u) __builtin_amdgcn_s_setprio(1); else if (pr == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+        }
         ahead(r.G0 + it + 2);
         __syncthreads();   // A
     }
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
     const bool consumer = wave < 2u;
-    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1];
+    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1] & 3u;
     switch (prio) {  // s_setprio takes an immediate
         case 0: break;
         case 1: __builtin_amdgcn_s_setprio(1); break;

@@ -40,7 +40,7 @@ struct WaveStats {
 // per-ray constants in registers.
 template <bool CNT, bool QN>
 __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParams &rp, Path &p, const bool active, const uint32_t n_active, const uint32_t adv_den,
-                                              const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws) {
+                                              const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws, uint32_t &tick) {
     for (;;) {
         const bool trav = active && !trace_done(p.ts);
         const uint32_t n_trav = (uint32_t)__popcll(wave_ballot(trav));
@@ -52,8 +52,12 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
         // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
         // box pass is the trace kernel's critical loop.  Switched by the host from the measured times of the two kernels
         // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
-        // and costs ~1 % when the seed kernel is.  Level 2 adds the leaf phase (another +1 - 2 % where the trace kernel is far behind).
-        if (rp.trace_boost) __builtin_amdgcn_s_setprio(1);
+        // and costs ~1 % when the seed kernel is.  rp.trace_boost bits 0-3: which of every four box phases of a wave run boosted (a duty
+        // cycle of 0, 1/4, 1/2, 3/4 or 1: the balance point of the two kernels usually lies between "never" and "always"); bit 4 adds the
+        // leaf phase (another +1 - 2 % where the trace kernel is far behind).
+        const bool boost_box = (rp.trace_boost >> (tick & 3u)) & 1u;
+        tick++;
+        if (boost_box) __builtin_amdgcn_s_setprio(1);
         // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second.  The loop is written with its
         // wave-uniform test at the bottom: as `for (;;) { if (n_go <= walk_max) break; if (go) ... }` the compiler folds the exit
         // into the lane mask of `if (go)` and copies the live-out walk state every pass.
@@ -73,10 +77,10 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
             go = go && trace_can_walk(p.ts);
             n_go = (uint32_t)__popcll(wave_ballot(go));
         }
-        if (rp.trace_boost) __builtin_amdgcn_s_setprio(0);
+        if (boost_box) __builtin_amdgcn_s_setprio(0);
         HR_PHASE_END(ws, 2);
         HR_PHASE_BEGIN(ws);
-        if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(1);   // level 2: the leaf phase too
+        if (rp.trace_boost & 16u) __builtin_amdgcn_s_setprio(1);   // top level: the leaf phase too
         if (CNT) {
             uint32_t n = (uint32_t)__popcll(wave_ballot(trav && p.ts.leaf != 0));
             if (n) { ws.ph[4]++; ws.ph[5] += n; }
@@ -85,7 +89,7 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
             trace_leaf_next<CNT>(sc, p.ray, p.ts, &lc);   // the older parked leaf; the newer one (if any) moves up
             shadow_early_out(p);
         }
-        if (rp.trace_boost > 1u) __builtin_amdgcn_s_setprio(0);
+        if (rp.trace_boost & 16u) __builtin_amdgcn_s_setprio(0);
         HR_PHASE_END(ws, 3);
     }
 }
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0;
     const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
+    uint32_t tick = threadIdx.x >> 6;   // wave-uniform count of box phases (the boost's duty cycle); the waves of a workgroup start out of step
 
     for (;;) {
         // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             continue;
         }
         // ---- C: traversal
-        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, adv_den, leaf_den, lc, ws);
+        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, adv_den, leaf_den, lc, ws, tick);
     }
     flush_counters<CNT>(cnt, lane, npaths, lc, ws);
 }
@@ -224,7 +229,8 @@ __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams 
     LaneCounters lc = {0, 0, 0, 0, 0};
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
-    traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws);
+    uint32_t tick = 0;
+    traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws, tick);
     if (!active) return;
     float *o = out + (size_t)i * 8;
     int32_t elem = -1;
@@ -285,7 +291,8 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
     if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
-    traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, leaf_den, lc, ws);
+    uint32_t tick = 0;
+    traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, leaf_den, lc, ws, tick);
     if (CNT && active) lc.rays++;
     V3f val = v3(0, 0, 0), lit = v3(0, 0, 0);
     Ray sh = p.ray;
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
         ray_quantise(sc, p.ray);
         trace_begin(p.ts, T_INF, p.ray.start);
         if (!more) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
-        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(wave_ballot(more)), 0u, leaf_den, lc, ws);
+        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(wave_ballot(more)), 0u, leaf_den, lc, ws, tick);
         if (CNT && more) lc.rays++;
         if (more) val = val + lit * (p.ts.prim >= 0 ? 0.5f : 1.0f);
     }

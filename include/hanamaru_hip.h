@@ -200,8 +200,9 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* Options that leave the image as the reference computes it (the summation order of the accumulator aside):
  *   "counters"      0 / 1: instrumented build of the trace kernel (fills the counter fields of hr_stats)
  *   "batch"         samplings per launch, 1..64; 0 = automatic (about 33 M paths per launch: 4 at 1080p, up to 64 for small images)
- *   "trace_boost"   -1 = the library decides from the measured kernel times whether the trace kernel's box phase (and its leaf
- *                   phase) run above the seed kernel's producer waves (default); 0 / 1 / 2 = fixed level
+ *   "trace_boost"   -1 = the library balances the two kernels from their measured times (default): five levels from "the seed kernel's
+ *                   producer waves above the trace kernel" (0) over "alternating" (1) and "equal" (2) to "the trace kernel's box
+ *                   phase (3) and leaf phase (4) above the producer waves"; 0 .. 4 = fixed level
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
  *   next hr_upload_scene:

@@ -333,7 +333,7 @@ def test_error_paths(ha):
     assert not r.read_accumulator().any()
     with pytest.raises(ha.HipError):
         r.set_option("nonsense", 1)
-    for key, bad in [("batch", 65), ("max_leaf", 0), ("bvh_builder", 3), ("rng_window", 32), ("russian_roulette", 1), ("trace_boost", 3)]:
+    for key, bad in [("batch", 65), ("max_leaf", 0), ("bvh_builder", 3), ("rng_window", 32), ("russian_roulette", 1), ("trace_boost", 5)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
     for key, bad in [("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("seed_mode", 3), ("seed_split", 10), ("nonsense", 1)]:
@@ -470,20 +470,20 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
 
 
 def test_priority_governor_does_not_change_results(gpu, scenes):
-    """Option trace_boost (the trace kernel's box phase above the seed kernel's producer waves; -1 = decided from the measured kernel
-    times) only moves issue slots between the two kernels: the accumulator is the same up to the atomics' summation order."""
+    """Option trace_boost (five levels from "the seed kernel's producer waves first" to "the trace kernel's box and leaf phases first";
+    -1 = decided from the measured kernel times) only moves issue slots between the two kernels: the accumulator is the same up to the atomics' summation order."""
     sc, _ = scenes("rtcamp6_v3_1")
     gpu.upload_scene(sc)
     gpu.set_resolution(320, 180)
     outs = []
     try:
-        for boost in (0, 1, 2, -1):
+        for boost in (0, 1, 2, 3, 4, -1):
             gpu.set_option("trace_boost", boost)
             gpu.clear()
             gpu.render(1, 13)
             outs.append(gpu.read_accumulator().astype(np.float64))
         with pytest.raises(Exception):
-            gpu.set_option("trace_boost", 3)
+            gpu.set_option("trace_boost", 5)
     finally:
         gpu.set_option("trace_boost", -1)
     assert outs[0].sum() > 0
