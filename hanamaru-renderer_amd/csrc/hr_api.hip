@@ -199,6 +199,24 @@ static int drain_events(hr_ctx *c) {
     c->gov_next = 0;
     return HR_OK;
 }
+// Long renders: retire the event pairs of launches that have finished (both kernels), oldest first, without waiting for anything —
+// the lists stay a few launches long however many samplings one hr_render call covers, and no drain ever has to stop the pipeline.
+static void retire_finished_launches(hr_ctx *c) {
+    size_t n = 0;
+    const size_t limit = std::min(c->seed_events.size(), c->trace_events.size());
+    while (n < limit && hipEventQuery(c->seed_events[n].b) == hipSuccess && hipEventQuery(c->trace_events[n].b) == hipSuccess) n++;
+    if (n > 2) n -= 2; else return;   // the newest finished launches stay: the governor may not have looked at them yet
+    for (size_t i = 0; i < n; i++) {
+        float sm = 0, tm = 0;
+        if (hipEventElapsedTime(&sm, c->seed_events[i].a, c->seed_events[i].b) == hipSuccess) c->seed_ms += sm;
+        if (hipEventElapsedTime(&tm, c->trace_events[i].a, c->trace_events[i].b) == hipSuccess) c->trace_ms += tm;
+        (void)hipEventDestroy(c->seed_events[i].a); (void)hipEventDestroy(c->seed_events[i].b);
+        (void)hipEventDestroy(c->trace_events[i].a); (void)hipEventDestroy(c->trace_events[i].b);
+    }
+    c->seed_events.erase(c->seed_events.begin(), c->seed_events.begin() + (long)n);
+    c->trace_events.erase(c->trace_events.begin(), c->trace_events.begin() + (long)n);
+    c->gov_next = c->gov_next > n ? c->gov_next - n : 0;
+}
 static int sync_all(hr_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->seed_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -735,7 +753,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(c->trace_done[slot], c->stream));
         c->trace_pending[slot] = true;
         c->paths_rendered += (uint64_t)c->W * c->H * 4 * nk;
-        if (c->trace_events.size() > 4096) {  // keep the event list bounded on very long renders
+        if (c->trace_events.size() >= 64 && c->seed_events.size() == c->trace_events.size()) retire_finished_launches(c);
+        if (c->trace_events.size() > 4096) {  // (never reached while launches finish: the host would have to be 4,096 launches ahead)
             if ((rc = sync_all(c))) return rc;
         }
     }

@@ -741,6 +741,29 @@ def test_device_builders_at_a_million_primitives(gpu, ha):
     assert np.abs(pos[:, 1] - yy).max() < 2e-3     # the mesh samples the function every 0.0113 units: chord error ~1e-4
 
 
+def test_hundreds_of_launches_in_one_call(gpu, scenes):
+    """One hr_render call that issues 400 launches (batch = 1): the event pairs of finished launches are retired on the way without
+    stopping the pipeline, the kernel times of all 400 launches end up in the statistics, and the accumulator equals four calls
+    of 100 samplings."""
+    sc, _ = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(48, 32)
+    gpu.set_option("batch", 1)
+    try:
+        gpu.clear()
+        gpu.render(1, 401)
+        one = gpu.read_accumulator().astype(np.float64)
+        st = gpu.stats()
+        assert st["seed_launches"] == 400 and st["trace_launches"] == 400 and st["trace_kernel_ms"] > 0 and st["seed_kernel_ms"] > 0
+        gpu.clear()
+        for k in range(4):
+            gpu.render(1 + 100 * k, 101 + 100 * k)
+        four = gpu.read_accumulator().astype(np.float64)
+    finally:
+        gpu.set_option("batch", 0)
+    assert np.abs(one - four).max() <= 1e-5 * max(1.0, np.abs(one).max())
+
+
 def test_mark_and_wait_keep_the_pipeline_running(gpu, scenes):
     """hr_mark / hr_wait: waiting for an earlier marker must not disturb later work, and the result equals a plain render."""
     sc, _ = scenes("cornell_mini")

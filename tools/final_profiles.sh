@@ -13,9 +13,9 @@ python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_kernel_stats.md "rocprof
 python bench.py > $OUT/${TAG}_bench_full_unprofiled.json.log 2>> $OUT/bench_full.err
 # other BASELINE configurations on one GPU
 python bench.py --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres.json.log 2>> $OUT/bench_full.err
-python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --steps 32 --warmup 1 --spp-per-step 4 --no-cpu-baseline > $OUT/${TAG}_bench_c5_4k_dodeca.json.log 2>> $OUT/bench_full.err
-python bench.py --bvh-builder 1 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_lbvh.json.log 2>> $OUT/bench_full.err
-python bench.py --bvh-builder 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
+python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --steps 64 --warmup 1 --spp-per-step 4 --no-cpu-baseline > $OUT/${TAG}_bench_c5_4k_dodeca.json.log 2>> $OUT/bench_full.err
+python bench.py --bvh-builder 1 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_lbvh.json.log 2>> $OUT/bench_full.err
+python bench.py --bvh-builder 2 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
 # N > 1 exactly as the driver runs N = 1 (no launcher): one process, two contexts; on this 1-GPU box both share device 0
 python bench.py --gpus 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_gpus2_one_device.json.log 2>> $OUT/bench_full.err
 python bench.py --russian-roulette 3 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_russian_roulette_nonparity.json.log 2>> $OUT/bench_full.err
