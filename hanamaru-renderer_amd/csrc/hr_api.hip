@@ -325,8 +325,10 @@ int hr_destroy(hr_ctx *c) {
     return HR_OK;
 }
 
-// Device LBVH (option bvh_builder = 1): the primitive arrays were uploaded in input order; build the tree over them,
-// re-store the primitives in leaf order and point the scene at the results.  Scratch is freed before returning.
+// Device builders (option bvh_builder = 1 LBVH, 2 PLOC; gpu_bvh.h): the primitive arrays were uploaded in input order; split long
+// thin triangles into references (early split clipping), build the tree over them, emit it in both record formats (16-byte quantised
+// records in per-octant near-first preorder — what the trace kernel walks — and the 32-byte fp32 records), re-store the primitives
+// in leaf order and point the scene at the results.  Scratch is freed before returning.
 static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     using namespace lbvh;
     Scene &d = c->dsc;

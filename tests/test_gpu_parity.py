@@ -442,10 +442,10 @@ def test_cli_checkpoint_resume_and_debug(tmp_path):
 
 
 def test_seed_kernels_are_bit_identical(gpu, scenes):
-    """The producer / consumer seed kernel (seed_mode 1, default: init in registers on producer waves, only the blocks
-    < seed_split come from producer waves through the ring, the consumer does the rest and runs the round) must hand the trace kernel
-    exactly the draws of the fused kernel (seed_mode 0): same raw tails -> the accumulators agree up to the atomics'
-    fp32 summation order."""
+    """The three seed kernels — the three-run kernel (seed_mode 2, the default: the init sweep as three runs computed side by side from
+    states the producer waves work out ahead), the producer / consumer kernel with the ring of generator words (seed_mode 1, every
+    seed_split) and the fused kernel (seed_mode 0) — must hand the trace kernel exactly the same draws: same raw tails -> the
+    accumulators agree up to the atomics' fp32 summation order."""
     sc, _ = scenes("rtcamp6_v3_1")
     gpu.upload_scene(sc)
     outs = []
