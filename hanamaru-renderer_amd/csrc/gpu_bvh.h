@@ -147,6 +147,7 @@ __global__ void fit_kernel(int n, uint32_t max_leaf, Work w) {
         __threadfence();
         if (atomicAdd(&w.flags[cur], 1u) == 0u) return;
         __threadfence();
+        rotate_children(n, cur, max_leaf, w);   // both subtrees are complete and nobody else is inside them
         fit_inner(n, cur, max_leaf, w);
         cur = w.parent[cur];
     }

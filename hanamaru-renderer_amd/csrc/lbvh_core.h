@@ -249,6 +249,44 @@ HD void fit_inner(int n, uint32_t cur, uint32_t max_leaf, const Work &w) {
     LBVH_ST(&w.size[cur], collapsed ? 1u : 1u + LBVH_LD(&w.size[l]) + LBVH_LD(&w.size[r]));
 }
 
+// ---- tree rotations (Kensler 2008) during the bottom-up fit: before an inner node is fitted — its two subtrees are complete and no
+// other thread touches them — one of its children may change places with a grandchild on the other side when that shrinks the box
+// of the inner node the grandchild leaves behind (the only box of the tree that changes).  Bottom-up builders (Morton splits,
+// merges of Morton neighbours) leave such local mistakes; the host builder's top-down SAH splits do not.
+HD float union_area3(const Work &w, uint32_t a, uint32_t b) {
+    float d[3];
+    for (int k = 0; k < 3; k++) d[k] = fmaxf(LBVH_LD(&w.bmax[a * 3 + k]), LBVH_LD(&w.bmax[b * 3 + k])) - fminf(LBVH_LD(&w.bmin[a * 3 + k]), LBVH_LD(&w.bmin[b * 3 + k]));
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+HD float node_half_area(const Work &w, uint32_t a) {
+    float d[3];
+    for (int k = 0; k < 3; k++) d[k] = LBVH_LD(&w.bmax[a * 3 + k]) - LBVH_LD(&w.bmin[a * 3 + k]);
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+HD void fit_inner(int n, uint32_t cur, uint32_t max_leaf, const Work &w);
+HD void rotate_children(int n, uint32_t cur, uint32_t max_leaf, const Work &w) {
+    const uint32_t c[2] = {w.left[cur], w.right[cur]};
+    float best = 0.0f;
+    int best_side = -1, best_grand = 0;
+    for (int side = 0; side < 2; side++) {
+        const uint32_t x = c[side], other = c[1 - side];           // a grandchild below x may change places with `other`
+        if (x >= (uint32_t)(n - 1) || (LBVH_LD(&w.info[x]) & INFO_COLLAPSED)) continue;   // x is a leaf of the emitted tree
+        const uint32_t g[2] = {w.left[x], w.right[x]};
+        const float ax = node_half_area(w, x);
+        for (int k = 0; k < 2; k++) {
+            const float gain = ax - union_area3(w, other, g[1 - k]);   // x would keep g[1 - k] and get `other`
+            if (gain > best) { best = gain; best_side = side; best_grand = k; }
+        }
+    }
+    if (best_side < 0) return;
+    const uint32_t x = c[best_side], other = c[1 - best_side];
+    const uint32_t g = best_grand ? w.right[x] : w.left[x];
+    if (best_grand) w.right[x] = other; else w.left[x] = other;
+    if (best_side == 0) w.right[cur] = g; else w.left[cur] = g;
+    w.parent[other] = x; w.parent[g] = cur;
+    fit_inner(n, x, max_leaf, w);
+}
+
 // ---- builder 2: PLOC.  `cl` = the current clusters (node ids) in Morton order, m of them
 HD float union_area(const Work &w, uint32_t a, uint32_t b) {
     float d[3];

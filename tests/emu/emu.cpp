@@ -17,6 +17,7 @@
 #include "isaac_core.h"
 #include "lbvh_core.h"
 #include "post_core.h"
+#include <cstdlib>
 #include "pt_core.h"
 
 using namespace hr;
@@ -191,6 +192,7 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
         uint32_t cur = parent[n - 1 + k];
         while (cur != NO_PARENT) {
             if (flags[cur]++ == 0) break;
+            rotate_children(n, cur, (uint32_t)max_leaf, w);
             fit_inner(n, cur, (uint32_t)max_leaf, w);
             cur = parent[cur];
         }
