@@ -192,9 +192,9 @@ HD bool node_hit(const Node &nd, const Ray &r, float tbest) {
     const f2v oxy = {r.o.x, r.o.y}, ozz = {r.o.z, r.o.z}, ixy = {r.inv.x, r.inv.y}, izz = {r.inv.z, r.inv.z};
     const f2v nxy = {nd.nearx, nd.neary}, fxy = {nd.farx, nd.fary}, zz = {nd.nearz, nd.farz};
     const f2v tn = (nxy - oxy) * ixy, tf = (fxy - oxy) * ixy, tz = (zz - ozz) * izz;
-    const float tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
-    const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
-    return tmin <= tmax && !signbit(tmax) && tmin <= tbest;
+    const float entry = fmaxf(fmaxf(fmaxf(tn[0], tn[1]), tz[0]), 0.0f);      // as in trace_qnode: one compare
+    const float exit_ = fminf(fminf(fminf(tf[0], tf[1]), tz[1]), tbest);
+    return entry <= exit_;
 }
 // What a visit does to the walk.  `link` is the record's link word (inner: miss successor, leaf: leaf word), `next` the successor
 // in preorder (inner: the near child, leaf: the node behind it).  Written for the instruction count of the box phase's loop: one
@@ -236,9 +236,11 @@ HD void trace_qnode(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters 
     const f2v zz = {(float)(nd.z_nf & 0xffffu), (float)(nd.z_nf >> 16)};
     const f2v ixy = {r.qinv.x, r.qinv.y}, izz = {r.qinv.z, r.qinv.z}, cxy = {r.qc.x, r.qc.y}, czz = {r.qc.z, r.qc.z};
     const f2v tn = nxy * ixy + cxy, tf = fxy * ixy + cxy, tz = zz * izz + czz;
-    const float tmin = fmaxf(fmaxf(tn[0], tn[1]), tz[0]);
-    const float tmax = fminf(fminf(tf[0], tf[1]), tz[1]);
-    const bool hit = tmin <= tmax && !signbit(tmax) && tmin <= ts.t;
+    // entry distance clamped at 0, exit distance clamped at the closest hit so far: ONE compare decides (three compares joined by two
+    // scalar ANDs before).  A box that ends exactly at the origin (exit = -0.0) now counts as hit — one more visit, never a lost one.
+    const float entry = fmaxf(fmaxf(fmaxf(tn[0], tn[1]), tz[0]), 0.0f);
+    const float exit_ = fminf(fminf(fminf(tf[0], tf[1]), tz[1]), ts.t);
+    const bool hit = entry <= exit_;
     node_advance<SPEC>(ts, hit, nd.link, ts.cur + 16u);
 }
 template <bool CNT>
