@@ -479,6 +479,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     uint32_t total = 0;
     memcpy(&total, &hframe[6], sizeof total);
     if (total == 0 || total > (uint32_t)N) return fail(HR_ERR_DEVICE, "device BVH build: implausible record count %u for %d primitives", total, n);
+    if ((uint64_t)(total + 1u) * 8u * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "device BVH build: %u records per octant exceed the 2^28-byte offset range of the quantised records", total);
     c->bvh_build_ms = ms;
     d.nodes = nodes; d.num_nodes = total;
     d.qnodes = c->quant_nodes ? qnodes : nullptr;
@@ -518,6 +519,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     else {
         if ((r = upload(c, hs.nodes, &d.nodes))) return r;
         d.qnodes = nullptr;
+        if (c->quant_nodes && hs.qnodes.size() * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "hr_upload_scene: the quantised BVH records exceed their 2^28-byte offset range (set quant_nodes = 0)");
         if (c->quant_nodes && !hs.qnodes.empty() && (r = upload(c, hs.qnodes, &d.qnodes))) return r;
     }
     c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
