@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--quant-nodes", type=int, default=-1)
     ap.add_argument("--russian-roulette", type=int, default=0, help="NOT the reference's estimator: first iteration that plays (0 = off, default)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
-                    help="measurement knob of hr_set_debug_option (adv_den, leaf_den, min_waves, kchunk, node_unroll, trace_wgs, seed_mode, seed_split, seed_prio, init_prio)")
+                    help="measurement knob of hr_set_debug_option (adv_den, leaf_den, min_waves, kchunk, node_unroll, trace_wgs, seed_mode, seed_split, seed_prio, init_prio, ploc_top)")
     ap.add_argument("--debug-skip", type=int, default=0, help="timing experiments: drop parts of the pipeline after the warm-up (image is garbage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
@@ -173,6 +173,10 @@ def main():
             r.set_option("quant_nodes", args.quant_nodes)
         if args.split_ratio is not None:
             r.set_option("split_ratio", args.split_ratio)
+        for kv in args.debug:          # builder knobs act at the upload
+            k, v = kv.split("=")
+            if k == "ploc_top":
+                r.set_debug_option(k, float(v))
         r.upload_scene(scene)
         r.set_resolution(W, H)
         r.set_option("batch", args.batch)

@@ -4,6 +4,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <emmintrin.h>
 
 namespace hr {
 namespace {
@@ -263,6 +264,112 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
         node_set_box(pad, mn, mx, 0);
         pad.a = NODE_END; pad.b = NODE_END;
     }
+}
+
+namespace {
+// Binned SAH over cluster boxes, weighted by the primitives each cluster holds.  This runs on the host between two
+// device phases of builder 2, so its time is build time: boxes are four-float SSE values (x, y, z, pad), the three axes
+// are binned in one pass over the range, and small ranges use few bins (most of a tree's nodes are small).
+struct TopBuilder {
+    static constexpr int NBMAX = 32;
+    struct FBox {
+        __m128 mn, mx;
+        void reset() { mn = _mm_set1_ps(FLT_MAX); mx = _mm_set1_ps(-FLT_MAX); }
+        void grow(const FBox &o) { mn = _mm_min_ps(mn, o.mn); mx = _mm_max_ps(mx, o.mx); }
+        float area() const {
+            alignas(16) float d[4];
+            _mm_store_ps(d, _mm_sub_ps(mx, mn));
+            return d[0] < 0 ? 0.0f : d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+        }
+    };
+    const uint32_t *counts;
+    std::vector<uint32_t> idx;
+    std::vector<FBox> box;
+    struct V4 { __m128 v; };
+    std::vector<V4> cen;
+    std::vector<int32_t> &left, &right;
+    TopBuilder(const float *b, const uint32_t *c, uint32_t m, std::vector<int32_t> &l, std::vector<int32_t> &r) : counts(c), left(l), right(r) {
+        idx.resize(m);
+        box.resize(m);
+        cen.resize(m);
+        for (uint32_t i = 0; i < m; i++) {
+            const float *p = b + 6 * (size_t)i;
+            idx[i] = i;
+            box[i].mn = _mm_set_ps(0.0f, p[2], p[1], p[0]);
+            box[i].mx = _mm_set_ps(0.0f, p[5], p[4], p[3]);
+            cen[i].v = _mm_mul_ps(_mm_set1_ps(0.5f), _mm_add_ps(box[i].mn, box[i].mx));
+        }
+    }
+    int32_t build(uint32_t first, uint32_t count) {
+        if (count == 1) return ~(int32_t)idx[first];
+        const int32_t id = (int32_t)left.size();
+        left.push_back(0); right.push_back(0);
+        uint32_t mid = first + 1;
+        if (count > 2) {
+            __m128 lo = _mm_set1_ps(FLT_MAX), hi = _mm_set1_ps(-FLT_MAX);
+            for (uint32_t i = first; i < first + count; i++) { lo = _mm_min_ps(lo, cen[idx[i]].v); hi = _mm_max_ps(hi, cen[idx[i]].v); }
+            const int NB = (int)std::min<uint32_t>(NBMAX, std::max<uint32_t>(4u, count));
+            alignas(16) float ext[4], lof[4], scalef[4];
+            _mm_store_ps(ext, _mm_sub_ps(hi, lo));
+            _mm_store_ps(lof, lo);
+            for (int a = 0; a < 3; a++) scalef[a] = ext[a] > 0 ? (float)NB / ext[a] : 0.0f;
+            scalef[3] = 0.0f;
+            const __m128 scale = _mm_load_ps(scalef), top = _mm_set1_ps((float)(NB - 1));
+            FBox bb[3][NBMAX];
+            float bc[3][NBMAX];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < NB; b++) { bb[a][b].reset(); bc[a][b] = 0; }
+            for (uint32_t i = first; i < first + count; i++) {
+                const uint32_t c = idx[i];
+                alignas(16) int bin[4];
+                _mm_store_si128((__m128i *)bin, _mm_cvttps_epi32(_mm_min_ps(_mm_max_ps(_mm_mul_ps(_mm_sub_ps(cen[c].v, lo), scale), _mm_setzero_ps()), top)));
+                const float w = (float)counts[c];
+                for (int a = 0; a < 3; a++) { bb[a][bin[a]].grow(box[c]); bc[a][bin[a]] += w; }
+            }
+            float best_cost = FLT_MAX;
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; a++) {
+                if (!(scalef[a] > 0)) continue;
+                float ra[NBMAX], rc[NBMAX];
+                FBox acc;
+                acc.reset();
+                float cnt = 0;
+                for (int b = NB - 1; b > 0; b--) { acc.grow(bb[a][b]); cnt += bc[a][b]; ra[b] = acc.area(); rc[b] = cnt; }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    acc.grow(bb[a][b]);
+                    cnt += bc[a][b];
+                    if (!(cnt > 0) || !(rc[b + 1] > 0)) continue;
+                    const float cost = acc.area() * cnt + ra[b + 1] * rc[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            mid = first + count / 2;
+            if (best_axis >= 0) {
+                const float l0 = lof[best_axis], sc = scalef[best_axis], tp = (float)(NB - 1);
+                auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t c) {
+                    alignas(16) float cc[4];
+                    _mm_store_ps(cc, cen[c].v);
+                    return (int)std::min(std::max((cc[best_axis] - l0) * sc, 0.0f), tp) <= best_bin;
+                });
+                const uint32_t m2 = (uint32_t)(it - idx.begin());
+                if (m2 > first && m2 < first + count) mid = m2;
+            }
+        }
+        const int32_t l = build(first, mid - first), r = build(mid, first + count - mid);
+        left[(size_t)id] = l; right[(size_t)id] = r;
+        return id;
+    }
+};
+}  // namespace
+
+void build_top_tree(const float *boxes, const uint32_t *counts, uint32_t m, std::vector<int32_t> &out_left, std::vector<int32_t> &out_right) {
+    out_left.clear(); out_right.clear();
+    if (m < 2) return;
+    out_left.reserve(m - 1); out_right.reserve(m - 1);
+    TopBuilder b(boxes, counts, m, out_left, out_right);
+    b.build(0, m);
 }
 
 }  // namespace hr

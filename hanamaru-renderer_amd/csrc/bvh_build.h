@@ -28,4 +28,10 @@ struct BuiltBvh {
 
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out);
 
+// The TOP of a device-built tree (gpu_bvh.h, option bvh_builder = 2): the agglomerative PLOC build stops at <= a few thousand clusters
+// — bottom-up merges of Morton neighbours are at their worst where the boxes are big — and this top-down binned-SAH build (the rule of
+// build_bvh, weighted by the clusters' primitive counts) joins them.  boxes: 6 floats per cluster (min, max); out_left / out_right
+// get m - 1 entries, inner node i's children: a value v >= 0 is inner node v, a value < 0 is cluster ~v.  Inner node 0 is the root.
+void build_top_tree(const float *boxes, const uint32_t *counts, uint32_t m, std::vector<int32_t> &out_left, std::vector<int32_t> &out_right);
+
 }  // namespace hr

@@ -1,6 +1,7 @@
 // GPU BVH build: kernels around csrc/lbvh_core.h + the hipCUB radix sort.  Included by hr_api.hip.
-//   keys -> radix sort -> leaf boxes -> hierarchy (LBVH: one thread per internal node | PLOC: one workgroup iterating
-//   nearest-neighbour search / merge / compaction) -> bottom-up fit -> finish (leaf words, primitive order) -> frame of the
+//   (split clipping ->) keys -> radix sort -> leaf boxes -> hierarchy (LBVH: one thread per internal node | PLOC: iterations of
+//   nearest-neighbour search / merge / compaction down to a few thousand clusters, joined top-down by the host's binned SAH)
+//   -> bottom-up fit with tree rotations -> finish (leaf words, primitive order) -> frame of the
 //   quantised planes -> emit (both record formats, per-octant preorder) -> gather the primitives into leaf order
 #pragma once
 #include <hip/hip_runtime.h>
@@ -36,71 +37,18 @@ __global__ void hierarchy_kernel(const mkey_t *keys, int n, Work w) {
     if (i < n - 1) hierarchy_node(keys, n, i, w);
 }
 
-// PLOC: ONE workgroup runs all iterations (the scenes of this path have 10^4 - 10^5 primitives: an iteration is m x 16 box unions,
-// there are ~40 of them, and nothing has to leave the CU or return to the host in between).  Every thread owns a contiguous chunk
-// of the cluster array: nearest neighbours, then roles counted and scanned across the workgroup, then merge + compaction in order.
-static const int PLOC_THREADS = 1024;
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[16]*/, uint32_t &total) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t x = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = __shfl_up(x, off);
-        if (lane >= (uint32_t)off) x += y;
-    }
-    if (lane == 63u) s_wave[wave] = x;
-    __syncthreads();
-    uint32_t base = 0, sum = 0;
-    for (uint32_t k = 0; k < PLOC_THREADS / 64; k++) { if (k < wave) base += s_wave[k]; sum += s_wave[k]; }
-    __syncthreads();
-    total = sum;
-    return base + x - v;
-}
-__global__ __launch_bounds__(PLOC_THREADS) void ploc_kernel(int n, Work w, uint32_t *cl_a, uint32_t *cl_b, uint32_t *nn) {
-    __shared__ uint32_t s_wave[PLOC_THREADS / 64];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t k = tid; k < (uint32_t)n; k += PLOC_THREADS) cl_a[k] = (uint32_t)(n - 1) + k;
-    __syncthreads();
-    uint32_t *cur = cl_a, *nxt = cl_b;
-    uint32_t m = (uint32_t)n, next_node = (uint32_t)(n - 1);   // internal ids are handed out downwards: the last merge makes node 0, the root
-    while (m > 1u) {
-        const uint32_t chunk = (m + PLOC_THREADS - 1u) / PLOC_THREADS;
-        const uint32_t c0 = tid * chunk < m ? tid * chunk : m, c1 = c0 + chunk < m ? c0 + chunk : m;
-        for (uint32_t i = c0; i < c1; i++) nn[i] = ploc_nearest(w, cur, m, i);
-        __syncthreads();
-        uint32_t keep = 0, made = 0;
-        for (uint32_t i = c0; i < c1; i++) {
-            int role = ploc_role(nn, i);
-            keep += role != 2;
-            made += role == 1;
-        }
-        uint32_t total_keep, total_made;
-        uint32_t pos = block_exclusive_scan(keep, s_wave, total_keep);
-        uint32_t mrank = block_exclusive_scan(made, s_wave, total_made);
-        for (uint32_t i = c0; i < c1; i++) {
-            int role = ploc_role(nn, i);
-            if (role == 2) continue;
-            if (role == 1) {
-                uint32_t id = next_node - 1u - mrank++;
-                ploc_make_node(w, id, cur[i], cur[nn[i]]);
-                nxt[pos++] = id;
-            } else nxt[pos++] = cur[i];
-        }
-        __syncthreads();
-        m = total_keep;
-        next_node -= total_made;
-        uint32_t *t = cur; cur = nxt; nxt = t;
-    }
-    if (tid == 0) w.parent[0] = NO_PARENT;
-}
-
-// PLOC over several workgroups (scenes beyond what one workgroup iterates in reasonable time: the single-workgroup kernel above takes
-// 3 - 5 ms at 10^4 primitives and would take seconds at 10^6).  One iteration = four launches on the build stream:
+// PLOC, the bottom of the tree.  One iteration = four launches on the build stream (round 2 ran all iterations in ONE workgroup:
+// 3 - 5 ms at 10^4 primitives, unusable at 10^6):
 //   ploc_nn_kernel     every cluster's nearest neighbour within +-PLOC_RADIUS (reads the boxes the previous iteration's merges wrote)
 //   ploc_role_kernel   role per cluster -> packed counters {keeps a slot, makes a node}
 //   hipcub ExclusiveSum over the packed counters: the position of every survivor and the rank of every merge, in Morton order
 //   ploc_merge_kernel  merges + compaction into the other cluster array; the last cluster's thread writes the next iteration's
 //                      {cluster count, next free node id} into the OTHER half of a two-slot state (no kernel reads what it writes)
 // The cluster count lives on the device; the host reads it back every few iterations only to stop and to shrink the grids.
+// The merges stop at <= PLOC_TOP_CLUSTERS clusters: bottom-up merges of Morton neighbours are at their worst where the boxes are
+// big (the PLOC-only tree cost 1.10x the host SAH tree's node tests per ray), so the TOP of the tree is built top-down by the host
+// builder's binned SAH over the clusters (bvh_build.cpp build_top_tree: a few thousand boxes, well under a millisecond):
+// ploc_top_gather_kernel hands the clusters' boxes and primitive counts to the host, ploc_top_apply_kernel wires the result in.
 struct PlocState { uint32_t m, next_node; };
 __global__ void ploc_init_kernel(int n, uint32_t *cl, PlocState *st) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,7 +84,17 @@ __global__ void ploc_merge_kernel(Work w, const uint32_t *cur, uint32_t *nxt, co
     }
     if (i == m - 1u) { st_next->m = slot + (uint32_t)f; st_next->next_node = st->next_node - (mrank + (uint32_t)(f >> 32)); }
 }
-__global__ void ploc_root_kernel(Work w) { if (blockIdx.x == 0 && threadIdx.x == 0) w.parent[0] = NO_PARENT; }
+__global__ void ploc_top_gather_kernel(Work w, const uint32_t *clusters, uint32_t m, float *boxes, uint32_t *counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t c = clusters[i];
+    for (int a = 0; a < 3; a++) { boxes[6 * (size_t)i + a] = w.bmin[c * 3 + a]; boxes[6 * (size_t)i + 3 + a] = w.bmax[c * 3 + a]; }
+    counts[i] = w.info[c] & INFO_COUNT;
+}
+__global__ void ploc_top_apply_kernel(Work w, uint32_t inner, const int32_t *tl, const int32_t *tr, const uint32_t *clusters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < inner) top_apply(w, i, tl, tr, clusters);
+}
 
 // one thread per leaf walks up; the second arrival at a node fits it (its two subtrees are then complete)
 __global__ void fit_kernel(int n, uint32_t max_leaf, Work w) {

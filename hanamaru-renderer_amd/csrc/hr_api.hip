@@ -113,6 +113,7 @@ struct hr_ctx {
     bool seed_prof = false;                  // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
+    uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
     std::vector<EventPair> seed_events, trace_events, post_events, debug_events;
@@ -416,7 +417,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     if (e != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "hipcub sort (size query): %s", hipGetErrorString(e)); }
     LBVH_ALLOC(sort_tmp, unsigned char, sort_bytes, false)
     // multi-workgroup PLOC: packed role counters, their scan, the two-slot iteration state
-    const bool ploc_multi = c->bvh_builder == 2 && n > PLOC_THREADS;
+    const bool ploc_multi = c->bvh_builder == 2 && n > 1;
     size_t scan_bytes = 0;
     if (ploc_multi) {
         e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (u64t *)nullptr, (u64t *)nullptr, n, c->stream);
@@ -426,6 +427,11 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     LBVH_ALLOC(ploc_pos, u64t, ploc_multi ? n : 1, false)
     LBVH_ALLOC(scan_tmp, unsigned char, scan_bytes, false)
     LBVH_ALLOC(ploc_state, PlocState, 2, false)
+    const uint32_t top_cap = ploc_multi ? std::min<uint32_t>((uint32_t)n, c->ploc_top) : 1u;   // clusters the top-down build may be handed
+    LBVH_ALLOC(top_boxes, float, 6 * (size_t)top_cap, false)
+    LBVH_ALLOC(top_counts, uint32_t, top_cap, false)
+    LBVH_ALLOC(top_left, int32_t, top_cap, false)
+    LBVH_ALLOC(top_right, int32_t, top_cap, false)
 #undef LBVH_ALLOC
     const int T = 256;
     hipStream_t st = c->stream;
@@ -438,12 +444,12 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     if (e == hipSuccess) {
         leaf_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, w);
         if (n > 1 && c->bvh_builder == 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
-        if (n > 1 && c->bvh_builder == 2 && !ploc_multi) ploc_kernel<<<1, PLOC_THREADS, 0, st>>>(n, w, cl_a, cl_b, nn);
         if (ploc_multi) {
             ploc_init_kernel<<<(n + T - 1) / T, T, 0, st>>>(n, cl_a, ploc_state);
             uint32_t *cur = cl_a, *nxt = cl_b;
             uint32_t m_known = (uint32_t)n;   // the host's upper bound of the cluster count (refreshed every few iterations)
-            for (int it = 0; it < 4096 && m_known > 1u && e == hipSuccess; it++) {
+            int it = 0;
+            for (; it < 4096 && m_known > c->ploc_top && e == hipSuccess; it++) {
                 const uint32_t g = (m_known + T - 1) / T;
                 const PlocState *sin = ploc_state + (it & 1);
                 ploc_nn_kernel<<<g, T, 0, st>>>(w, cur, nn, sin);
@@ -451,15 +457,35 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
                 e = hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, ploc_flags, ploc_pos, (int)m_known, st);
                 ploc_merge_kernel<<<g, T, 0, st>>>(w, cur, nxt, nn, ploc_flags, ploc_pos, sin, ploc_state + ((it + 1) & 1));
                 std::swap(cur, nxt);
-                if ((it & 3) == 3 || m_known <= 64u) {   // every fourth iteration (and every one at the very end): how many are left?
+                if ((it & 3) == 3 || m_known <= 4u * c->ploc_top) {   // every fourth iteration (every one near the end): how many are left?
                     PlocState hs{};
                     if (e == hipSuccess) e = hipMemcpyAsync(&hs, ploc_state + ((it + 1) & 1), sizeof hs, hipMemcpyDeviceToHost, st);
                     if (e == hipSuccess) e = hipStreamSynchronize(st);
                     if (e == hipSuccess) m_known = hs.m;
                 }
             }
-            ploc_root_kernel<<<1, 64, 0, st>>>(w);
-            if (e == hipSuccess && m_known > 1u) e = hipErrorUnknown;   // did not converge (cannot happen: every iteration merges at least one pair)
+            if (e == hipSuccess && m_known > top_cap) e = hipErrorUnknown;   // (the loop ends at <= ploc_top clusters, the size of the top buffers)
+            // the top of the tree: binned SAH over the clusters that are left, on the host (a few thousand boxes)
+            if (e == hipSuccess && m_known > 1u) {
+                const uint32_t m = m_known;
+                std::vector<float> hb(6 * (size_t)m);
+                std::vector<uint32_t> hc(m);
+                ploc_top_gather_kernel<<<(m + T - 1) / T, T, 0, st>>>(w, cur, m, top_boxes, top_counts);
+                e = hipMemcpyAsync(hb.data(), top_boxes, hb.size() * sizeof(float), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), top_counts, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                std::vector<int32_t> tl, tr;
+                if (e == hipSuccess) {
+                    build_top_tree(hb.data(), hc.data(), m, tl, tr);
+                    if (tl.size() != (size_t)m - 1) e = hipErrorUnknown;
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(top_left, tl.data(), tl.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(top_right, tr.data(), tr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) {
+                    ploc_top_apply_kernel<<<(m - 1 + T - 1) / T, T, 0, st>>>(w, m - 1, top_left, top_right, cur);
+                    e = hipStreamSynchronize(st);   // tl / tr are host vectors about to go out of scope
+                }
+            }
         }
         fit_kernel<<<(n + T - 1) / T, T, 0, st>>>(n, (uint32_t)c->max_leaf, w);
         finish_kernel<<<(N + T - 1) / T, T, 0, st>>>(p, n, w, prim_pos);
@@ -1128,6 +1154,11 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
+    if (k == "ploc_top") {
+        if (value < 1 || value > (1 << 16)) return fail(HR_ERR_INVALID, "ploc_top must be in [1,65536]");
+        c->ploc_top = (uint32_t)value;
+        return HR_OK;
+    }
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
     return fail(HR_ERR_INVALID, "unknown debug option '%s'", key);
 }

@@ -310,9 +310,11 @@ HD int ploc_role(const uint32_t *nn, uint32_t i) {
     if (nn[j] != i) return 0;
     return i < j ? 1 : 2;
 }
+static const uint32_t PLOC_TOP_CLUSTERS = 8192;   // the merges stop at <= this many clusters; bvh_build.cpp's build_top_tree joins them top-down
 HD void ploc_make_node(const Work &w, uint32_t id, uint32_t l, uint32_t r) {
     w.left[id] = l; w.right[id] = r;
     w.parent[l] = id; w.parent[r] = id;
+    w.info[id] = (w.info[l] & INFO_COUNT) + (w.info[r] & INFO_COUNT);   // primitives in the cluster, for the top-down build (the fit rewrites info)
     for (int a = 0; a < 3; a++) {
         w.bmin[id * 3 + a] = fminf(w.bmin[l * 3 + a], w.bmin[r * 3 + a]);
         w.bmax[id * 3 + a] = fmaxf(w.bmax[l * 3 + a], w.bmax[r * 3 + a]);
@@ -331,6 +333,15 @@ HD float node_area(const Work &w, uint32_t node) {
 HD float sah_share(const Work &w, uint32_t node) {
     if (!is_emitted(w, node)) return 0.0f;
     return node_area(w, node) * (1.0f + (is_leaf_top(w, node) ? 1.5f * (float)(w.info[node] & INFO_COUNT) : 0.0f));
+}
+
+// the top tree (bvh_build.h build_top_tree) joins the clusters the merges left: its inner node i is internal node i of the hierarchy
+// (the merges handed their ids out downwards and left exactly 0 .. m - 2), a child value < 0 is cluster ~v
+HD void top_apply(const Work &w, uint32_t i, const int32_t *tl, const int32_t *tr, const uint32_t *clusters) {
+    const uint32_t l = tl[i] >= 0 ? (uint32_t)tl[i] : clusters[~tl[i]], r = tr[i] >= 0 ? (uint32_t)tr[i] : clusters[~tr[i]];
+    w.left[i] = l; w.right[i] = r;
+    w.parent[l] = i; w.parent[r] = i;
+    if (i == 0) w.parent[0] = NO_PARENT;
 }
 
 // ---- finish: every node finds its own place by walking up

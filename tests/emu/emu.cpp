@@ -173,7 +173,7 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
         std::vector<uint32_t> cl(n), nxt(n), nn(n);
         for (int k = 0; k < n; k++) cl[k] = (uint32_t)(n - 1 + k);
         uint32_t m = (uint32_t)n, next_node = (uint32_t)(n - 1);   // internal ids are handed out downwards: the last merge makes node 0, the root
-        while (m > 1) {
+        while (m > PLOC_TOP_CLUSTERS) {   // the merges stop at a few thousand clusters ...
             for (uint32_t i = 0; i < m; i++) nn[i] = ploc_nearest(w, cl.data(), m, i);
             uint32_t pos = 0, made = 0;
             for (uint32_t i = 0; i < m; i++) {
@@ -185,6 +185,17 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
             next_node -= made;
             m = pos;
             cl.swap(nxt);
+        }
+        if (m > 1) {   // ... and the host builder's binned SAH joins them top-down (as build_bvh_on_device does)
+            std::vector<float> boxes(6 * (size_t)m);
+            std::vector<uint32_t> counts(m);
+            for (uint32_t i = 0; i < m; i++) {
+                for (int a = 0; a < 3; a++) { boxes[6 * (size_t)i + a] = bmin[cl[i] * 3 + a]; boxes[6 * (size_t)i + 3 + a] = bmax[cl[i] * 3 + a]; }
+                counts[i] = info[cl[i]] & INFO_COUNT;
+            }
+            std::vector<int32_t> tl, tr;
+            build_top_tree(boxes.data(), counts.data(), m, tl, tr);
+            for (uint32_t i = 0; i + 1 < m; i++) top_apply(w, i, tl.data(), tr.data(), cl.data());
         }
         parent[0] = NO_PARENT;
     }
