@@ -4,7 +4,10 @@
 //                       octant o, each in its own near-first preorder; rtcamp6_v3_1: 8 x 13,950 x 16 B = 1.8 MB, L2-resident
 //   nodes[o][]   32 B   the same trees with fp32 near / far planes and explicit hit / miss links (Node below): debug kernels and the
 //                       quant_nodes = 0 variant of the trace kernel.  One record = two 16-byte loads
-//   tris[]       48 B   leaf-ordered: v0, e1 = v1-v0, e2 = v2-v0 (edges formed in f64, then rounded) + element id
+//   tris[]       48 B   leaf-ordered TriT: unit normal, the two barycentric gradients, v0 — what the intersection test consumes
+//   tri_shade[]  16 B   leaf-ordered TriS: unit normal + element id — what shading a triangle hit consumes
+//                       (both derived in f64 by tri_derive() from the geometry record Tri: v0, e1 = v1-v0, e2 = v2-v0 — edges formed in
+//                       f64, then rounded — + element id; Tri is what the builders read and is not kept after the upload of a host-built tree)
 //   spheres[]    16 B   centre, radius            (+ sphere_elem[])
 //   cuboids[]    32 B   min, max                  (+ element id in .w of the first float4)
 //   materials[]  64 B   per element
@@ -120,6 +123,33 @@ struct alignas(16) Tri {
     float e2z; int32_t element; float pad0, pad1;
 };
 
+// The records the kernels read for a triangle, derived from Tri (the fp32 triangle v0, v0 + e1, v0 + e2 IS the geometry: everything
+// below is computed in f64 from those nine floats and rounded once).  With n = e1 x e2:
+//   test:  t = -(nu . dd) / (nu . d) for dd = o - v0 (nu = n / |n|: the quotient does not depend on the length of n, the unit vector
+//          keeps both dot products well inside the fp32 range for any triangle size), p = dd + t d, u = a . p, v = b . p with
+//          a = (e2 x n) / |n|^2, b = (n x e1) / |n|^2  (a . e1 = 1, a . e2 = 0, b . e1 = 0, b . e2 = 1: the gradients of the barycentrics).
+//          Same t as Cramer's rule on (e1, e2, -d) (bvh.rs:266-290); u and v come out of 6 FMAs instead of a cross product and two dots.
+//   shade: the normal normalize(e1 x e2) of bvh.rs:286 (never flipped) and the element id in ONE 16-byte load.
+struct alignas(16) TriT {
+    float n[3]; float ax;
+    float ay, az, bx, by;
+    float bz; float v0[3];
+};
+struct alignas(16) TriS { float n[3]; int32_t element; };
+HD void tri_derive(const Tri &t, TriT &tt, TriS &ts) {
+    const double e1[3] = {t.e1x, t.e1y, t.e1z}, e2[3] = {t.e2x, t.e2y, t.e2z};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    // a degenerate triangle (nn == 0) gets n = a = b = 0: nu . d == 0 is the reference's det == 0, which rejects (bvh.rs:271)
+    const double inn = nn > 0.0 ? 1.0 / nn : 0.0, il = nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
+    const double a[3] = {(e2[1] * n[2] - e2[2] * n[1]) * inn, (e2[2] * n[0] - e2[0] * n[2]) * inn, (e2[0] * n[1] - e2[1] * n[0]) * inn};
+    const double b[3] = {(n[1] * e1[2] - n[2] * e1[1]) * inn, (n[2] * e1[0] - n[0] * e1[2]) * inn, (n[0] * e1[1] - n[1] * e1[0]) * inn};
+    for (int k = 0; k < 3; k++) { tt.n[k] = (float)(n[k] * il); tt.v0[k] = t.v0[k]; ts.n[k] = (float)(n[k] * il); }
+    tt.ax = (float)a[0]; tt.ay = (float)a[1]; tt.az = (float)a[2];
+    tt.bx = (float)b[0]; tt.by = (float)b[1]; tt.bz = (float)b[2];
+    ts.element = t.element;
+}
+
 struct alignas(16) Material {
     int32_t surface; float param; int32_t albedo_img, emission_img;
     float albedo[3]; int32_t roughness_img;
@@ -141,7 +171,7 @@ struct Scene {
     const QNode *qnodes;     // [8][num_nodes + 1], octant-major (host- and device-built trees alike); nullptr with option quant_nodes = 0
     float qmin[3], qstep[3]; // the grid of the quantised planes
     const Node *nodes;       // [8][num_nodes], octant-major
-    const Tri *tris;
+    const TriT *tris; const TriS *tri_shade;   // leaf-ordered, one pair per triangle reference
     const f4 *spheres; const int32_t *sphere_elem;
     const f4 *cuboids;       // 2 per cuboid: {min, element-as-int-bits}, {max, 0}
     const Material *materials;

@@ -77,10 +77,15 @@ static int ferr(std::string &err, int code, const char *fmt, ...) {
     return code;
 }
 
+void HostScene::derive_triangles() {
+    tri_t.resize(tris.size()); tri_s.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) tri_derive(tris[i], tri_t[i], tri_s[i]);
+}
+
 Scene HostScene::view() const {
     Scene d;
     memset(&d, 0, sizeof d);
-    d.nodes = nodes.data(); d.tris = tris.data();
+    d.nodes = nodes.data(); d.tris = tri_t.data(); d.tri_shade = tri_s.data();
     d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
     for (int k = 0; k < 3; k++) { d.qmin[k] = qmin[k]; d.qstep[k] = qstep[k]; }
     d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.cuboids = cuboids.data();
@@ -236,6 +241,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         d.e2x = (float)(s.v2[0] - s.v0[0]); d.e2y = (float)(s.v2[1] - s.v0[1]); d.e2z = (float)(s.v2[2] - s.v0[2]);
         d.element = s.elem;
     }
+    if (host_bvh) out.derive_triangles();   // (the device builders derive the records in their gather, in leaf order)
     out.spheres.resize(spheres.size()); out.sphere_elem.resize(spheres.size());
     for (size_t i = 0; i < spheres.size(); i++) { out.spheres[i] = spheres[bvh.order[1][i]]; out.sphere_elem[i] = sphere_elem[bvh.order[1][i]]; }
     out.cuboids.resize(cuboids.size());

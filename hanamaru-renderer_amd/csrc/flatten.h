@@ -16,7 +16,10 @@ struct HostScene {
     std::vector<QNode> qnodes; // [8][num_nodes + 1] (host builder only)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     uint32_t num_nodes = 0;
-    std::vector<Tri> tris;
+    std::vector<Tri> tris;       // geometry records (leaf order with host_bvh, input order without): what the builders read
+    std::vector<TriT> tri_t;     // derived from tris by derive_triangles(): what the kernels read (device_scene.h)
+    std::vector<TriS> tri_s;
+    void derive_triangles();
     std::vector<f4> spheres;
     std::vector<int32_t> sphere_elem;
     std::vector<f4> cuboids;

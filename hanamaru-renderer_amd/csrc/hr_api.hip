@@ -330,11 +330,11 @@ int hr_destroy(hr_ctx *c) {
 // thin triangles into references (early split clipping), build the tree over them, emit it in both record formats (16-byte quantised
 // records in per-octant near-first preorder — what the trace kernel walks — and the 32-byte fp32 records), re-store the primitives
 // in leaf order and point the scene at the results.  Scratch is freed before returning.
-static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
+static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_in) {
     using namespace lbvh;
     Scene &d = c->dsc;
     Prims p{};
-    p.tris = d.tris; p.num_tris = d.num_tris; p.spheres = d.spheres; p.num_spheres = d.num_spheres; p.cuboids = d.cuboids; p.num_cuboids = d.num_cuboids;
+    p.tris = tris_in; p.num_tris = d.num_tris; p.spheres = d.spheres; p.num_spheres = d.num_spheres; p.cuboids = d.cuboids; p.num_cuboids = d.num_cuboids;
     p.ref_tri = nullptr; p.ref_box = nullptr;
     double scene_sa = 0.0;
     for (int a = 0; a < 3; a++) {
@@ -376,7 +376,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
         size_t sbytes = 0;
         hipError_t se = hipcub::DeviceScan::ExclusiveSum(nullptr, sbytes, split_counts, split_offsets, (int)nt, c->stream);
         LBVH_ALLOC(split_tmp, unsigned char, sbytes, false)
-        split_count_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(d.tris, nt, sp, split_counts);
+        split_count_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(tris_in, nt, sp, split_counts);
         if (se == hipSuccess) se = hipcub::DeviceScan::ExclusiveSum(split_tmp, sbytes, split_counts, split_offsets, (int)nt, c->stream);
         uint32_t last[2] = {0, 0};
         if (se == hipSuccess) se = hipMemcpyAsync(&last[0], split_offsets + (nt - 1), 4, hipMemcpyDeviceToHost, c->stream);
@@ -387,7 +387,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
         if (refs > nt && refs + d.num_spheres + d.num_cuboids < (1ull << KEY_INDEX_BITS)) {
             LBVH_ALLOC(ref_tri, uint32_t, refs, false)
             LBVH_ALLOC(ref_box, float, 6 * refs, false)
-            split_emit_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(d.tris, nt, sp, split_offsets, ref_tri, ref_box);
+            split_emit_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(tris_in, nt, sp, split_offsets, ref_tri, ref_box);
             p.ref_tri = ref_tri; p.ref_box = ref_box; p.num_tris = (uint32_t)refs;
         }
     }
@@ -408,7 +408,8 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     // the emitted tree has size[root] <= 2n-1 records per octant (collapsed subtrees are one record): sized for the worst case
     LBVH_ALLOC(nodes, Node, 8 * (size_t)N + 1, true)
     LBVH_ALLOC(qnodes, QNode, 8 * ((size_t)N + 1), true)
-    LBVH_ALLOC(tris, Tri, p.num_tris, true)
+    LBVH_ALLOC(tris, TriT, p.num_tris, true)
+    LBVH_ALLOC(tri_shade, TriS, p.num_tris, true)
     LBVH_ALLOC(spheres, f4, d.num_spheres, true)
     LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
     LBVH_ALLOC(cuboids, f4, 2 * (size_t)d.num_cuboids, true)
@@ -491,7 +492,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
         finish_kernel<<<(N + T - 1) / T, T, 0, st>>>(p, n, w, prim_pos);
         frame_kernel<<<1, 64, 0, st>>>(w, frame);
         emit_kernel<<<(8 * N + T - 1) / T, T, 0, st>>>(n, w, frame, nodes, qnodes);
-        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, spheres, sphere_elem, d.sphere_elem, cuboids);
+        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, tri_shade, spheres, sphere_elem, d.sphere_elem, cuboids);
         e = hipGetLastError();
     }
     (void)hipEventRecord(eb, st);
@@ -511,7 +512,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs) {
     d.qnodes = c->quant_nodes ? qnodes : nullptr;
     for (int a = 0; a < 3; a++) { d.qmin[a] = hframe[a]; d.qstep[a] = hframe[3 + a]; }
 
-    d.tris = tris; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
+    d.tris = tris; d.tri_shade = tri_shade; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
     d.num_tris = p.num_tris;   // leaf-ordered records: one per reference (a split triangle appears once per piece)
     return HR_OK;
 }
@@ -532,7 +533,8 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     Scene &d = c->dsc;
     d = hs.view();
     int r;
-    if ((r = upload(c, hs.tris, &d.tris))) return r;
+    const Tri *tris_in = nullptr;   // the geometry records: input of the device builders, or (host-built tree, leaf order) of the derivation below
+    if ((r = upload(c, hs.tris, &tris_in))) return r;
     if ((r = upload(c, hs.spheres, &d.spheres))) return r;
     if ((r = upload(c, hs.sphere_elem, &d.sphere_elem))) return r;
     if ((r = upload(c, hs.cuboids, &d.cuboids))) return r;
@@ -541,8 +543,21 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.emitters, &d.emitters))) return r;
     if ((r = upload(c, hs.texels, &d.texels))) return r;
     c->bvh_build_ms = 0;
-    if (gpu_build) { if ((r = build_bvh_on_device(c, hs))) return r; }
+    if (gpu_build) { if ((r = build_bvh_on_device(c, hs, tris_in))) return r; }
     else {
+        // the records the kernels read for a triangle, derived on the device (as the device builders' gather does)
+        TriT *tt = nullptr; TriS *tsh = nullptr;
+        const size_t nt = hs.tris.size();
+        HIP_TRY(hipMalloc((void **)&tt, std::max<size_t>(nt * sizeof(TriT), 16)));
+        c->scene_allocs.push_back(tt);
+        HIP_TRY(hipMalloc((void **)&tsh, std::max<size_t>(nt * sizeof(TriS), 16)));
+        c->scene_allocs.push_back(tsh);
+        if (nt) {
+            lbvh::tri_derive_kernel<<<(unsigned)((nt + 255) / 256), 256, 0, c->stream>>>(tris_in, (uint32_t)nt, tt, tsh);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        d.tris = tt; d.tri_shade = tsh;
         if ((r = upload(c, hs.nodes, &d.nodes))) return r;
         d.qnodes = nullptr;
         if (c->quant_nodes && hs.qnodes.size() * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "hr_upload_scene: the quantised BVH records exceed their 2^28-byte offset range (set quant_nodes = 0)");

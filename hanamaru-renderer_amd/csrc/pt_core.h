@@ -100,25 +100,24 @@ HD bool trace_done(const TraceState &ts) { return ts.cur == NODE_END && ts.leaf 
 
 struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests; };
 
-// bvh.rs:266-290 (Cramer's rule, two-sided, accepts t == best) with e1,e2 precomputed
+// bvh.rs:266-290 (two-sided, accepts t == best, rejects det == 0) on the derived record TriT (device_scene.h): the plane first, then the
+// barycentrics as two dot products with the hit position relative to v0.  Straight-line: the lanes of a wave test different triangles,
+// an early return saves nothing unless ALL of them take it, and the branches cost scalar slots the seed kernel's waves want.
+//   `live` = this lane really has a triangle to test (the second slot of an odd-sized leaf repeats the first).
+// Acceptance: t >= 0, u >= 0, v >= 0 (one min3 and one compare), u + v <= 1, t <= closest so far.  u <= 1 (bvh.rs:277) follows from
+// v >= 0 and u + v <= 1 (rounding is monotonic).  nu . d == 0 needs no compare of its own: 1 / 0 = inf makes t infinite or NaN, the
+// position p then has infinite or NaN components exactly where d is non-zero, and a dot product with it is +-inf or NaN (0 x inf),
+// never finite: u + v <= 1 fails (a NaN fails every compare; min ignores a NaN operand, the sum does not).
 template <bool CNT>
-HD void tri_test(const Tri &tr, const Ray &r, TraceState &ts, int32_t index, LaneCounters *cn) {
-    if (CNT) cn->tri_tests++;
-    V3f e1 = v3(tr.e1x, tr.e1y, tr.e1z), e2 = v3(tr.e2x, tr.e2y, tr.e2z);
-    V3f ri = -r.d;
-    V3f c12 = cross(e1, e2);                 // det(e1,e2,c) = (e1 x e2) . c
-    float den = dot(c12, ri);
-    if (den == 0.0f) return;
-    float inv = HR_RCP(den);
-    V3f dd = r.o - v3(tr.v0);
-    V3f q = cross(dd, ri);                   // helpers: det(d,e2,ri) = -(d x ri).e2 ... written out below
-    float u = -dot(q, e2) * inv;             // det(d, e2, ri)  = d . (e2 x ri) = -(d x ri) . e2
-    if (!(u >= 0.0f && u <= 1.0f)) return;   // bvh.rs:277 (written so that a NaN from a degenerate triangle rejects)
-    float v = dot(q, e1) * inv;              // det(e1, d, ri)  = e1 . (d x ri)
-    if (!(v >= 0.0f && u + v <= 1.0f)) return;
-    float t = dot(c12, dd) * inv;            // det(e1, e2, d)
-    if (!(t >= 0.0f && t <= ts.t)) return;
-    ts.t = t; ts.prim = index; ts.type = 0; ts.u = u; ts.v = v;
+HD void tri_test(const TriT &tr, const Ray &r, TraceState &ts, int32_t index, bool live, LaneCounters *cn) {
+    if (CNT) cn->tri_tests += live ? 1u : 0u;
+    const V3f n = v3(tr.n), a = v3(tr.ax, tr.ay, tr.az), b = v3(tr.bx, tr.by, tr.bz);
+    const V3f dd = r.o - v3(tr.v0);
+    const float t = -dot(n, dd) * HR_RCP(dot(n, r.d));
+    const V3f p = v3(fmaf(t, r.d.x, dd.x), fmaf(t, r.d.y, dd.y), fmaf(t, r.d.z, dd.z));
+    const float u = dot(a, p), v = dot(b, p);   // (packed FMAs for the two pairs of dot products: measured, 2 % slower — the operand pairs cost moves)
+    const bool ok = live & (fminf(fminf(t, u), v) >= 0.0f) & (u + v <= 1.0f) & (t <= ts.t);
+    ts.t = ok ? t : ts.t; ts.prim = ok ? index : ts.prim; ts.type = ok ? 0 : ts.type; ts.u = ok ? u : ts.u; ts.v = ok ? v : ts.v;
 }
 // scene.rs:58-78 (outer root only), in f64 on the fp32 ray and sphere.  Same roots as the reference's b^2 - c form, with the
 // discriminant taken from the perpendicular offset of the centre (r^2 - |a - b d|^2: no cancellation when the origin is many radii
@@ -250,11 +249,11 @@ HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *
     if (type == 0) {
         // two triangles per round so their loads are in flight together
         for (uint32_t k = 0; k < count; k += 2) {
-            const Tri ta = sc.tris[first + k];
+            const TriT ta = sc.tris[first + k];
             const bool two = k + 1 < count;
-            const Tri tb = sc.tris[first + (two ? k + 1 : k)];
-            tri_test<CNT>(ta, r, ts, (int32_t)(first + k), cn);
-            if (two) tri_test<CNT>(tb, r, ts, (int32_t)(first + k + 1), cn);
+            const TriT tb = sc.tris[first + (two ? k + 1 : k)];
+            tri_test<CNT>(ta, r, ts, (int32_t)(first + k), true, cn);
+            tri_test<CNT>(tb, r, ts, (int32_t)(first + k + 1), two, cn);
         }
     } else if (type == 1) {
         for (uint32_t k = 0; k < count; k++) sphere_test<CNT>(sc.spheres[first + k], r, ts, (int32_t)(first + k), cn);
@@ -290,8 +289,8 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
     s.pos = r.o + r.d * ts.t;
     s.u = ts.u; s.v = ts.v;
     if (ts.type == 0) {
-        const Tri tr = sc.tris[ts.prim];
-        s.n = normalize(cross(v3(tr.e1x, tr.e1y, tr.e1z), v3(tr.e2x, tr.e2y, tr.e2z)));  // bvh.rs:286 (never flipped)
+        const TriS tr = sc.tri_shade[ts.prim];
+        s.n = v3(tr.n);  // bvh.rs:286 (never flipped), normalised in f64 by tri_derive()
         s.elem = tr.element;
     } else if (ts.type == 1) {
         const f4 sp = sc.spheres[ts.prim];
@@ -562,7 +561,7 @@ HD void shadow_early_out(Path &p) {
 }
 
 HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
-    return (ts.type == 0) ? sc.tris[ts.prim].element : (ts.type == 1 ? sc.sphere_elem[ts.prim] : float_as_int(sc.cuboids[2 * ts.prim].w));
+    return (ts.type == 0) ? sc.tri_shade[ts.prim].element : (ts.type == 1 ? sc.sphere_elem[ts.prim] : float_as_int(sc.cuboids[2 * ts.prim].w));
 }
 
 // returns true when the path is finished (accum final)
