@@ -100,7 +100,7 @@ struct hr_ctx {
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
     int trace_boost = -1;                    // trace-kernel phases above the producer waves: -1 = governed by the measured kernel times (default), 0 .. 4 = fixed level (GOV_MASK)
-    int boost_now = 2;                       // the governor's current level
+    int boost_now = 0;                       // the governor's current level (it starts at "seed kernel first": see govern_reset)
     float gov_known[5] = {0, 0, 0, 0, 0};    // per level: smoothed max(seed, trace) ms of the launches measured at it (0 = not tried on this scene / size)
     size_t gov_next = 0;                     // first launch (index into seed_events / trace_events) the governor has not looked at
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
@@ -110,7 +110,7 @@ struct hr_ctx {
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
     int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
-    bool seed_prof = false;                  // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
+    int seed_prof = 0;                       // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
@@ -140,9 +140,9 @@ static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
     *out = reinterpret_cast<const T *>(d);
     return HR_OK;
 }
-// Priority governor (see hr_render).  Three levels (trace kernel's box phase / box and leaf phases above the producer waves).
+// Priority governor (see hr_render).  Five levels, from the seed kernel's producer waves first to the trace kernel's box and leaf phases first.
 // A finished launch says how long the slower of the two kernels took at the current level; an untried neighbouring level is tried
-// when the balance asks for it (trace kernel more than 3 % behind -> up, seed kernel -> down), otherwise the best level known wins.
+// when the balance asks for it (trace kernel more than 1.5 % behind -> up, seed kernel -> down), otherwise the best level known wins.
 // `level` is the level the measured launch RAN at (the host enqueues several launches ahead of the GPU, so it is not
 // necessarily the current one): its time is credited to that level, and only a launch that ran at the current level may move it.
 // Levels, from "the seed kernel's producer waves first" to "the trace kernel first":
@@ -171,7 +171,10 @@ static void invalidate_totals(hr_ctx *c) {
     c->total_valid = false;
     for (hr_ctx *p : c->same_device_peers) p->total_valid = false;
 }
-static void govern_reset(hr_ctx *c) { for (float &g : c->gov_known) g = 0; if (c->trace_boost < 0) c->boost_now = 2; }
+// The governor starts at level 0: next to a trace kernel that needs 16 ms per 33 M paths on the reference's scenes the seed kernel (24 ms)
+// is the slower one almost everywhere, and the host enqueues launches far ahead of the GPU — the governor gets to see finished launches
+// only where the host waits for the device anyway, so it climbs one level per synchronisation point at most.
+static void govern_reset(hr_ctx *c) { for (float &g : c->gov_known) g = 0; if (c->trace_boost < 0) c->boost_now = 0; }
 static int drain_events(hr_ctx *c) {
     {   // the lists about to be emptied still have something to tell the governor: the launch before the last one (the last trace
         // kernel had the chip to itself, the first seed kernel too)
@@ -277,6 +280,10 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
     // The seed kernel owns all 160 KiB of a CU's LDS and runs next to the trace kernel of the previous batch: a trace kernel that
     // uses ANY LDS (the compiler promotes small private arrays to LDS unless told not to, see the Makefile) could not share a CU
@@ -674,6 +681,11 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
         if (c->seed_prof) hipLaunchKernelGGL((seed_seg_kernel<true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
         else hipLaunchKernelGGL((seed_seg_kernel<false>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+    } else if (c->seed_mode == 3) {
+        if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
+#define HR_LAUNCH_PS(P) hipLaunchKernelGGL(seed_ps_kernel<P>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
+        switch (c->seed_prof) { case 1: HR_LAUNCH_PS(1); break; case 2: HR_LAUNCH_PS(2); break; case 3: HR_LAUNCH_PS(3); break; default: HR_LAUNCH_PS(0); break; }
+#undef HR_LAUNCH_PS
     } else if (c->seed_mode == 1) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
 #define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
@@ -1162,13 +1174,13 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "seed_mode") {
-        if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "seed_mode must be 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
+        if (value != 0 && value != 1 && value != 2 && value != 3) return fail(HR_ERR_INVALID, "seed_mode must be 3 (phase-shifted four-run kernel), 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
         int rc = sync_all(c);
         if (rc) return rc;
         c->seed_mode = (int)value;
         return HR_OK;
     }
-    if (k == "seed_prof") { c->seed_prof = value != 0.0; return HR_OK; }
+    if (k == "seed_prof") { c->seed_prof = (int)value; return HR_OK; }
     if (k == "ploc_top") {
         if (value < 1 || value > (1 << 16)) return fail(HR_ERR_INVALID, "ploc_top must be in [1,65536]");
         c->ploc_top = (uint32_t)value;

@@ -572,6 +572,216 @@ __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens
     else seed_seg_producer(rp, r, smem, lane, half);
 }
 
+// ---- phase-shifted four-run seeding (debug option seed_mode = 3) ----------------------------------------------------------------------------------
+// The three-run kernel's window is 11 blocks long because a half has 120 lanes to fill it with (its consumer wave and its producer
+// wave).  Here the two halves run HALF A PERIOD APART: while one consumer is in the middle of its round the other half's window is
+// served by that half's consumer AND BOTH producer waves — 192 lanes for 40 generators x 4 runs of 8 blocks (PS_NBLK; 160 lane-runs):
+//     slot 0 = the half's consumer, slot 1 / 2 = the producer waves; lane-run L = 64 slot + lane < 160: generator L % 40, run L / 40
+// The window is 8 blocks instead of 11.  s_barrier is workgroup-wide, so everybody meets at every barrier; per group there are four:
+//     W0s  half 0 is free (consumer 0 has finished its round)      W0e  half 0's states are in -> consumer 0 starts its round
+//     W1s  half 1 is free                                          W1e  half 1's states are in -> consumer 1 starts its round
+// A consumer passes the OTHER half's two barriers in the middle of its round (PsRoundSync: after steps 112 and 156 — the round is
+// 112 + 44 + 100 steps, its last 100 carry the record tail, and 44 steps take as long as the 8-block window), the producers run a
+// window at each pair and one half of a PAUSED ahead pass in each of the two slots in between (isaac_ahead_part1 / part2: a whole
+// ahead pass of a 64-path chunk is longer than a slot).  Consumer 1 idles half a period at the start, consumer 0 at the end; two
+// trailing barriers let consumer 1 finish its last round.
+static const int PS_NRUN = 4, PS_NBLK = 8, PS_P1BLK = 4;
+struct PsLayout {
+    static const size_t STATE_WORDS = (size_t)16 * SEED_LANES;
+    static const size_t HALF_WORDS = PS_NRUN * STATE_WORDS;
+    static const size_t GROUP_WORDS = 2 * HALF_WORDS;
+};
+static_assert(SEED_RING_GROUPS * PsLayout::GROUP_WORDS <= SEED_RING_WORDS_MAX, "the ring allocation of the producer / consumer kernel holds it");
+struct PsStateOut {
+    u64 *base;   // &half[0][0][column][0]
+    __device__ __forceinline__ void state(int k, u64 a, u64 b, u64 c, u64 d, u64 e, u64 f, u64 g, u64 h, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 *dst = reinterpret_cast<u64x2 *>(base + (size_t)k * PsLayout::STATE_WORDS);
+        const u64x2 q[8] = {{a, b}, {c, d}, {e, f}, {g, h}, {A, B}, {C, D}, {E, F}, {G, H}};
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst + j * SEED_LANES), "v"(q[j]) : "memory");   // (see SegStateOut)
+    }
+};
+struct PsLane { uint32_t col, run; bool on; };
+__device__ __forceinline__ PsLane ps_lane(uint32_t slot, uint32_t lane) {
+    const uint32_t L = slot * 64u + lane;
+    PsLane l;
+    l.on = L < (uint32_t)(PS_NRUN * SEED_LANES);
+    const uint32_t Lc = l.on ? L : 0u;
+    l.run = Lc / (uint32_t)SEED_LANES; l.col = Lc - l.run * (uint32_t)SEED_LANES;
+    return l;
+}
+struct PsRegs {
+    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t v[8];
+    __device__ __forceinline__ void load(const u64 *ring_wg, uint64_t g, uint32_t half, const PsLane &l) {
+        const u64 *regs = ring_wg + (g & (SEED_RING_GROUPS - 1)) * PsLayout::GROUP_WORDS + half * PsLayout::HALF_WORDS + (size_t)l.run * PsLayout::STATE_WORDS + (size_t)l.col * 2u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
+    }
+    __device__ __forceinline__ void run(unsigned char *lds_half, const PsLane &l) const {
+        u64 st16[16];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { st16[2 * q] = v[q].x; st16[2 * q + 1] = v[q].y; }
+        LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + l.col + (size_t)(l.run * (uint32_t)PS_NBLK) * 8u * SEED_LANES};
+        if (l.on) isaac_init_run<PS_NBLK>(m, st16);
+    }
+};
+template <bool PROF>
+struct PsRoundSync {
+    static constexpr bool ON = true;
+    static constexpr int N1 = 104, K1 = 2, N2 = 148, K2 = 2;   // after steps 111 and 155
+    unsigned long long *pc, *tm; mutable int k;
+    __device__ __forceinline__ void mid() const {   // a pure rendezvous: nothing of this wave's is handed over
+        if (PROF) { unsigned long long now = __builtin_readcyclecounter(); pc[3 + 2 * k] += now - *tm; *tm = now; }
+        __builtin_amdgcn_s_barrier();
+        if (PROF) { unsigned long long now = __builtin_readcyclecounter(); pc[4 + 2 * k] += now - *tm; *tm = now; k++; }
+    }
+};
+// PROF (option seed_prof = 1 | 2 | 3: consumer 0, consumer 1, producer 0): cycle stamps around every barrier of the chosen wave, summed into
+// Counters::seed_phase — consumer: wait Ws, window, wait We, round part 1, wait, part 2, wait, part 3 + records; producer: wait W0s, window 0,
+// wait W0e, slot A, wait W1s, window 1, wait W1e, slot B
+template <int PROF>
+__device__ __forceinline__ void seed_ps_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
+                                                 float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * rp.ovf_cap;
+    uint32_t ovf_count = 0;
+    const PsLane sl = ps_lane(0u, lane);
+    PsRegs regs;
+    constexpr bool P = PROF != 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
+#define HR_STAMP(i) do { if (P) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
+    const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+    unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+    LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
+    const uint64_t n_groups = r.G1 - r.G0;
+    __syncthreads();   // the states of groups G0 and G0 + 1 are in the ring
+    if (n_groups >= 1) regs.load(r.ring_wg, r.G0, half, sl);
+    if (half == 1u && n_groups >= 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // W0s(1), W0e(1): half a period behind
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        const uint64_t g = r.G0 + it - 1;
+        const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
+        const bool in_range = pid < r.paths;
+        const uint32_t item = (uint32_t)((in_range ? pid : r.paths - 1) >> 6), j = (uint32_t)((in_range ? pid : r.paths - 1) & 63u);
+        uint32_t tile = item / rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        const bool valid = in_range && px < rp.width && py < rp.height;
+        if (P) tm = __builtin_readcyclecounter();
+        __syncthreads();   // Ws: this half's LDS is free (the round before has read its last word)
+        HR_STAMP(0);
+        regs.run(lds_half, sl);                          // the window: this wave's runs of the sweep, straight into LDS
+        HR_STAMP(1);
+        __syncthreads();   // We: all four runs of every column are in
+        HR_STAMP(2);
+        if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);
+        RecStore rs(recs, pid);
+        RecordTail<RecStore> lt(rs, lens_shape);
+        if (lane < (uint32_t)SEED_LANES) {
+            isaac_round_deep28(m, lt, PsRoundSync<P>{pc, &tm, 0});   // passes the other half's Ws and We on its way
+            lt.finish();
+        }   // (s_barrier is a scalar instruction: the wave passes the two rendezvous once, whatever its lane mask is in there)
+        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count, rp.ovf_cap);
+        HR_STAMP(7);
+    }
+    if (half == 0u && n_groups >= 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // W0s(n + 1), W0e(n + 1): consumer 1's last round passes them
+#undef HR_STAMP
+    if (P && lane == 0 && half + 1u == (uint32_t)PROF)
+        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
+    const bool lane_on = lane < (uint32_t)SEED_LANES;
+    seed_fixup_wave(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
+}
+template <int PROF>
+__device__ __forceinline__ void seed_ps_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half, Counters *cnt) {
+    constexpr bool P = PROF == 3;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
+#define HR_STAMP(i) do { if (P) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
+    const IsaacWarm warm = isaac_warm();
+    const PsLane sl = ps_lane(1u + half, lane);
+    PsRegs regs;
+    const uint64_t n_groups = r.G1 - r.G0;
+    uint64_t frontier = r.first_path & ~63ull;               // first path whose states are not in the ring yet (chunks of 64 paths)
+    // one 64-path chunk of the ahead pass, in two parts (this wave takes every other chunk)
+    AheadRegs job;
+    PsStateOut job_out{nullptr};
+    bool job_on = false, job_open = false;
+    auto part1 = [&](uint64_t upto) -> bool {   // start the next chunk of this wave below group `upto`, if there is one
+        const uint64_t need = upto * SEED_COLS;
+        for (; frontier < need && frontier < r.end_path; frontier += 64) {
+            if (((frontier >> 6) & 1u) != half) continue;
+            const uint64_t pid0 = frontier + lane;
+            job_on = pid0 >= r.first_path && pid0 < r.end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
+            const uint64_t ppid = pid0 >= r.first_path && pid0 < r.end_path ? pid0 : r.end_path - 1;
+            const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
+            uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+            uint32_t px, py, sub;
+            tile_lane_pixel(rp, tile, j, px, py, sub);
+            bool pvalid = px < rp.width && py < rp.height;
+            u64 s, t;
+            path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
+            const uint64_t g = ppid / SEED_COLS;
+            const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS), hh = c80 >= (uint32_t)SEED_LANES ? 1u : 0u;
+            job_out.base = r.ring_wg + (g & (SEED_RING_GROUPS - 1)) * PsLayout::GROUP_WORDS + hh * PsLayout::HALF_WORDS + (size_t)(c80 - hh * (uint32_t)SEED_LANES) * 2u;
+            if (job_on) isaac_ahead_part1<PS_P1BLK>(job_out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, job);
+            frontier += 64;
+            return true;
+        }
+        return false;
+    };
+    auto part2 = [&]() {
+        if (job_on) isaac_ahead_part2<PS_NRUN, PS_NBLK, PS_P1BLK>(job_out, job);
+        __builtin_amdgcn_s_waitcnt(0);   // the state stores are hand-written: the compiler does not wait for them at the barrier by itself
+    };
+    // before the first window: the states of groups G0 and G0 + 1, without pausing
+    while (part1(r.G0 + 2)) part2();
+    __syncthreads();
+    if (P) tm = __builtin_readcyclecounter();
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        const uint64_t g = r.G0 + it - 1;
+        for (uint32_t hw = 0; hw < 2u; hw++) {
+            regs.load(r.ring_wg, g, hw, sl);                 // complete in the ring for more than a group
+            HR_STAMP(hw ? 3 : 7);
+            __syncthreads();   // Ws(hw)
+            HR_STAMP(hw ? 4 : 0);
+            regs.run(smem + (size_t)hw * SEED_LDS_HALF_BYTES, sl);   // the window of half hw
+            HR_STAMP(hw ? 5 : 1);
+            __syncthreads();   // We(hw)
+            HR_STAMP(hw ? 6 : 2);
+            // the slot behind the window: one half of a chunk of the ahead pass.  By the end of this group the states of group
+            // it + 2 have to be complete; a wave's chunks are 128 paths apart and the target moves by 80 paths a group, so one
+            // chunk per group and wave is enough
+            if (hw == 0u) job_open = part1(r.G0 + it + 2);
+            else if (job_open) { part2(); job_open = false; }
+        }
+    }
+    if (n_groups >= 1) { __syncthreads(); __syncthreads(); }   // W0s(n + 1), W0e(n + 1)
+#undef HR_STAMP
+    if (P && lane == 0 && half == 0u)
+        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
+}
+template <int PROF = 0>
+__global__ __launch_bounds__(256) void seed_ps_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
+                                                      uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
+    const bool consumer = wave < 2u;
+    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1] & 3u;
+    switch (prio) {  // s_setprio takes an immediate
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+    PcRange r;
+    r.paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t groups = (r.paths + SEED_COLS - 1) / SEED_COLS;
+    r.G0 = groups * blockIdx.x / gridDim.x; r.G1 = groups * (blockIdx.x + 1) / gridDim.x;
+    r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
+    r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
+    if (consumer) seed_ps_consumer<PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
+    else seed_ps_producer<PROF>(rp, r, smem, lane, half, cnt);
+}
+
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
 struct RawTail {
     u64 *out; int window;
