@@ -184,6 +184,83 @@ def test_lbvh_radiance(scenes, emu, orc, builder):
     assert (err < ATOL_REL).mean() > FRAC_OK
 
 
+def _triangle_scene(ha, verts, faces):
+    """One mesh element with the given triangles, camera / skybox / images borrowed from cornell_mini."""
+    import ctypes as C
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    faces = np.ascontiguousarray(faces, dtype=np.uint64)
+    base = ha.Scene("cornell_mini")
+    el = (ha.Element * 1)()
+    el[0].kind = ha.MESH
+    el[0].material.albedo.color = ha.Vec3(0.7, 0.7, 0.7)
+    el[0].material.albedo.image = el[0].material.emission.image = el[0].material.roughness.image = -1
+    el[0].vertexes = verts.ctypes.data_as(C.POINTER(ha.Vec3))
+    el[0].num_vertexes = verts.shape[0]
+    el[0].faces = faces.ctypes.data_as(C.POINTER(C.c_uint64))
+    el[0].num_faces = faces.shape[0]
+    d = ha.SceneDesc()
+    C.memmove(C.byref(d), base.desc_ptr, C.sizeof(d))
+    d.elements = C.cast(el, C.POINTER(ha.Element))
+    d.num_elements = 1
+    return d, (base, el, verts, faces)
+
+
+# rays against the unit right triangle (0,0,0) (1,0,0) (0,1,0) (+ a second one behind it and a degenerate one): every number is exact
+# in fp32 and f64, so the triangle test's boundary rules (bvh.rs:266-290) can be checked to the bit.  The rays are slightly tilted
+# (direction (2^-10, 2^-10, -1), not normalised — the triangle test does not care): an axis-parallel ray that runs exactly IN a face
+# of a node's box is a miss in the reference whatever the triangle test says (0 x inf = NaN in its slab test, bvh.rs:20-39), and the
+# triangle's legs lie in faces of its leaf box.
+_D = 2.0 ** -10
+
+
+def _tilted(tx, ty, back=False):
+    """the ray that reaches (tx, ty, 0) at t = 1"""
+    d = np.array([_D, _D, 1.0 if back else -1.0])
+    return list(np.array([tx, ty, 0.0]) - d) + list(d)
+
+
+TRI_EDGE_RAYS = np.array([
+    _tilted(0.25, 0.25),           # 0 interior
+    _tilted(0.5, 0.0),             # 1 on the edge v = 0: accepted (v >= 0)
+    _tilted(0.0, 0.5),             # 2 on the edge u = 0
+    _tilted(0.5, 0.5),             # 3 on the hypotenuse: u + v == 1 is accepted
+    _tilted(0.0, 0.0),             # 4 the vertex v0
+    _tilted(1.0, 0.0),             # 5 the vertex v1 (u == 1)
+    _tilted(0.75, 0.75),           # 6 beyond the hypotenuse: the second triangle, one unit further (t = 2)
+    _tilted(-0.25, 0.5),           # 7 u < 0, and outside the far triangle too
+    _tilted(0.25, 0.25, True),     # 8 from behind: two-sided
+    [0.25, 0.25, 0, _D, _D, -1],   # 9 origin on the triangle: t == 0 is a hit (t >= 0)
+    [0.25, 0.25, 1, _D, _D, 1],    # 10 pointing away: t < 0
+    [-1.0, 0.25, 0.0, 1, _D, 0],   # 11 in the triangle's plane: det == 0 rejects (bvh.rs:271)
+    _tilted(3.0, 3.0),             # 12 over the degenerate triangle only: no hit
+], dtype=np.float32)
+
+
+def _triangle_edge_geometry():
+    verts = [[0, 0, 0], [1, 0, 0], [0, 1, 0],              # the unit right triangle in z = 0
+             [0, 0, -1], [2, 0, -1], [0, 2, -1],            # a larger one in z = -1 behind it
+             [3, 3, 0], [3, 3, 0], [3, 3, 0]]               # a degenerate one (three equal vertices)
+    return verts, [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+
+
+def test_triangle_test_boundary_rules(ha, emu, orc):
+    """Edges, vertices, t == 0, det == 0, a degenerate triangle: the derived-record triangle test (pt_core.h tri_test on TriT) decides
+    exactly as the reference's Cramer's rule (oracle, f64) on geometry whose numbers are exact in both."""
+    import ctypes as C
+    verts, faces = _triangle_edge_geometry()
+    d, keep = _triangle_scene(ha, verts, faces)
+    e = emu.EmuScene(C.addressof(d))
+    o = orc.OracleScene(C.addressof(d))
+    got, gel = e.intersect(TRI_EDGE_RAYS)
+    ref, rel = o.intersect(TRI_EDGE_RAYS.astype(np.float64))
+    assert np.array_equal(got[:, 0], ref[:, 0].astype(np.float32)), (got[:, 0], ref[:, 0])
+    expect_hit = np.array([1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 0, 0, 0], dtype=np.float32)
+    assert np.array_equal(got[:, 0], expect_hit)
+    hit = expect_hit == 1
+    assert np.array_equal(got[hit, 1], ref[hit, 1].astype(np.float32))      # distances: 1, ..., 2 (the far triangle), 1, 0 — exact
+    assert got[6, 1] == 2.0 and got[9, 1] == 0.0
+
+
 @pytest.mark.parametrize("builder", [1, 2])
 def test_lbvh_single_primitive(ha, emu, builder):
     """n = 1: no internal node, the lone leaf is the root."""

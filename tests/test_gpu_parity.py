@@ -161,6 +161,38 @@ def test_production_traversal_closest_hit_matches_oracle(gpu, scenes, name, buil
     assert np.quantile(terr, 0.99) < 2e-5 and terr.max() < 1e-3, (np.quantile(terr, 0.99), terr.max())
 
 
+@pytest.mark.parametrize("builder", [0, 1, 2])
+def test_triangle_test_boundary_rules_on_the_gpu(gpu, ha, orc, builder):
+    """The GPU twin of tests/test_emu_parity.py::test_triangle_test_boundary_rules: edges, vertices, t == 0, det == 0 and a degenerate
+    triangle through the render kernel's traversal (hr_debug_trace) and the scalar walk (hr_debug_intersect), for every builder — the
+    same decisions and the same distances, to the bit, as the reference's Cramer's rule (oracle, f64) on geometry whose numbers are
+    exact in both (bvh.rs:266-290)."""
+    import ctypes as C
+    from test_emu_parity import TRI_EDGE_RAYS, _triangle_edge_geometry, _triangle_scene
+    verts, faces = _triangle_edge_geometry()
+    d, keep = _triangle_scene(ha, verts, faces)
+
+    class Holder:
+        pass
+    h = Holder()
+    h.desc_ptr = C.pointer(d)
+    h.keep = keep
+    o = orc.OracleScene(C.addressof(d))
+    ref, rel = o.intersect(TRI_EDGE_RAYS.astype(np.float64))
+    gpu.set_option("bvh_builder", builder)
+    try:
+        gpu.upload_scene(h)
+        got, gel = gpu.debug_trace(TRI_EDGE_RAYS)
+        scalar, sel = gpu.debug_intersect(TRI_EDGE_RAYS)
+    finally:
+        gpu.set_option("bvh_builder", 0)
+    assert np.array_equal(got.view(np.uint32), scalar.view(np.uint32)) and np.array_equal(gel, sel)
+    assert np.array_equal(got[:, 0], ref[:, 0].astype(np.float32)), (got[:, 0], ref[:, 0])
+    assert np.array_equal(got[:, 0], np.array([1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 0, 0, 0], dtype=np.float32))
+    hit = ref[:, 0] == 1
+    assert np.array_equal(got[hit, 1], ref[hit, 1].astype(np.float32)), (got[hit, 1], ref[hit, 1])
+
+
 @pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_v2", "tbf3"])
 def test_production_traversal_shadow_rays_match_oracle(gpu, scenes, name):
     """Shadow rays through the render kernel's traversal WITH its two exact work savers (search limited to the sample distance
