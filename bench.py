@@ -322,7 +322,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
-                "bvh_builder": builder, "bvh_build_ms": round(st["bvh_build_ms"], 4)}
+                "bvh_builder": builder, "bvh_build_ms": round(st["bvh_build_ms"], 4),
+                "priority_governor": {"level": int(st["governor_level"]), "launches_judged": int(st["governor_decisions"]), "moves": int(st["governor_moves"]),
+                                      "note": "which kernel's waves come first (0 = the seed kernel's producer waves .. 4 = the trace kernel's box and leaf phases), decided on the device from the kernels' own time stamps, launch by launch"}}
 
         def loaded_bytes(c):   # what the lanes request for the tests they perform (device_scene.h record sizes)
             return node_b * c["node_tests"] + 48 * c["tri_tests"] + 16 * c["sphere_tests"] + 32 * c["cuboid_tests"]

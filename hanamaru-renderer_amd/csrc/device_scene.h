@@ -184,6 +184,24 @@ struct Scene {
     CameraF cam;
 };
 
+// The priority governor's state, in device memory (hr_api.hip governor_kernel): the two kernels of a launch stamp their
+// first start and last end here, a one-thread kernel behind every trace kernel turns the stamps of the launch that has just finished into
+// the level the NEXT kernels start at, and the kernels read that level when they start — a launch is enqueued many launches before it
+// runs, so what the host could put into its arguments would be decided far too early.
+struct GovDev {
+    unsigned long long t0[2][2], t1[2][2];   // [0 seed | 1 trace][slot = launch parity]: min of the starts / max of the ends (s_memrealtime ticks)
+    unsigned long long prev_t0, prev_t1;     // the trace kernel of the launch before (what this launch's seed kernel ran beside)
+    uint32_t lvl[2][2];                      // the level each of the four kernels read
+    int32_t level;                           // what kernels that start now run at (0 .. 4, hr_api.hip GOV_LEVELS)
+    int32_t fixed;                           // >= 0: option trace_boost pins the level
+    float known[5];                          // smoothed max(seed, trace) ticks per level, 0 = not tried yet
+    uint32_t decisions, moves;               // launches the governor judged / times it changed the level
+};
+// the trace kernel's priority mask of a level (bits 0-3: which of every four box phases run at priority 1, bit 4: the leaf phase too)
+HD uint32_t gov_trace_mask(int32_t level) { return level >= 4 ? 0x1fu : level == 3 ? 0xfu : 0u; }
+// the seed kernel's producer priorities of a level: bits 0-1 even groups, bits 2-3 odd groups
+HD uint32_t gov_producer_prio(int32_t level, uint32_t init_prio) { return level <= 0 ? (init_prio | init_prio << 2) : level == 1 ? init_prio : 0u; }
+
 // One render launch covers `num_k` samplings (sampling_begin + k*stride) of the whole image.
 struct RenderParams {
     uint32_t width, height;
@@ -191,12 +209,14 @@ struct RenderParams {
     uint32_t sampling_begin, stride, num_k;
     uint32_t adv_den;                 // trace kernel: leave the traversal loop when 1/adv_den of the live lanes are done
     uint32_t leaf_den;                // trace kernel: run the leaf phase when 1/leaf_den of the traversing lanes parked a leaf
-    uint32_t pad[3];                  // seed kernel: [0] s_setprio of the consumer waves, [1] of the producer waves, [2] debug_skip bits
-    uint32_t trace_boost;             // trace kernel: 1 = its box phase, 2 = box and leaf phases run at priority 1, above the seed kernel's producer waves (hr_api.hip sets it from measured kernel times)
+    uint32_t pad[3];                  // seed kernel: [0] s_setprio of the consumer waves, [1] of the producer waves at level 0 (with gov == nullptr: the packed even | odd priorities themselves), [2] debug_skip bits
+    uint32_t trace_boost;             // trace kernel, gov == nullptr only: its priority mask (gov_trace_mask)
     uint32_t node_unroll;             // trace kernel: node fetches per pass of the box-phase loop (1 or 2)
     uint32_t kchunk;                  // trace kernel: samplings per work unit (0 = 4)
     uint32_t ovf_cap;                 // seed kernels: entries of each consumer wave's fix-up list (sized per launch by hr_api.hip)
     uint32_t rr_start;                // trace kernel: Russian roulette from this iteration on (0 = off, the default: the reference has none)
+    uint32_t gov_slot;                // parity of the launch: which slot of gov-> its two kernels stamp
+    GovDev *gov;                      // nullptr: no governor (debug kernels, host emulation) — trace_boost / pad[1] as given
 };
 
 // lane j of tile `tile` -> pixel and sub-sample (tile = 4x4 pixels x 4 sub-samples = 64 paths per sampling)

@@ -54,7 +54,7 @@ static int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------------------------------ context
 
-struct EventPair { hipEvent_t a, b; int level; };   // level: the trace_boost level the launch ran at (priority governor)
+struct EventPair { hipEvent_t a, b; };
 
 struct hr_ctx {
     int device = 0;
@@ -99,10 +99,8 @@ struct hr_ctx {
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
-    int trace_boost = -1;                    // trace-kernel phases above the producer waves: -1 = governed by the measured kernel times (default), 0 .. 4 = fixed level (GOV_MASK)
-    int boost_now = 0;                       // the governor's current level (it starts at "seed kernel first": see govern_reset)
-    float gov_known[5] = {0, 0, 0, 0, 0};    // per level: smoothed max(seed, trace) ms of the launches measured at it (0 = not tried on this scene / size)
-    size_t gov_next = 0;                     // first launch (index into seed_events / trace_events) the governor has not looked at
+    int trace_boost = -1;                    // which kernel's waves come first: -1 = governed on the device from the kernels' own time stamps (default), 0 .. 4 = fixed level
+    GovDev *gov = nullptr;                   // the governor's state (device memory; device_scene.h)
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by more than 7 %), 0 = off, > 0 = ratio
@@ -140,50 +138,77 @@ static int upload(hr_ctx *c, const std::vector<T> &v, const T **out) {
     *out = reinterpret_cast<const T *>(d);
     return HR_OK;
 }
-// Priority governor (see hr_render).  Five levels, from the seed kernel's producer waves first to the trace kernel's box and leaf phases first.
-// A finished launch says how long the slower of the two kernels took at the current level; an untried neighbouring level is tried
-// when the balance asks for it (trace kernel more than 1.5 % behind -> up, seed kernel -> down), otherwise the best level known wins.
-// `level` is the level the measured launch RAN at (the host enqueues several launches ahead of the GPU, so it is not
-// necessarily the current one): its time is credited to that level, and only a launch that ran at the current level may move it.
-// Levels, from "the seed kernel's producer waves first" to "the trace kernel first":
+// Priority governor.  All waves run at priority 0 except the seed kernel's consumer waves (3); which of the REST comes first decides which
+// of the two kernels is the slower one.  Five levels, from "the seed kernel's producer waves first" to "the trace kernel first":
 //   0  producers at init_prio (1), trace kernel at 0          3  producers at 0, the trace kernel's box phases at 1
 //   1  producers alternate between init_prio and 0 per group   4  ... box and leaf phases at 1
 //   2  producers at 0, trace kernel at 0
-// RenderParams::trace_boost carries the trace kernel's mask (bits 0-3: the box phases of a period of four, bit 4: the leaf phase),
-// pad[1] the producers' priority for even (bits 0-1) and odd (bits 2-3) groups.
+// The decision is taken ON THE DEVICE: a launch is enqueued many launches before it runs (hr_render never blocks), so a level put into
+// its arguments by the host would be decided from measurements that are tens of launches old — or, inside one long hr_render call,
+// never.  Both kernels stamp their first start and last end into GovDev (s_memrealtime), this one-thread kernel runs behind every trace
+// kernel (in the gap in which the trace stream waits for the next seed kernel anyway), and kernels read GovDev::level when they start.
+// A launch counts if its seed kernel ran beside the trace kernel of the launch before and its trace kernel beside the seed kernel of
+// the launch after (the first and last launches of a burst do not).  An untried neighbouring level is tried when the balance asks for
+// it (one kernel more than 1.5 % behind the other), otherwise the level with the best smoothed max(seed, trace) wins.
 static const int GOV_LEVELS = 5;
-static const uint32_t GOV_MASK[GOV_LEVELS] = {0x0u, 0x0u, 0x0u, 0xfu, 0x1fu};
-static void govern(hr_ctx *c, float seed_ms, float trace_ms, int level) {
-    if (c->trace_boost >= 0 || !(seed_ms > 0) || !(trace_ms > 0) || level < 0 || level >= GOV_LEVELS) return;
-    const int L = level;
-    const float m = std::max(seed_ms, trace_ms);
-    c->gov_known[L] = c->gov_known[L] > 0 ? 0.5f * (c->gov_known[L] + m) : m;
-    if (L != c->boost_now) return;   // a launch issued before the last change of level: noted, nothing decided from it
-    if (trace_ms > 1.015f * seed_ms && L < GOV_LEVELS - 1 && c->gov_known[L + 1] == 0) { c->boost_now = L + 1; return; }
-    if (seed_ms > 1.015f * trace_ms && L > 0 && c->gov_known[L - 1] == 0) { c->boost_now = L - 1; return; }
-    int best = L;
-    for (int k = 0; k < GOV_LEVELS; k++)
-        if (c->gov_known[k] > 0 && c->gov_known[k] < 0.995f * c->gov_known[best]) best = k;
-    c->boost_now = best;
+__global__ void governor_kernel(GovDev *g, uint32_t slot) {
+    typedef unsigned long long u64t;
+    const uint32_t other = slot ^ 1u;
+    const u64t none = ~0ull;
+    const u64t s0 = g->t0[0][slot], s1 = g->t1[0][slot], r0 = g->t0[1][slot], r1 = g->t1[1][slot];
+    const bool have = s0 != none && s1 > s0 && r0 != none && r1 > r0;
+    if (have && g->fixed < 0) {
+        const u64t p0 = g->prev_t0, p1 = g->prev_t1;
+        const u64t n0 = g->t0[0][other], n1 = g->t1[0][other];     // the next launch's seed kernel: running (n1 not final) or done
+        float ov_seed = 0.0f, ov_trace = 0.0f;
+        if (p1 > p0) {
+            const u64t lo = p0 > s0 ? p0 : s0, hi = p1 < s1 ? p1 : s1;
+            if (hi > lo) ov_seed = (float)(hi - lo) / (float)(s1 - s0);
+        }
+        if (n0 != none && n0 < r1) {
+            const u64t lo = n0 > r0 ? n0 : r0, hi = (n1 > n0 && n1 < r1) ? n1 : r1;
+            if (hi > lo) ov_trace = (float)(hi - lo) / (float)(r1 - r0);
+        }
+        const int L = (int)g->lvl[0][slot];
+        if (ov_seed > 0.7f && ov_trace > 0.7f && L == (int)g->lvl[1][slot] && L >= 0 && L < GOV_LEVELS) {
+            const float seed_t = (float)(s1 - s0), trace_t = (float)(r1 - r0), m = seed_t > trace_t ? seed_t : trace_t;
+            g->known[L] = g->known[L] > 0 ? 0.5f * (g->known[L] + m) : m;
+            g->decisions++;
+            if (L == g->level) {   // (a launch that started before the last change of level: noted, nothing decided from it)
+                int next = L;
+                if (trace_t > 1.015f * seed_t && L < GOV_LEVELS - 1 && g->known[L + 1] == 0) next = L + 1;
+                else if (seed_t > 1.015f * trace_t && L > 0 && g->known[L - 1] == 0) next = L - 1;
+                else
+                    for (int k = 0; k < GOV_LEVELS; k++)
+                        if (g->known[k] > 0 && g->known[k] < 0.995f * g->known[next]) next = k;
+                if (next != L) { g->moves++; __hip_atomic_store(&g->level, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+        }
+    }
+    if (r0 != none && r1 > r0) { g->prev_t0 = r0; g->prev_t1 = r1; }
+    for (int k = 0; k < 2; k++) { g->t0[k][slot] = none; g->t1[k][slot] = 0; }
+    if (g->fixed >= 0) __hip_atomic_store(&g->level, g->fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a new scene, resolution or option: the balance of the two kernels is another one.  The governor starts at level 0 — next to a trace
+// kernel that needs 16 ms per 33 M paths on the reference's scenes the seed kernel (24 ms) is the slower one almost everywhere.
+// (Callers have synchronised the context: no kernel is stamping.)
+static int govern_reset(hr_ctx *c) {
+    if (!c->gov) return HR_OK;
+    GovDev h;
+    memset(&h, 0, sizeof h);
+    for (int k = 0; k < 2; k++)
+        for (int sl = 0; sl < 2; sl++) h.t0[k][sl] = ~0ull;
+    h.fixed = c->trace_boost;
+    h.level = c->trace_boost >= 0 ? c->trace_boost : 0;
+    HIP_TRY(hipMemcpy(c->gov, &h, sizeof h, hipMemcpyHostToDevice));
+    return HR_OK;
 }
 // the accumulator of `c` is about to change: totals that include it are stale — its own and, in a same-device group, its peers'
 static void invalidate_totals(hr_ctx *c) {
     c->total_valid = false;
     for (hr_ctx *p : c->same_device_peers) p->total_valid = false;
 }
-// The governor starts at level 0: next to a trace kernel that needs 16 ms per 33 M paths on the reference's scenes the seed kernel (24 ms)
-// is the slower one almost everywhere, and the host enqueues launches far ahead of the GPU — the governor gets to see finished launches
-// only where the host waits for the device anyway, so it climbs one level per synchronisation point at most.
-static void govern_reset(hr_ctx *c) { for (float &g : c->gov_known) g = 0; if (c->trace_boost < 0) c->boost_now = 0; }
 static int drain_events(hr_ctx *c) {
-    {   // the lists about to be emptied still have something to tell the governor: the launch before the last one (the last trace
-        // kernel had the chip to itself, the first seed kernel too)
-        const size_t n = std::min(c->seed_events.size(), c->trace_events.size());
-        float sm = 0, tm = 0;
-        if (n >= 3 && n - 2 >= c->gov_next && hipEventElapsedTime(&sm, c->seed_events[n - 2].a, c->seed_events[n - 2].b) == hipSuccess &&
-            hipEventElapsedTime(&tm, c->trace_events[n - 2].a, c->trace_events[n - 2].b) == hipSuccess)
-            govern(c, sm, tm, c->trace_events[n - 2].level);
-    }
     auto sum = [](std::vector<EventPair> &ev, double &acc) -> hipError_t {
         for (auto &e : ev) {
             float ms = 0;
@@ -200,7 +225,6 @@ static int drain_events(hr_ctx *c) {
     HIP_TRY(sum(c->trace_events, c->trace_ms));
     HIP_TRY(sum(c->post_events, c->post_ms));
     HIP_TRY(sum(c->debug_events, c->debug_ms));
-    c->gov_next = 0;
     return HR_OK;
 }
 // Long renders: retire the event pairs of launches that have finished (both kernels), oldest first, without waiting for anything —
@@ -209,7 +233,7 @@ static void retire_finished_launches(hr_ctx *c) {
     size_t n = 0;
     const size_t limit = std::min(c->seed_events.size(), c->trace_events.size());
     while (n < limit && hipEventQuery(c->seed_events[n].b) == hipSuccess && hipEventQuery(c->trace_events[n].b) == hipSuccess) n++;
-    if (n > 2) n -= 2; else return;   // the newest finished launches stay: the governor may not have looked at them yet
+    if (n > 2) n -= 2; else return;
     for (size_t i = 0; i < n; i++) {
         float sm = 0, tm = 0;
         if (hipEventElapsedTime(&sm, c->seed_events[i].a, c->seed_events[i].b) == hipSuccess) c->seed_ms += sm;
@@ -219,7 +243,6 @@ static void retire_finished_launches(hr_ctx *c) {
     }
     c->seed_events.erase(c->seed_events.begin(), c->seed_events.begin() + (long)n);
     c->trace_events.erase(c->trace_events.begin(), c->trace_events.begin() + (long)n);
-    c->gov_next = c->gov_next > n ? c->gov_next - n : 0;
 }
 static int sync_all(hr_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->seed_stream));
@@ -269,6 +292,8 @@ static int create_resources(hr_ctx *c) {
     HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(Counters)));
     HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
     HIP_TRY(hipMalloc((void **)&c->d_tile_counter, 2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&c->gov, sizeof(GovDev)));
+    { int grc = govern_reset(c); if (grc) return grc; }
     HIP_TRY(hipFuncSetAttribute((const void *)seed_isaac64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
 HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
@@ -322,6 +347,7 @@ int hr_destroy(hr_ctx *c) {
     if (c->ovf_win) (void)hipFree(c->ovf_win);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->gov) (void)hipFree(c->gov);
     if (c->post_tmp) (void)hipFree(c->post_tmp);
     if (c->d_rgb8) (void)hipFree(c->d_rgb8);
     if (c->accum_total) (void)hipFree(c->accum_total);
@@ -572,7 +598,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     }
     c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
     c->have_scene = true;
-    govern_reset(c);   // another scene: the balance of the two kernels is another one
+    if ((r = govern_reset(c))) return r;   // another scene: the balance of the two kernels is another one
     return HR_OK;
 }
 
@@ -596,8 +622,7 @@ int hr_set_resolution(hr_ctx *c, uint32_t w, uint32_t h) {
     HIP_TRY(hipMalloc((void **)&c->d_rgb8, n));
     c->W = w; c->H = h;
     c->accum = c->accum_own;
-    govern_reset(c);
-    return HR_OK;
+    return govern_reset(c);
 }
 
 int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
@@ -672,7 +697,7 @@ static int ensure_ovf(hr_ctx *c, uint64_t paths_per_launch) {
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
-    EventPair ev{nullptr, nullptr, c->boost_now};
+    EventPair ev{nullptr, nullptr};
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, st));
@@ -750,24 +775,10 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         rp.num_k = nk;
         int slot = (int)(c->batch_counter & 1);
         c->batch_counter++;
-        // Priority governor: the two kernels share every SIMD, and which of them should win the issue slots of the producers'
-        // SIMDs depends on which is the slower one on this scene.  Look at the newest launch whose seed and trace kernel have both
-        // finished and lean towards the slower kernel (3 % hysteresis).  Results do not depend on it.
-        if (c->trace_boost < 0) {
-            const size_t n = std::min(c->seed_events.size(), c->trace_events.size());
-            if (c->gov_next > n) c->gov_next = 0;   // the lists were drained
-            for (size_t j = n > 0 ? n - 1 : 0; j-- > c->gov_next;) {   // not the newest launch: its trace kernel may have run alone
-                if (hipEventQuery(c->seed_events[j].b) != hipSuccess || hipEventQuery(c->trace_events[j].b) != hipSuccess) continue;
-                float sm = 0, tm = 0;
-                if (hipEventElapsedTime(&sm, c->seed_events[j].a, c->seed_events[j].b) == hipSuccess &&
-                    hipEventElapsedTime(&tm, c->trace_events[j].a, c->trace_events[j].b) == hipSuccess)
-                    govern(c, sm, tm, c->trace_events[j].level);
-                c->gov_next = j + 1;
-                break;
-            }
-        } else c->boost_now = c->trace_boost;
-        rp.trace_boost = GOV_MASK[c->boost_now];
-        rp.pad[1] = c->boost_now == 0 ? (c->init_prio | c->init_prio << 2) : c->boost_now == 1 ? c->init_prio : 0u;   // the producer waves' priority: even | odd groups
+        // the priority governor lives on the device (governor_kernel above): the kernels read its level when they start
+        rp.gov = c->gov; rp.gov_slot = (uint32_t)slot;
+        rp.trace_boost = 0;
+        rp.pad[1] = c->init_prio;   // the producer waves' priority at level 0
         hipStream_t sstream = c->seed_stream;  // (alternating two seed streams to overlap kernel tails was measured: no gain)
         // seed of this batch may only overwrite draws[slot] once the trace that read it has finished
         if (c->trace_pending[slot]) HIP_TRY(hipStreamWaitEvent(sstream, c->trace_done[slot], 0));
@@ -775,7 +786,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(c->seed_done[slot], sstream));
         c->seed_pending[slot] = true;
         HIP_TRY(hipStreamWaitEvent(c->stream, c->seed_done[slot], 0));
-        EventPair ev{nullptr, nullptr, c->boost_now};
+        EventPair ev{nullptr, nullptr};
         HIP_TRY(hipEventCreate(&ev.a));
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, c->stream));
@@ -807,6 +818,10 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(ev.b, c->stream));
         c->trace_events.push_back(ev);
         c->trace_launches++;
+        // the governor judges the launch that has just finished and frees its stamps; the seed kernel that reuses the slot waits for
+        // trace_done, recorded behind it
+        hipLaunchKernelGGL(governor_kernel, dim3(1), dim3(1), 0, c->stream, c->gov, (uint32_t)slot);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->trace_done[slot], c->stream));
         c->trace_pending[slot] = true;
         c->paths_rendered += (uint64_t)c->W * c->H * 4 * nk;
@@ -828,7 +843,7 @@ int hr_render_debug(hr_ctx *c, int mode) {
     rp.width = c->W; rp.height = c->H;
     rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
     rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll;
-    EventPair ev{nullptr, nullptr, -1};
+    EventPair ev{nullptr, nullptr};
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, c->stream));
@@ -909,7 +924,7 @@ int hr_resolve(hr_ctx *c, uint32_t samplings, uint8_t *host_rgb8) {
     if (rc) return rc;
     uint32_t n = c->W * c->H;
     float scale = 1.0f / (float)(samplings * 4u);
-    EventPair ev{nullptr, nullptr, -1};
+    EventPair ev{nullptr, nullptr};
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventRecord(ev.a, c->stream));
@@ -1063,6 +1078,11 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
     out->bvh_build_ms = c->bvh_build_ms;
     out->debug_kernel_ms = c->debug_ms; out->debug_launches = c->debug_launches;
+    {
+        GovDev g;
+        HIP_TRY(hipMemcpy(&g, c->gov, sizeof g, hipMemcpyDeviceToHost));
+        out->governor_level = (uint64_t)(g.level < 0 ? 0 : g.level); out->governor_decisions = g.decisions; out->governor_moves = g.moves;
+    }
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
     for (int i = 0; i < 4; i++) out->phase_cycles[i] = h.phase_cycles[i];
@@ -1085,9 +1105,10 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
     }
     if (k == "trace_boost") {
         if (value != -1 && !(value >= 0 && value <= 4 && value == (int)value)) return fail(HR_ERR_INVALID, "trace_boost must be -1 (governed by the measured kernel times) or a level 0 .. 4");
+        int rc = sync_all(c);
+        if (rc) return rc;
         c->trace_boost = (int)value;
-        govern_reset(c);
-        return HR_OK;
+        return govern_reset(c);
     }
     if (k == "quant_nodes") { c->quant_nodes = value != 0.0; return HR_OK; }
     if (k == "max_tail_gib") {

@@ -19,6 +19,20 @@ __device__ __forceinline__ u64 lds_load64(uint32_t a) { return *(const __attribu
 // One generator per LDS bank column: mem[i][col], SEED_COLS columns per workgroup.
 static const int SEED_COLS = 80;               // 80 x 2 KiB = 160 KiB = the whole LDS of a CU
 static const int SEED_WAVES = 2, SEED_LANES = SEED_COLS / SEED_WAVES;   // 2 waves x 40 active lanes
+// the priority governor's view of a seed kernel (device_scene.h GovDev): one wave per workgroup stamps the start and the end; the producer
+// waves' priorities (bits 0-1 even groups, bits 2-3 odd groups) follow from the level in force when the workgroup starts
+__device__ __forceinline__ uint32_t seed_gov_begin(const RenderParams &rp, bool stamp) {
+    if (!rp.gov) return rp.pad[1];
+    const int32_t lvl = __hip_atomic_load(&rp.gov->level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp) {
+        atomicMin(&rp.gov->t0[0][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        if (blockIdx.x == 0) rp.gov->lvl[0][rp.gov_slot] = (uint32_t)lvl;
+    }
+    return gov_producer_prio(lvl, rp.pad[1] & 3u);
+}
+__device__ __forceinline__ void seed_gov_end(const RenderParams &rp, bool stamp) {
+    if (rp.gov && stamp) atomicMax(&rp.gov->t1[0][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
 struct LdsMem {
     u64 *col;  // &mem[0][col]
     __device__ __forceinline__ u64 ld(int i) const { return col[i * SEED_COLS]; }
@@ -375,7 +389,8 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
     const bool consumer = wave < 2u;
-    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1] & 3u;
+    const uint32_t pprio = consumer ? 0u : seed_gov_begin(rp, wave == 2u && lane == 0u);   // the producers' priorities (even | odd groups) at the governor's level
+    const uint32_t prio = consumer ? rp.pad[0] : pprio & 3u;
     switch (prio) {  // s_setprio takes an immediate
         case 0: break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -389,7 +404,10 @@ __global__ __launch_bounds__(256) void seed_pc_kernel(RenderParams rp, int lens_
     r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
     r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
     if (consumer) seed_pc_consumer<SEED_SPLIT, PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
-    else seed_pc_producer<SEED_SPLIT>(rp, r, smem, lane, half);
+    else {
+        seed_pc_producer<SEED_SPLIT>(rp, r, smem, lane, half);
+        seed_gov_end(rp, wave == 2u && lane == 0u);
+    }
 }
 
 // ---- three-run seeding (the default; debug option seed_mode = 2) ---------------------------------------------------------------------------------
@@ -501,7 +519,7 @@ __device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int le
     const bool lane_on = lane < (uint32_t)SEED_LANES;
     seed_fixup_wave(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
 }
-__device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half) {
+__device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half, const uint32_t pprio) {
     const IsaacWarm warm = isaac_warm();
     const SegLane sl = seg_lane(false, lane);
     SegRegs regs;
@@ -539,10 +557,10 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
         regs.run(lds_half, sl);          // the window
         __syncthreads();   // B
         if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);   // for the next window; complete in the ring since the last barrier A
-        // the ahead pass's priority may alternate between groups (rp.pad[1] bits 2-3: the priority of the odd groups): the host's
-        // priority governor balances the two kernels with it, and the balance point usually lies between two whole levels
-        if (((rp.pad[1] >> 2) & 3u) != (rp.pad[1] & 3u)) {
-            const uint32_t pr = (it & 1u) ? (rp.pad[1] >> 2) & 3u : rp.pad[1] & 3u;
+        // the ahead pass's priority may alternate between groups (pprio bits 2-3: the priority of the odd groups): the priority
+        // governor balances the two kernels with it, and the balance point usually lies between two whole levels
+        if (((pprio >> 2) & 3u) != (pprio & 3u)) {
+            const uint32_t pr = (it & 1u) ? (pprio >> 2) & 3u : pprio & 3u;
             if (pr == 0u) __builtin_amdgcn_s_setprio(0); else if (pr == 1u) __builtin_amdgcn_s_setprio(1); else if (pr == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
         }
         ahead(r.G0 + it + 2);
@@ -555,7 +573,8 @@ __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
     const bool consumer = wave < 2u;
-    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1] & 3u;
+    const uint32_t pprio = consumer ? 0u : seed_gov_begin(rp, wave == 2u && lane == 0u);   // the producers' priorities (even | odd groups) at the governor's level
+    const uint32_t prio = consumer ? rp.pad[0] : pprio & 3u;
     switch (prio) {  // s_setprio takes an immediate
         case 0: break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -569,7 +588,10 @@ __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens
     r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
     r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
     if (consumer) seed_seg_consumer<PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
-    else seed_seg_producer(rp, r, smem, lane, half);
+    else {
+        seed_seg_producer(rp, r, smem, lane, half, pprio);
+        seed_gov_end(rp, wave == 2u && lane == 0u);
+    }
 }
 
 // ---- phase-shifted four-run seeding (debug option seed_mode = 3) ----------------------------------------------------------------------------------
@@ -765,7 +787,8 @@ __global__ __launch_bounds__(256) void seed_ps_kernel(RenderParams rp, int lens_
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = wave & 1u;
     const bool consumer = wave < 2u;
-    const uint32_t prio = consumer ? rp.pad[0] : rp.pad[1] & 3u;
+    const uint32_t pprio = consumer ? 0u : seed_gov_begin(rp, wave == 2u && lane == 0u);   // the producers' priorities (even | odd groups) at the governor's level
+    const uint32_t prio = consumer ? rp.pad[0] : pprio & 3u;
     switch (prio) {  // s_setprio takes an immediate
         case 0: break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -779,7 +802,10 @@ __global__ __launch_bounds__(256) void seed_ps_kernel(RenderParams rp, int lens_
     r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
     r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
     if (consumer) seed_ps_consumer<PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
-    else seed_ps_producer<PROF>(rp, r, smem, lane, half, cnt);
+    else {
+        seed_ps_producer<PROF>(rp, r, smem, lane, half, cnt);
+        seed_gov_end(rp, wave == 2u && lane == 0u);
+    }
 }
 
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p

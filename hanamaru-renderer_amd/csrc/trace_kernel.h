@@ -40,7 +40,7 @@ struct WaveStats {
 // per-ray constants in registers.
 template <bool CNT, bool QN>
 __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParams &rp, Path &p, const bool active, const uint32_t n_active, const uint32_t adv_den,
-                                              const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws, uint32_t &tick) {
+                                              const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws, uint32_t &tick, const uint32_t boost_mask) {
     for (;;) {
         const bool trav = active && !trace_done(p.ts);
         const uint32_t n_trav = (uint32_t)__popcll(wave_ballot(trav));
@@ -55,7 +55,7 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
         // and costs ~1 % when the seed kernel is.  rp.trace_boost bits 0-3: which of every four box phases of a wave run boosted (a duty
         // cycle of 0, 1/4, 1/2, 3/4 or 1: the balance point of the two kernels usually lies between "never" and "always"); bit 4 adds the
         // leaf phase (another +1 - 2 % where the trace kernel is far behind).
-        const bool boost_box = (rp.trace_boost >> (tick & 3u)) & 1u;
+        const bool boost_box = (boost_mask >> (tick & 3u)) & 1u;
         tick++;
         if (boost_box) __builtin_amdgcn_s_setprio(1);
         // a lane may keep walking with ONE leaf parked (trace_node<SPEC>); it stops at the second.  The loop is written with its
@@ -80,7 +80,7 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
         if (boost_box) __builtin_amdgcn_s_setprio(0);
         HR_PHASE_END(ws, 2);
         HR_PHASE_BEGIN(ws);
-        if (rp.trace_boost & 16u) __builtin_amdgcn_s_setprio(1);   // top level: the leaf phase too
+        if (boost_mask & 16u) __builtin_amdgcn_s_setprio(1);   // top level: the leaf phase too
         if (CNT) {
             uint32_t n = (uint32_t)__popcll(wave_ballot(trav && p.ts.leaf != 0));
             if (n) { ws.ph[4]++; ws.ph[5] += n; }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
             trace_leaf_next<CNT>(sc, p.ray, p.ts, &lc);   // the older parked leaf; the newer one (if any) moves up
             shadow_early_out(p);
         }
-        if (rp.trace_boost & 16u) __builtin_amdgcn_s_setprio(0);
+        if (boost_mask & 16u) __builtin_amdgcn_s_setprio(0);
         HR_PHASE_END(ws, 3);
     }
 }
@@ -136,6 +136,17 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
     uint32_t tick = threadIdx.x >> 6;   // wave-uniform count of box phases (the boost's duty cycle); the waves of a workgroup start out of step
+    // the priority governor (device_scene.h GovDev): this kernel's level is the one in force when the wave starts; the first wave to
+    // start and the last to finish give the kernel's time
+    uint32_t boost_mask = rp.trace_boost;
+    if (rp.gov) {
+        const int32_t lvl = __hip_atomic_load(&rp.gov->level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        boost_mask = gov_trace_mask(lvl);
+        if (lane == 0) {
+            atomicMin(&rp.gov->t0[1][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+            if (blockIdx.x == 0 && threadIdx.x == 0) rp.gov->lvl[1][rp.gov_slot] = (uint32_t)lvl;
+        }
+    }
 
     for (;;) {
         // ---- A: lanes whose ray is complete: shade / NEE / next ray (or the path ends)
@@ -202,9 +213,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
             continue;
         }
         // ---- C: traversal
-        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, adv_den, leaf_den, lc, ws, tick);
+        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, adv_den, leaf_den, lc, ws, tick, boost_mask);
     }
     flush_counters<CNT>(cnt, lane, npaths, lc, ws);
+    if (rp.gov && lane == 0) atomicMax(&rp.gov->t1[1][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // hr_debug_trace: closest-hit / shadow queries through the PRODUCTION traversal — traverse_wave on the record format the renderer
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams 
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     uint32_t tick = 0;
-    traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws, tick);
+    traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws, tick, rp.trace_boost);
     if (!active) return;
     float *o = out + (size_t)i * 8;
     int32_t elem = -1;
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
     uint32_t tick = 0;
-    traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, leaf_den, lc, ws, tick);
+    traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, leaf_den, lc, ws, tick, rp.trace_boost);
     if (CNT && active) lc.rays++;
     V3f val = v3(0, 0, 0), lit = v3(0, 0, 0);
     Ray sh = p.ray;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
         ray_quantise(sc, p.ray);
         trace_begin(p.ts, T_INF, p.ray.start);
         if (!more) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
-        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(wave_ballot(more)), 0u, leaf_den, lc, ws, tick);
+        traverse_wave<CNT, QN>(sc, rp, p, more, (uint32_t)__popcll(wave_ballot(more)), 0u, leaf_den, lc, ws, tick, rp.trace_boost);
         if (CNT && more) lc.rays++;
         if (more) val = val + lit * (p.ts.prim >= 0 ? 0.5f : 1.0f);
     }

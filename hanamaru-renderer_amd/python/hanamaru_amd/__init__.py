@@ -79,7 +79,8 @@ class Stats(C.Structure):
                 ("shade_calls", C.c_uint64), ("shade_lanes", C.c_uint64), ("box_passes", C.c_uint64), ("box_lanes", C.c_uint64),
                 ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
                 ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8),
-                ("debug_kernel_ms", C.c_double), ("debug_launches", C.c_uint64)]
+                ("debug_kernel_ms", C.c_double), ("debug_launches", C.c_uint64),
+                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}

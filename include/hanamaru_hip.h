@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 3
+#define HR_ABI_VERSION 4
 
 typedef enum hr_status {
     HR_OK = 0,
@@ -124,6 +124,9 @@ typedef struct hr_stats {
     uint64_t seed_phase_cycles[8]; /* debug option seed_prof: consumer-wave cycles per phase of the seed kernel, [7] = groups */
     double debug_kernel_ms;    /* sum of HIP-event durations of the hr_render_debug launches (the traversal-only workload) */
     uint64_t debug_launches;
+    /* the priority governor (option trace_boost): the level kernels start at now (0 = the seed kernel's producer waves first .. 4 = the
+     * trace kernel's box and leaf phases first), launches it has judged since the last scene / resolution / option change, level changes */
+    uint64_t governor_level, governor_decisions, governor_moves;
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;
@@ -200,9 +203,10 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* Options that leave the image as the reference computes it (the summation order of the accumulator aside):
  *   "counters"      0 / 1: instrumented build of the trace kernel (fills the counter fields of hr_stats)
  *   "batch"         samplings per launch, 1..64; 0 = automatic (about 33 M paths per launch: 4 at 1080p, up to 64 for small images)
- *   "trace_boost"   -1 = the library balances the two kernels from their measured times (default): five levels from "the seed kernel's
- *                   producer waves above the trace kernel" (0) over "alternating" (1) and "equal" (2) to "the trace kernel's box
- *                   phase (3) and leaf phase (4) above the producer waves"; 0 .. 4 = fixed level
+ *   "trace_boost"   -1 = the two kernels are balanced from their own time stamps, on the device, launch by launch (default): five
+ *                   levels from "the seed kernel's producer waves above the trace kernel" (0) over "alternating" (1) and "equal" (2)
+ *                   to "the trace kernel's box phase (3) and leaf phase (4) above the producer waves"; 0 .. 4 = fixed level
+ *                   (hr_stats.governor_level says where it stands)
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
  *   next hr_upload_scene:

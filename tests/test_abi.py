@@ -20,7 +20,7 @@ def test_hip_library_exports_header(ha):
     lib = C.CDLL(ha.HIP_LIB)
     for n in names:
         assert hasattr(lib, n), "libhanamaru_hip.so lacks %s" % n
-    assert ha.hip_lib().hr_abi_version() == 3
+    assert ha.hip_lib().hr_abi_version() == 4
 
 
 def test_host_library_exports_header(ha):
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(ha):
     assert C.sizeof(ha.Vec3) == 24 and C.sizeof(ha.Texture) == 32 and C.sizeof(ha.Material) == 16 + 3 * 32
     assert C.sizeof(ha.Image) == 16 and C.sizeof(ha.Camera) == 6 * 24 + 24 and C.sizeof(ha.Skybox) == 48
     assert C.sizeof(ha.Element) == 8 + 112 + 32 + 48 + 32
-    assert C.sizeof(ha.Stats) == 38 * 8
+    assert C.sizeof(ha.Stats) == 41 * 8
 
 
 def test_no_device_is_a_clean_error(ha):

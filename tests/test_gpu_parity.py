@@ -524,6 +524,35 @@ def test_priority_governor_does_not_change_results(gpu, scenes):
         assert np.abs(outs[0] - o).max() <= 1e-5 * max(1.0, np.abs(outs[0]).max())
 
 
+def test_priority_governor_decides_on_the_device(gpu, scenes):
+    """The governor lives in device memory (GovDev, governor_kernel): inside ONE hr_render call — the host never waits — it judges the
+    launches as they finish (all but the first and last of the burst, whose kernels ran alone for part of their time), and a fixed
+    level is what the kernels run at."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(1920, 1080)
+    try:
+        gpu.set_option("trace_boost", -1)
+        st0 = gpu.stats()
+        assert st0["governor_decisions"] == 0 and st0["governor_level"] == 0      # a new balance starts at "seed kernel first"
+        gpu.clear()
+        gpu.render(1, 1 + 4 * 24)                                                  # 24 launches of 4 samplings, one call
+        gpu.synchronize()
+        st = gpu.stats()
+        assert st["trace_launches"] == 24                                          # (hr_clear zeroed the launch counters)
+        assert 16 <= st["governor_decisions"] <= 23, st["governor_decisions"]     # not the first, not the last
+        assert 0 <= st["governor_level"] <= 4 and st["governor_moves"] <= st["governor_decisions"]
+        for level in (3, 0):
+            gpu.set_option("trace_boost", level)
+            gpu.clear()
+            gpu.render(1, 9)
+            gpu.synchronize()
+            st = gpu.stats()
+            assert st["governor_level"] == level and st["governor_decisions"] == 0 and st["governor_moves"] == 0
+    finally:
+        gpu.set_option("trace_boost", -1)
+
+
 def _run_bench(extra, env=None, launcher_ranks=0, port=29541):
     import os
     import subprocess
