@@ -381,8 +381,12 @@ def main():
                 "ms_per_launch": round(tms, 4), "Mrays_per_s": round(rays / (tms * 1e-3) / 1e6, 1),
                 "node_tests_per_ray": round(tc["node_tests"] / rays, 2), "tri_tests_per_ray": round(tc["tri_tests"] / rays, 2),
                 "lanes_per_box_pass": round(tc["box_lanes"] / max(1, tc["box_passes"]), 1),
-                "achieved": round(tb / (tms * 1e-3) / 1e9, 1), "frac": round(tb / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frac_l2": round(tb / (tms * 1e-3) / 1e9 / L2_PEAK_GBS, 4),
-                "survey_8d_frac": round(survey_bytes(tc) / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                "achieved": round(tb / (tms * 1e-3) / 1e9, 1), "bound": "l2", "peak": L2_PEAK_GBS, "unit": "GB/s",
+                "frac": round(tb / (tms * 1e-3) / 1e9 / L2_PEAK_GBS, 4),
+                "hbm_normalised": round(tb / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "survey_8d_normalised": round(survey_bytes(tc) / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "coherent camera rays: the CUs' L1 and the L2 serve nearly all of the loaded bytes, so the rate is priced against the aggregate L2 bandwidth; "
+                        "the *_normalised figures divide the same bytes (and SURVEY 8(d)'s) by the HBM peak for comparison with the render kernel's line and are NOT fractions of anything physical (they exceed 1)"}
         # HBM / fabric traffic and instruction counts are PMC measurements (separate rocprofv3 --pmc passes of this same command,
         # tools/prof_pmc.sh, which also writes the JSON read here); per launch like `achieved`
         pmc = latest_pmc_traffic()

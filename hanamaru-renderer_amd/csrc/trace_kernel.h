@@ -50,11 +50,10 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
         const uint32_t walk_max = n_trav - park;
         HR_PHASE_BEGIN(ws);
         // Box phase above the seed kernel's producer waves (which then run at priority 0): their ahead pass is not urgent, a
-        // box pass is the trace kernel's critical loop.  Switched by the host from the measured times of the two kernels
-        // (hr_api.hip, trace_boost): it pays when the trace kernel is the slower of the pair (+3.4 % on the headline scene),
-        // and costs ~1 % when the seed kernel is.  rp.trace_boost bits 0-3: which of every four box phases of a wave run boosted (a duty
-        // cycle of 0, 1/4, 1/2, 3/4 or 1: the balance point of the two kernels usually lies between "never" and "always"); bit 4 adds the
-        // leaf phase (another +1 - 2 % where the trace kernel is far behind).
+        // box pass is the trace kernel's critical loop.  Decided by the priority governor (device_scene.h GovDev, hr_api.hip
+        // governor_kernel) from the two kernels' own time stamps: it pays when the trace kernel is the slower of the pair and costs
+        // ~1 - 3 % when the seed kernel is.  boost_mask bits 0-3: which of every four box phases of a wave run boosted (levels 3 and 4:
+        // all of them); bit 4 adds the leaf phase (another +1 - 2 % where the trace kernel is far behind).
         const bool boost_box = (boost_mask >> (tick & 3u)) & 1u;
         tick++;
         if (boost_box) __builtin_amdgcn_s_setprio(1);
