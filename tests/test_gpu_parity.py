@@ -193,6 +193,37 @@ def test_triangle_test_boundary_rules_on_the_gpu(gpu, ha, orc, builder):
     assert np.array_equal(got[hit, 1], ref[hit, 1].astype(np.float32)), (got[hit, 1], ref[hit, 1])
 
 
+@pytest.mark.parametrize("builder", [0, 2])
+def test_triangle_test_across_scales_on_the_gpu(gpu, ha, orc, builder):
+    """The GPU twin of tests/test_emu_parity.py::test_triangle_test_across_scales: triangles of edge length 1e-3 .. 1e3 up to 1e3 from
+    the origin through the render kernel's traversal — the oracle's hits, distances to a few fp32 roundings of the quantities involved."""
+    import ctypes as C
+    from test_emu_parity import _hit_scale, _scaled_triangle_soup, _triangle_scene
+    verts, faces, rays, expect = _scaled_triangle_soup()
+    d, keep = _triangle_scene(ha, verts, faces)
+
+    class Holder:
+        pass
+    h = Holder()
+    h.desc_ptr = C.pointer(d)
+    h.keep = keep
+    o = orc.OracleScene(C.addressof(d))
+    ref, rel = o.intersect(rays.astype(np.float64))
+    gpu.set_option("bvh_builder", builder)
+    try:
+        gpu.upload_scene(h)
+        got, gel = gpu.debug_trace(rays)
+        scalar, sel = gpu.debug_intersect(rays)
+    finally:
+        gpu.set_option("bvh_builder", 0)
+    assert np.array_equal(got.view(np.uint32), scalar.view(np.uint32)) and np.array_equal(gel, sel)
+    assert np.array_equal(got[:, 0], ref[:, 0].astype(np.float32))
+    hit = ref[:, 0] == 1
+    assert hit[expect].mean() > 0.95 and np.array_equal(gel[hit], rel[hit])
+    terr = np.abs(got[hit, 1] - ref[hit, 1]) / _hit_scale(verts, faces, rays[hit].astype(np.float64), ref[hit, 1])
+    assert terr.max() < 2e-6 and np.quantile(terr, 0.9) < 1e-7, (terr.max(), np.quantile(terr, 0.9))
+
+
 @pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_v2", "tbf3"])
 def test_production_traversal_shadow_rays_match_oracle(gpu, scenes, name):
     """Shadow rays through the render kernel's traversal WITH its two exact work savers (search limited to the sample distance
