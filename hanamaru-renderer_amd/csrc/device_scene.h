@@ -12,6 +12,7 @@
 //   cuboids[]    32 B   min, max                  (+ element id in .w of the first float4)
 //   materials[]  64 B   per element
 //   texels[]      4 B   RGBA8, all images back to back; images[] = {offset, width, height}
+//   sky_quads[]   8 B   the six skybox faces once more, as column pairs: a bilinear footprint is 16 contiguous bytes (Scene::sky_quads below)
 //
 // "Algorithmic bytes"  are counted as 32 B per node test, 36 B per triangle test,
 // 16 B per sphere test, 24 B per cuboid test — the information content, not the padded layout.
@@ -181,6 +182,13 @@ struct Scene {
     uint32_t num_nodes, num_tris, num_spheres, num_cuboids, num_elements, num_emitters;
     int32_t sky_image[6];
     float sky_intensity[3];
+    // The skybox again as bilinear FOOTPRINTS (nullptr when its faces differ in size): [face][iy1 = 0 .. h][x = 0 .. w + 1] x 2 RGBA8 words,
+    // the column pair {(x, iy1), (x, iy2)} as texture.rs:29-49 would fetch it (clamps and the flipped row included) — the four texels
+    // of the footprint of corner (ix1, iy1) are the 16 contiguous bytes of pairs ix1 and ix1 + 1: ONE load instead of an image descriptor
+    // and four scattered texels.  A path ends with a sky lookup in a random direction: 7 % of the trace kernel's time went into
+    // those loads.  2 x the texels (50 MB for six 1024^2 faces).
+    const uint32_t *sky_quads;
+    uint32_t sky_w, sky_h;
     CameraF cam;
 };
 

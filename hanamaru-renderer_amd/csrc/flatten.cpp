@@ -93,6 +93,7 @@ Scene HostScene::view() const {
     d.num_nodes = num_nodes; d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
     d.num_cuboids = (uint32_t)(cuboids.size() / 2); d.num_elements = (uint32_t)materials.size(); d.num_emitters = (uint32_t)emitters.size();
     for (int f = 0; f < 6; f++) d.sky_image[f] = sky_image[f];
+    d.sky_quads = sky_quads.empty() ? nullptr : sky_quads.data(); d.sky_w = sky_w; d.sky_h = sky_h;
     for (int k = 0; k < 3; k++) d.sky_intensity[k] = sky_intensity[k];
     d.cam = cam;
     return d;
@@ -264,6 +265,34 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         out.sky_image[f] = sd->skybox.face_image[f];
     }
     f3(out.sky_intensity, sd->skybox.intensity);
+    {   // the skybox as bilinear footprints (device_scene.h Scene::sky_quads): column pairs {(x, y), (x, y + 1)} for x = 0 .. w + 1, with
+        // exactly the clamps and the flipped row of pt_core.h texel() — texture.rs:29-49 in u32 arithmetic
+        const ImageRef im0 = out.images[out.sky_image[0]];
+        bool same = true;
+        for (int f = 1; f < 6; f++) same = same && out.images[out.sky_image[f]].width == im0.width && out.images[out.sky_image[f]].height == im0.height;
+        out.sky_quads.clear(); out.sky_w = out.sky_h = 0;
+        if (same && (uint64_t)(im0.width + 2) * (im0.height + 1) * 6 * 2 < (1ull << 31)) {
+            const uint32_t w = im0.width, h = im0.height;
+            out.sky_w = w; out.sky_h = h;
+            out.sky_quads.resize((size_t)6 * (h + 1) * (w + 2) * 2);
+            auto row_of = [&](const ImageRef &im, uint32_t y) {   // texel(): the row is flipped (u32 wrap-around and all), then clamped
+                uint32_t yy = im.height - y - 1u;
+                yy = yy > im.height - 1 ? im.height - 1 : yy;
+                return &out.texels[im.offset + (size_t)yy * im.width];
+            };
+            uint32_t *dst = out.sky_quads.data();
+            for (int f = 0; f < 6; f++) {
+                const ImageRef im = out.images[out.sky_image[f]];
+                for (uint32_t y = 0; y <= h; y++) {
+                    const uint32_t *ra = row_of(im, y), *rb = row_of(im, y + 1);
+                    for (uint32_t x = 0; x <= w + 1; x++, dst += 2) {   // column pairs: the footprint of corner x is pairs x and x + 1
+                        const uint32_t xa = x > w - 1 ? w - 1 : x;
+                        dst[0] = ra[xa]; dst[1] = rb[xa];
+                    }
+                }
+            }
+        }
+    }
     const hr_camera &cam = sd->camera;
     memset(&out.cam, 0, sizeof out.cam);
     f3(out.cam.eye, cam.eye); f3(out.cam.right, cam.right); f3(out.cam.up, cam.up); f3(out.cam.forward, cam.forward);

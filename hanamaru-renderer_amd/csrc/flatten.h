@@ -29,6 +29,8 @@ struct HostScene {
     std::vector<uint32_t> texels;
     int32_t sky_image[6];
     float sky_intensity[3];
+    std::vector<uint32_t> sky_quads;   // Scene::sky_quads (empty when the faces differ in size)
+    uint32_t sky_w = 0, sky_h = 0;
     CameraF cam;
     uint32_t bvh_max_depth = 0, bvh_leaves = 0;
     double bvh_sah_cost = 0;

@@ -575,6 +575,8 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.images, &d.images))) return r;
     if ((r = upload(c, hs.emitters, &d.emitters))) return r;
     if ((r = upload(c, hs.texels, &d.texels))) return r;
+    if (!hs.sky_quads.empty()) { if ((r = upload(c, hs.sky_quads, &d.sky_quads))) return r; }
+    else d.sky_quads = nullptr;
     c->bvh_build_ms = 0;
     if (gpu_build) { if ((r = build_bvh_on_device(c, hs, tris_in))) return r; }
     else {

@@ -380,7 +380,26 @@ HD V3f sky_sample(const Scene &sc, V3f d) {  // scene.rs:295-319
         float i = HR_RCP(d.z);
         if (!signbit(d.z)) { face = 4; u = d.x * i; v = d.y * i; } else { face = 5; u = d.x * i; v = -d.y * i; }
     }
-    return v3(sc.sky_intensity) * sample_bilinear(sc, sc.sky_image[face], 0.5f * (u + 1.0f), 0.5f * (v + 1.0f));
+    u = 0.5f * (u + 1.0f); v = 0.5f * (v + 1.0f);
+    if (sc.sky_quads) {
+        // the footprint of sample_bilinear() as one 16-byte load (Scene::sky_quads).  x and y are clamped at 0: |u| <= 1 holds exactly in
+        // the reference's f64, here the approximate reciprocal can leave it by an ulp, and a corner of -1 has another footprint than 0
+        const float x = fmaxf(u * (float)sc.sky_w, 0.0f), y = fmaxf(v * (float)sc.sky_h, 0.0f);
+        const float x1 = floorf(x), y1 = floorf(y), x2 = x1 + 1.0f, y2 = y1 + 1.0f;
+        const uint32_t ix = f32_as_u32_sat(x1), iy = f32_as_u32_sat(y1);
+        const uint32_t cx = ix > sc.sky_w ? sc.sky_w : ix, cy = iy > sc.sky_h ? sc.sky_h : iy;   // (beyond the last corner every texel is the clamped one, as at it)
+        const uint32_t *q = sc.sky_quads + (((size_t)face * (sc.sky_h + 1u) + cy) * (sc.sky_w + 2u) + cx) * 2u;   // column pairs cx and cx + 1
+        struct alignas(8) Quad { uint32_t p11, p12, p21, p22; };
+        const Quad t = *reinterpret_cast<const Quad *>(q);
+        const float k = 1.0f / 255.0f;
+        const V3f p11 = v3((float)(t.p11 & 255u) * k, (float)((t.p11 >> 8) & 255u) * k, (float)((t.p11 >> 16) & 255u) * k);
+        const V3f p12 = v3((float)(t.p12 & 255u) * k, (float)((t.p12 >> 8) & 255u) * k, (float)((t.p12 >> 16) & 255u) * k);
+        const V3f p21 = v3((float)(t.p21 & 255u) * k, (float)((t.p21 >> 8) & 255u) * k, (float)((t.p21 >> 16) & 255u) * k);
+        const V3f p22 = v3((float)(t.p22 & 255u) * k, (float)((t.p22 >> 8) & 255u) * k, (float)((t.p22 >> 16) & 255u) * k);
+        const V3f g = p11 * ((x2 - x) * (y2 - y)) + p21 * ((x - x1) * (y2 - y)) + p12 * ((x2 - x) * (y - y1)) + p22 * ((x - x1) * (y - y1));
+        return v3(sc.sky_intensity) * v3(gamma_to_linear(g.x), gamma_to_linear(g.y), gamma_to_linear(g.z));
+    }
+    return v3(sc.sky_intensity) * sample_bilinear(sc, sc.sky_image[face], u, v);
 }
 
 // ---------------------------------------------------------------------------------------------
