@@ -800,9 +800,9 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
-#define HR_LAUNCH_TRACE(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
+#define HR_LAUNCH_TRACE(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->d_counters, c->d_tile_counter + slot)
             const bool qn = c->dsc.qnodes != nullptr;
-#define HR_LAUNCH_TRACE_RR(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->accum, c->d_counters, c->d_tile_counter + slot)
+#define HR_LAUNCH_TRACE_RR(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->d_counters, c->d_tile_counter + slot)
             if (c->debug_skip & 16) {
             } else if (c->rr_start) {   // the non-parity estimator has its own instantiations (one occupancy variant)
                 if (c->counters) { if (qn) HR_LAUNCH_TRACE_RR(true, 3, true); else HR_LAUNCH_TRACE_RR(true, 3, false); }
@@ -820,6 +820,12 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         HIP_TRY(hipEventRecord(ev.b, c->stream));
         c->trace_events.push_back(ev);
         c->trace_launches++;
+        // the launch's radiance into the accumulator (the trace kernel left every path's in its record), in the gap in which this
+        // stream waits for the next seed kernel anyway
+        if (!(c->debug_skip & 16)) {
+            hipLaunchKernelGGL(accumulate_kernel, dim3((tiles + 3) / 4), dim3(256), 0, c->stream, rp, c->recs[slot], c->accum);
+            HIP_TRY(hipGetLastError());
+        }
         // the governor judges the launch that has just finished and frees its stamps; the seed kernel that reuses the slot waits for
         // trace_done, recorded behind it
         hipLaunchKernelGGL(governor_kernel, dim3(1), dim3(1), 0, c->stream, c->gov, (uint32_t)slot);

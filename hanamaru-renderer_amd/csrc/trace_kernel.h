@@ -115,8 +115,7 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uin
 }
 
 template <bool CNT, int MINW, bool QN, bool RR = false>
-__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, const float *__restrict__ recs,
-                                                                       float *__restrict__ accum, Counters *cnt, uint32_t *tile_counter) {
+__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     LaneCounters lc = {0, 0, 0, 0, 0};
@@ -157,18 +156,13 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         HR_PHASE_BEGIN(ws);
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
             if (path_advance<CNT, RR>(sc, p, recs + (size_t)p.tile * tile_stride, &lc, rp.rr_start, rp.sampling_begin * 64u + rp.stride)) {
-                // The kernel uses no LDS at all (the seed kernel next to it owns all 160 KiB), so a finished
-                // path adds its radiance straight into the accumulator.  A work unit is one tile x up to TRACE_KCHUNK
-                // samplings, so with more than TRACE_KCHUNK samplings per launch several waves — in other workgroups,
-                // on other XCDs — add to the same pixels concurrently: the adds are AGENT-scope atomics (device-wide
-                // at the memory side; the same global_atomic_add_f32 instruction on gfx950, so no cost).  Only the
-                // fp32 summation order per pixel varies between runs.
-                uint32_t pix = (p.q & 63u) >> 2;
-                uint32_t px = (p.tile % rp.tiles_x) * 4u + (pix & 3u), py = (p.tile / rp.tiles_x) * 4u + (pix >> 2);
-                float *dst = accum + ((size_t)py * rp.width + px) * 3;
-                __hip_atomic_fetch_add(dst + 0, p.accum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dst + 1, p.accum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(dst + 2, p.accum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // A finished path leaves its radiance in its own hand-off record (quad 0: the draws there have been consumed), and
+                // accumulate_kernel below sums the records of a pixel into the accumulator behind this kernel.  Until round 3 the path
+                // added its radiance straight into the accumulator with three agent-scope atomics (several waves, on other XCDs,
+                // hold samplings of the same pixel): 100 M atomics per launch were 9 % of this kernel's time and cost the seed
+                // kernel beside it another 1.5 % (measured by leaving them out).  The store is one 16-byte write per path, the sum
+                // a 0.1-ms pass over 0.5 GB — and the summation order is fixed now: renders are bit-reproducible.
+                *reinterpret_cast<f4 *>(recs + (size_t)p.tile * tile_stride + rec_slot(path_draw_base(p), 0)) = f4{p.accum.x, p.accum.y, p.accum.z, 0.0f};
                 p.q = PATH_IDLE;
             }
         }
@@ -216,6 +210,30 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     }
     flush_counters<CNT>(cnt, lane, npaths, lc, ws);
     if (rp.gov && lane == 0) atomicMax(&rp.gov->t1[1][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// The radiance of a launch into the accumulator (renderer.rs:33-38: acc += the 2x2 sub-sample sum of calc_pixel, for every sampling
+// of the launch): one wave per tile, lane j = (pixel of the tile, sub-sample) as everywhere; the lane adds up its slot of the num_k
+// records the trace kernel left (quad 0 of the hand-off record), the four sub-samples of a pixel are neighbouring lanes, and the lane
+// of sub-sample 0 adds the sum to the pixel — plain loads and stores, nothing else touches the accumulator while this runs.
+__global__ __launch_bounds__(256) void accumulate_kernel(RenderParams rp, const float *__restrict__ recs, float *__restrict__ accum) {
+    const uint32_t lane = threadIdx.x & 63u, tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= rp.tiles_x * rp.tiles_y) return;
+    uint32_t px, py, sub;
+    tile_lane_pixel(rp, tile, lane, px, py, sub);
+    const bool valid = px < rp.width && py < rp.height;      // (the records of lanes beyond the image's edge were never written)
+    const f4 *src = reinterpret_cast<const f4 *>(recs + (size_t)tile * rp.num_k * REC_ITEM_FLOATS) + lane;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < rp.num_k; k++) {
+        const f4 v = valid ? src[(size_t)k * (REC_ITEM_FLOATS / 4u)] : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        r += v.x; g += v.y; b += v.z;
+    }
+    r += __shfl_xor(r, 1); g += __shfl_xor(g, 1); b += __shfl_xor(b, 1);
+    r += __shfl_xor(r, 2); g += __shfl_xor(g, 2); b += __shfl_xor(b, 2);
+    if (valid && sub == 0u) {
+        float *dst = accum + ((size_t)py * rp.width + px) * 3;
+        dst[0] += r; dst[1] += g; dst[2] += b;
+    }
 }
 
 // hr_debug_trace: closest-hit / shadow queries through the PRODUCTION traversal — traverse_wave on the record format the renderer
