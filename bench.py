@@ -364,10 +364,13 @@ def main():
                                       "note": "all of the kernel's traversal bytes over the time its waves spend in the box and leaf phases (shade and refill excluded)"}})
             out["rays_per_s_M"] = round(value * counters["rays"] / npaths, 1)
             if alone_ms:
-                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs * avg_ms / alone_ms, 1), "frac_alone": round(gbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4),
+                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs * avg_ms / alone_ms, 1),
+                             "hbm_normalised_alone": round(gbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4),
                              "note": "achieved / frac: trace kernel running concurrently with the seed kernel of the next batch (the production schedule); "
-                                     "*_alone: the same kernel on the same workload with the chip to itself"})
-                roof["survey_8d"]["frac_alone"] = round(sgbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4)
+                                     "*_alone: the same kernel on the same workload with the chip to itself.  The loaded bytes are served by the CUs' L1 and "
+                                     "the L2 (physical HBM traffic: `traffic`, an eighth of them), so with the chip to itself their rate can pass the HBM "
+                                     "peak: hbm_normalised_alone is NOT a fraction of anything physical — l2.frac_alone and physical.ta_busy_frac are"})
+                roof["survey_8d"]["normalised_alone"] = round(sgbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4)
             # L2 is the level that serves the tree: the same bytes against its aggregate bandwidth
             roof["l2"] = {"achieved": roof["achieved"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4),
                           "frac_alone": round(gbs * avg_ms / alone_ms / L2_PEAK_GBS, 4) if alone_ms else None,

@@ -22,9 +22,9 @@ def line(name):
 for name in ("bench_full_unprofiled", "bench_full", "bench_c2_spheres", "bench_c5_4k_dodeca", "bench_lbvh", "bench_ploc", "bench_gpus2_one_device", "bench_russian_roulette_nonparity"):
     d = line(name)
     r = d["roofline"]
-    print("%-34s %8.1f Mpaths/s  step %.2f ms  trace %.2f (alone %s) seed %.2f  frac %.3f alone %s  l2 %.3f  8d %.3f/%s  nodes/ray %.2f tris/ray %.2f  lanes box %.1f  build %.2f ms" % (
-        name, d["value"], d["ms_per_step"], r["avg_launch_ms"], r.get("avg_launch_ms_alone"), r["seed_kernel_avg_ms"], r["frac"] or 0, r.get("frac_alone"),
-        (r.get("l2") or {}).get("frac", 0), (r.get("survey_8d") or {}).get("frac", 0), (r.get("survey_8d") or {}).get("frac_alone"), r.get("node_tests_per_ray", 0),
+    print("%-34s %8.1f Mpaths/s  step %.2f ms  trace %.2f (alone %s) seed %.2f  frac %.3f (hbm-normalised alone %s)  l2 %.3f  8d %.3f/%s  nodes/ray %.2f tris/ray %.2f  lanes box %.1f  build %.2f ms" % (
+        name, d["value"], d["ms_per_step"], r["avg_launch_ms"], r.get("avg_launch_ms_alone"), r["seed_kernel_avg_ms"], r["frac"] or 0, r.get("hbm_normalised_alone"),
+        (r.get("l2") or {}).get("frac", 0), (r.get("survey_8d") or {}).get("frac", 0), (r.get("survey_8d") or {}).get("normalised_alone"), r.get("node_tests_per_ray", 0),
         r.get("tri_tests_per_ray", 0), r.get("lanes_per_box_pass", 0), r["bvh_build_ms"]))
 d = line("bench_full_unprofiled")
 r = d["roofline"]
