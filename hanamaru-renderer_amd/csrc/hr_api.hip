@@ -305,6 +305,8 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_w5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)seed_w5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
@@ -708,6 +710,10 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
         if (c->seed_prof) hipLaunchKernelGGL((seed_seg_kernel<true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
         else hipLaunchKernelGGL((seed_seg_kernel<false>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+    } else if (c->seed_mode == 4) {
+        if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
+        if (c->seed_prof) hipLaunchKernelGGL((seed_w5_kernel<true>), dim3(grid), dim3(320), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+        else hipLaunchKernelGGL((seed_w5_kernel<false>), dim3(grid), dim3(320), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
     } else if (c->seed_mode == 3) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
 #define HR_LAUNCH_PS(P) hipLaunchKernelGGL(seed_ps_kernel<P>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
@@ -1203,7 +1209,7 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "seed_mode") {
-        if (value != 0 && value != 1 && value != 2 && value != 3) return fail(HR_ERR_INVALID, "seed_mode must be 3 (phase-shifted four-run kernel), 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4) return fail(HR_ERR_INVALID, "seed_mode must be 4 (five-wave four-run kernel), 3 (phase-shifted four-run kernel), 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
         int rc = sync_all(c);
         if (rc) return rc;
         c->seed_mode = (int)value;

@@ -808,6 +808,204 @@ __global__ __launch_bounds__(256) void seed_ps_kernel(RenderParams rp, int lens_
     }
 }
 
+// ---- five-wave four-run seeding (debug option seed_mode = 4) ---------------------------------------------------------------------------------------
+// The three-run kernel's window is 11 blocks because a half has 120 lanes to fill it with.  With a FIFTH wave in the workgroup there are
+// 160 per half — consumer 64 + 96 of the three producer waves' 192 — which is 40 generators x 4 runs of 8 blocks (PS_NBLK): the window is
+// 8 blocks, both halves still run it at the same time (no window beside a round, which is what sank the phase-shifted kernel), the
+// round is the three-run kernel's own code, and there are the same two barriers per group.  What it costs is paid by the trace kernel,
+// which has the time since round 3: five waves on four SIMDs put two of them on one SIMD, and a SIMD with two of this kernel's 128-
+// register waves holds two trace waves instead of four.  The two waves that share a SIMD must not be consumers (a consumer's round is
+// the critical path): the roles are handed out at run time from the SIMD each wave finds itself on (HW_ID), through LDS words that the
+// generators overwrite later.
+//     window of half h:  slot 0 = its consumer (64 lanes), slot 1 = producer h (64 lanes), slot 2 = lanes 32 h .. 32 h + 31 of producer 2;
+//                        lane-run L = 64 slot + lane (slot 2: 128 + lane - 32 h) < 160: generator L % 40, run L / 40
+//     ahead pass:        64-path chunks in the order solo, pair A, solo, pair B (solo = the producer with a SIMD to itself): the two
+//                        producers that share a SIMD never have a chunk in the same group
+struct W5Roles {
+    uint32_t consumer_half;   // 0 | 1 for the two consumers, 2 = producer
+    uint32_t prod;            // producers: 0, 1, 2 (the window's slots); 2 is the solo producer when there is one
+    uint32_t solo_ok;         // a producer has a SIMD to itself (else the chunks go round-robin)
+};
+__device__ __forceinline__ W5Roles w5_roles(unsigned char *smem, uint32_t wave, uint32_t lane) {
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    volatile uint32_t *box = reinterpret_cast<volatile uint32_t *>(smem);
+    if (lane == 0) box[wave] = (hwid >> 4) & 3u;   // SIMD_ID
+    __syncthreads();
+    uint32_t simd[5], cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 5; i++) { simd[i] = box[i]; cnt[simd[i]]++; }
+    __syncthreads();                                // (the words are generator state from the first window on)
+    // consumers: the first two waves that have their SIMD to themselves (any two, if the placement is an unusual one)
+    int c0 = -1, c1 = -1;
+    for (int i = 0; i < 5; i++)
+        if (cnt[simd[i]] == 1) { if (c0 < 0) c0 = i; else if (c1 < 0) c1 = i; }
+    if (c1 < 0) { c0 = 0; c1 = 1; }
+    // producers in wave order; the one with a SIMD to itself (if any) takes slot 2
+    int pr[3], np = 0, solo = -1;
+    for (int i = 0; i < 5; i++)
+        if (i != c0 && i != c1) { pr[np] = i; if (cnt[simd[i]] == 1) solo = np; np++; }
+    if (solo >= 0 && solo != 2) { const int t = pr[2]; pr[2] = pr[solo]; pr[solo] = t; }
+    W5Roles r;
+    r.consumer_half = (int)wave == c0 ? 0u : (int)wave == c1 ? 1u : 2u;
+    r.prod = (int)wave == pr[0] ? 0u : (int)wave == pr[1] ? 1u : 2u;
+    r.solo_ok = solo >= 0 ? 1u : 0u;
+    return r;
+}
+struct W5Lane { uint32_t half, col, run; bool on; };
+__device__ __forceinline__ W5Lane w5_lane(uint32_t slot, uint32_t half_of_wave, uint32_t lane) {   // slot 0 consumer, 1 producer 0 | 1, 2 producer 2
+    W5Lane l;
+    l.half = slot == 2u ? lane >> 5 : half_of_wave;
+    const uint32_t L = slot == 2u ? 128u + (lane & 31u) : slot * 64u + lane;
+    l.on = L < (uint32_t)(PS_NRUN * SEED_LANES);
+    l.run = L / (uint32_t)SEED_LANES; l.col = L - l.run * (uint32_t)SEED_LANES;
+    return l;
+}
+struct W5Regs {
+    typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t v[8];
+    __device__ __forceinline__ void load(const u64 *ring_wg, uint64_t g, const W5Lane &l) {
+        const u64 *regs = ring_wg + (g & (SEED_RING_GROUPS - 1)) * PsLayout::GROUP_WORDS + l.half * PsLayout::HALF_WORDS + (size_t)l.run * PsLayout::STATE_WORDS + (size_t)l.col * 2u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(regs + q * (2 * SEED_LANES)));
+    }
+    __device__ __forceinline__ void run(unsigned char *smem, const W5Lane &l) const {
+        u64 st16[16];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { st16[2 * q] = v[q].x; st16[2 * q + 1] = v[q].y; }
+        LdsHalfMem m{reinterpret_cast<u64 *>(smem + (size_t)l.half * SEED_LDS_HALF_BYTES) + l.col + (size_t)(l.run * (uint32_t)PS_NBLK) * 8u * SEED_LANES};
+        if (l.on) isaac_init_run<PS_NBLK>(m, st16);
+    }
+};
+template <bool PROF>
+__device__ __forceinline__ void seed_w5_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
+                                                 float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * rp.ovf_cap;
+    uint32_t ovf_count = 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = 0;
+#define HR_STAMP(i) do { if (PROF) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tm; tm = now_; } } while (0)
+    const W5Lane sl = w5_lane(0u, half, lane);
+    W5Regs regs;
+    const uint32_t colr = lane < (uint32_t)SEED_LANES ? lane : 0u;
+    unsigned char *lds_half = smem + (size_t)half * SEED_LDS_HALF_BYTES;
+    LdsHalfMem m{reinterpret_cast<u64 *>(lds_half) + colr};
+    const uint64_t n_groups = r.G1 - r.G0;
+    __syncthreads();   // A of iteration 0: the states of groups G0 and G0 + 1 are in the ring
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        if (PROF) tm = __builtin_readcyclecounter();
+        const uint64_t g = r.G0 + it - 1;
+        if (it == 1) regs.load(r.ring_wg, g, sl);   // later groups: fetched during the previous round
+        const uint64_t pid = g * SEED_COLS + half * SEED_LANES + colr;
+        const bool in_range = pid < r.paths;
+        const uint32_t item = (uint32_t)((in_range ? pid : r.paths - 1) >> 6), j = (uint32_t)((in_range ? pid : r.paths - 1) & 63u);
+        uint32_t tile = item / rp.num_k;
+        uint32_t px, py, sub;
+        tile_lane_pixel(rp, tile, j, px, py, sub);
+        const bool valid = in_range && px < rp.width && py < rp.height;
+        HR_STAMP(0);
+        if (PROF) { __builtin_amdgcn_s_waitcnt(0x0F70); HR_STAMP(1); }   // vmcnt(0)
+        regs.run(smem, sl);                              // the window: this wave's runs of the sweep, straight into LDS
+        HR_STAMP(2);
+        __syncthreads();   // B: all four runs of every column are in
+        HR_STAMP(3);
+        if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, sl);
+        RecStore rs(recs, pid);
+        RecordTail<RecStore> lt(rs, lens_shape);
+        if (lane < (uint32_t)SEED_LANES) {
+            isaac_round<REC_DRAWS>(m, lt);
+            lt.finish();
+        }
+        HR_STAMP(4);
+        ovf_note(lane < (uint32_t)SEED_LANES && valid && lt.overflow(), pid, ovf_list, ovf_count, rp.ovf_cap);
+        HR_STAMP(5);
+        if (PROF) pc[7]++;
+        __syncthreads();   // A: the LDS is free again; the states of group G0 + it + 1 are in the ring
+        HR_STAMP(6);
+    }
+#undef HR_STAMP
+    if (PROF && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
+    const bool lane_on = lane < (uint32_t)SEED_LANES;
+    seed_fixup_wave(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
+}
+__device__ __forceinline__ void seed_w5_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, const W5Roles &role, const uint32_t pprio) {
+    const IsaacWarm warm = isaac_warm();
+    const W5Lane sl = w5_lane(role.prod == 2u ? 2u : 1u, role.prod & 1u, lane);
+    W5Regs regs;
+    const uint64_t n_groups = r.G1 - r.G0;
+    uint64_t frontier = r.first_path & ~63ull;               // first path whose states are not in the ring yet (chunks of 64 paths)
+    // whose chunk is it?  solo, pair A, solo, pair B (producer 2 is the solo one); without a solo producer: round-robin
+    auto mine = [&](uint64_t chunk) -> bool {
+        if (role.solo_ok) { const uint32_t ph = (uint32_t)(chunk & 3u); return ph == 1u ? role.prod == 0u : ph == 3u ? role.prod == 1u : role.prod == 2u; }
+        return (uint32_t)(chunk % 3u) == role.prod;
+    };
+    auto ahead = [&](uint64_t upto) {
+        const uint64_t need = upto * SEED_COLS;
+        for (; frontier < need && frontier < r.end_path; frontier += 64) {
+            if (!mine(frontier >> 6)) continue;
+            const uint64_t pid0 = frontier + lane;
+            const bool on = pid0 >= r.first_path && pid0 < r.end_path && !(rp.pad[2] & 4u);   // pad[2]: timing experiments (debug_skip)
+            const uint64_t ppid = pid0 >= r.first_path && pid0 < r.end_path ? pid0 : r.end_path - 1;
+            const uint32_t item = (uint32_t)(ppid >> 6), j = (uint32_t)(ppid & 63u);
+            uint32_t tile = item / rp.num_k, k = item - tile * rp.num_k;
+            uint32_t px, py, sub;
+            tile_lane_pixel(rp, tile, j, px, py, sub);
+            bool pvalid = px < rp.width && py < rp.height;
+            u64 s, t;
+            path_seed_words(rp.width, rp.height, pvalid ? px : 0u, pvalid ? py : 0u, sub, s, t);
+            const uint64_t g = ppid / SEED_COLS;
+            const uint32_t c80 = (uint32_t)(ppid - g * SEED_COLS), hh = c80 >= (uint32_t)SEED_LANES ? 1u : 0u;
+            PsStateOut out{r.ring_wg + (g & (SEED_RING_GROUPS - 1)) * PsLayout::GROUP_WORDS + hh * PsLayout::HALF_WORDS + (size_t)(c80 - hh * (uint32_t)SEED_LANES) * 2u};
+            if (on) {
+                AheadRegs job;
+                isaac_ahead_part1<PS_P1BLK>(out, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, job);
+                isaac_ahead_part2<PS_NRUN, PS_NBLK, PS_P1BLK>(out, job);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // the state stores are hand-written: the compiler does not wait for them at the barrier by itself
+    };
+    ahead(r.G0 + 2);
+    __syncthreads();   // A
+    if (n_groups >= 1) regs.load(r.ring_wg, r.G0, sl);
+    for (uint64_t it = 1; it <= n_groups; it++) {
+        regs.run(smem, sl);          // the window
+        __syncthreads();   // B
+        if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, sl);   // for the next window; complete in the ring since the last barrier A
+        if (((pprio >> 2) & 3u) != (pprio & 3u)) {
+            const uint32_t pr = (it & 1u) ? (pprio >> 2) & 3u : pprio & 3u;
+            if (pr == 0u) __builtin_amdgcn_s_setprio(0); else if (pr == 1u) __builtin_amdgcn_s_setprio(1); else if (pr == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+        }
+        ahead(r.G0 + it + 2);
+        __syncthreads();   // A
+    }
+}
+template <bool PROF = false>
+__global__ __launch_bounds__(320) void seed_w5_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
+                                                      uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const W5Roles role = w5_roles(smem, wave, lane);
+    const bool consumer = role.consumer_half < 2u;
+    const uint32_t pprio = consumer ? 0u : seed_gov_begin(rp, role.prod == 0u && lane == 0u);
+    const uint32_t prio = consumer ? rp.pad[0] : pprio & 3u;
+    switch (prio) {  // s_setprio takes an immediate
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+    PcRange r;
+    r.paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
+    const uint64_t groups = (r.paths + SEED_COLS - 1) / SEED_COLS;
+    r.G0 = groups * blockIdx.x / gridDim.x; r.G1 = groups * (blockIdx.x + 1) / gridDim.x;
+    r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
+    r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
+    if (consumer) seed_w5_consumer<PROF>(rp, lens_shape, r, smem, lane, role.consumer_half, recs, ovf, win, cnt);
+    else {
+        seed_w5_producer(rp, r, smem, lane, role, pprio);
+        seed_gov_end(rp, role.prod == 0u && lane == 0u);
+    }
+}
+
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
 struct RawTail {
     u64 *out; int window;

@@ -226,7 +226,8 @@ int hr_set_option(hr_ctx *ctx, const char *key, double value);
 /* Measurement / experiment knobs, kept out of hr_set_option so that a host cannot change the kernels' schedule — or produce a
  * garbage image — by a key string meant for a product option: "adv_den" / "leaf_den" (trace-kernel phase thresholds), "min_waves"
  * (4..6, occupancy variant of the trace kernel; only with quant_nodes = 1), "kchunk", "node_unroll" (1 | 2), "trace_wgs",
- * "seed_mode" (2 = three-run seed kernel, default; 3 = its phase-shifted four-run form, slower; 1 = producer / consumer kernel with a
+ * "seed_mode" (2 = three-run seed kernel, default; 3 = its phase-shifted four-run form and 4 = its five-wave four-run form, both
+ * slower, kept as measured experiments; 1 = producer / consumer kernel with a
  * ring of generator words; 0 = fused),
  * "seed_split" (seed_mode 1), "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves), "seed_prof"
  * (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles; seed_mode 3: 1 | 2 | 3 = consumer 0, consumer 1, producer 0), "ploc_top" (bvh_builder 2: clusters the bottom-up merges

@@ -399,7 +399,7 @@ def test_error_paths(ha):
     for key, bad in [("batch", 65), ("max_leaf", 0), ("bvh_builder", 3), ("rng_window", 32), ("russian_roulette", 1), ("trace_boost", 5)]:
         with pytest.raises(ha.HipError):
             r.set_option(key, bad)
-    for key, bad in [("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("seed_mode", 4), ("seed_split", 10), ("nonsense", 1)]:
+    for key, bad in [("adv_den", 0), ("leaf_den", 100), ("min_waves", 9), ("seed_mode", 5), ("seed_split", 10), ("nonsense", 1)]:
         with pytest.raises(ha.HipError):
             r.set_debug_option(key, bad)
     # the measurement knobs are not reachable through the product call: a host cannot ship a garbage image by key string
@@ -505,9 +505,9 @@ def test_cli_checkpoint_resume_and_debug(tmp_path):
 
 
 def test_seed_kernels_are_bit_identical(gpu, scenes):
-    """The four seed kernels — the three-run kernel (seed_mode 2, the default: the init sweep as three runs computed side by side from
+    """The five seed kernels — the three-run kernel (seed_mode 2, the default: the init sweep as three runs computed side by side from
     states the producer waves work out ahead), its phase-shifted four-run form (seed_mode 3: the halves half a period apart, barriers in
-    the middle of the round, a paused ahead pass), the producer / consumer kernel with the ring of generator words (seed_mode 1, every
+    the middle of the round, a paused ahead pass), its five-wave four-run form (seed_mode 4: roles by SIMD), the producer / consumer kernel with the ring of generator words (seed_mode 1, every
     seed_split) and the fused kernel (seed_mode 0) — must hand the trace kernel exactly the same draws: same raw tails -> the
     same accumulator, bit for bit (since round 3 a launch's radiance is summed in a fixed order: accumulate_kernel)."""
     sc, _ = scenes("rtcamp6_v3_1")
@@ -517,7 +517,7 @@ def test_seed_kernels_are_bit_identical(gpu, scenes):
         for (w, h, s) in [(130, 71, 6), (640, 360, 9)]:   # ragged: tiles hang over the right and bottom edges; many groups per CU
             gpu.set_resolution(w, h)
             ref = None
-            for mode, head in [(0, 16), (1, 16), (1, 8), (1, 12), (1, 24), (2, 16), (3, 16)]:   # 2: the three-run kernel (no state ring), 3: its phase-shifted four-run form
+            for mode, head in [(0, 16), (1, 16), (1, 8), (1, 12), (1, 24), (2, 16), (3, 16), (4, 16)]:   # 2: the three-run kernel (no state ring), 3: its phase-shifted four-run form
                 gpu.set_debug_option("seed_mode", mode)
                 gpu.set_debug_option("seed_split", head)
                 gpu.clear()
@@ -894,7 +894,7 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
             end = begin + stride * int(rng.integers(1, 9))
             gpu.set_resolution(w, h)
             outs = []
-            for mode in (0, 1, 2, 3):
+            for mode in (0, 1, 2, 3, 4):
                 gpu.set_debug_option("seed_mode", mode)
                 gpu.clear()
                 gpu.render(begin, end, stride)

@@ -23,6 +23,7 @@ python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_fro
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
 python tools/seedprof_ps.py > $OUT/${TAG}_seed_ps_phases.txt 2>&1
+python tools/seedprof.py 16 4 > $OUT/${TAG}_seed_w5_phases.txt 2>&1
 tools/bin/issueprobe > $OUT/${TAG}_issueprobe.txt 2>&1
 tools/bin/roundprobe2 > $OUT/${TAG}_roundprobe2.txt 2>&1
 tools/bin/roundprobe3 > $OUT/${TAG}_roundprobe3.txt 2>&1
