@@ -625,7 +625,7 @@ def test_bench_gpus_n_without_a_launcher(tmp_path):
     # the bench line's roofline: loaded bytes can not exceed the §8(d) booking, nothing above 1, and the traversal-only workload is there
     r = j1["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["frac"] <= r["survey_8d"]["frac"] and "frac_alone" not in r
-    assert 0 < r["l2"]["frac"] <= r["l2"]["frac_alone"] < 1 and r["hbm_normalised_alone"] > 0
+    assert 0 < r["l2"]["frac"] < 1 and 0 < r["l2"]["frac_alone"] < 1 and r["hbm_normalised_alone"] > 0   # (at 160x90 "alone" is not reliably the faster one)
     assert 0 < r["traversal_section"]["share_of_wave_cycles"] < 1 and r["traversal_only"]["Mrays_per_s"] > 0 and 0 < r["traversal_only"]["frac"] < 1
     assert "cpu_baseline" not in j1 and j1["config"]["estimator"].startswith("reference")
     # three contexts, odd step count
