@@ -62,3 +62,13 @@ def test_product_does_not_reference_oracle_or_emulation():
                     if re.search(r"liboracle|oracle_py|libhr_emu|emu_py|#include\s+\"\.\./\.\./oracle", code):
                         offenders.append((f, line.strip()))
     assert not offenders, offenders
+
+
+def test_graft_entry_build_check_follows_the_header():
+    """__graft_entry__.build() compares the library's ABI version with the header's, not with a literal (a literal went stale once)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert "HR_ABI_VERSION" in src and not re.search(r"hr_abi_version\(\)\s*==\s*\d", src)
+
