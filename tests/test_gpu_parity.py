@@ -557,6 +557,43 @@ def test_priority_governor_does_not_change_results(gpu, scenes):
         assert np.array_equal(outs[0], o), np.abs(outs[0] - o).max()
 
 
+def test_kernel_variants_render_the_same_bits(gpu, scenes):
+    """The instrumented build (counters), the occupancy variants (min_waves 4 / 6), the walk on the 32-byte fp32 records (quant_nodes 0)
+    and a device-built tree are other INSTRUCTION STREAMS for the same arithmetic: closest hits do not depend on the tree or the
+    record format, every product is an explicit FMA or not one, and a launch's radiance is summed in a fixed order — so the accumulator
+    is the same, bit for bit."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(400, 225)
+
+    def render():
+        gpu.clear()
+        gpu.render(1, 9)
+        return gpu.read_accumulator().copy()
+    ref = render()
+    assert ref.sum() > 0
+    try:
+        gpu.set_option("counters", 1)
+        assert np.array_equal(ref, render()), "instrumented build"
+        gpu.set_option("counters", 0)
+        for mw in (4, 6):
+            gpu.set_debug_option("min_waves", mw)
+            assert np.array_equal(ref, render()), ("min_waves", mw)
+        gpu.set_debug_option("min_waves", 5)
+        gpu.set_option("quant_nodes", 0)
+        gpu.upload_scene(sc)
+        assert np.array_equal(ref, render()), "fp32 node records"
+        gpu.set_option("quant_nodes", 1)
+        gpu.set_option("bvh_builder", 2)
+        gpu.upload_scene(sc)
+        assert np.array_equal(ref, render()), "device-built tree"
+    finally:
+        gpu.set_option("counters", 0)
+        gpu.set_debug_option("min_waves", 5)
+        gpu.set_option("quant_nodes", 1)
+        gpu.set_option("bvh_builder", 0)
+
+
 def test_priority_governor_decides_on_the_device(gpu, scenes):
     """The governor lives in device memory (GovDev, governor_kernel): inside ONE hr_render call — the host never waits — it judges the
     launches as they finish (all but the first and last of the burst, whose kernels ran alone for part of their time), and a fixed
