@@ -20,12 +20,21 @@ Two ways to run N > 1, the same library calls underneath:
     with fewer than N GPUs all contexts share device 0 and the library sums them with a kernel on that device (RCCL wants one
     rank per device) — labelled in config.parallelism; that is the path the 1-GPU test tier exercises.
 
+`--total-samplings S` switches to strong scaling: exactly the samplings 1..S in total, sharded over the N GPUs and spread over
+--steps steps ("scaling": "strong").  BASELINE config 4 is `--gpus 8 --total-samplings 4096`, config 5
+`--scene rtcamp6_dodeca --width 3840 --height 2160 --gpus 8 --total-samplings 1024`.
+
 Extra objects on the JSON line:
-  roofline     — trace kernel: bytes its lanes load for the tests it performs (counted by an instrumented run of the same kernel
-                 on the same seeds: 16 B per node visit on the quantised records, 48 B per triangle, 16 B per sphere, 32 B per
-                 cuboid) divided by the kernel's mean launch duration (HIP events on its stream), vs 8 TB/s HBM peak; next to it
-                 SURVEY.md §8(d)'s normalised figure (32 / 36 / 16 / 24 B), the traversal section's share, the traversal-only
-                 workload (hr_render_debug, Depth mode) and the PMC view of what physically bounds the kernel.
+  roofline     — trace kernel, `achieved` / `frac` (= `frac_survey_8d`): SURVEY.md §8(d)'s byte booking (32 B per node test, 36 B per
+                 triangle, 16 B per sphere, 24 B per cuboid; test counts from an instrumented run of the same kernel on the same
+                 seeds) per launch, divided by the kernel's mean launch duration (HIP events on its stream), vs the 8 TB/s HBM peak —
+                 the BASELINE-mandated normalisation.  `bound` names what the PMC passes say limits the kernel physically
+                 (`l1_ta_issue`: L1 tag lookups and lane divergence; the tree is L2-resident), `bound_contract` the roof the metric
+                 is priced against (`hbm`), `pair_bound` the slower kernel of the concurrent pair (the seed kernel).  Next to them:
+                 `loaded_bytes` (what the lanes really request with this build's 16-byte node records), the traversal section's
+                 share, the traversal-only workload (hr_render_debug, Depth mode), `traffic` (PMC) and `physical`.
+  multi_gpu    — per rank: wall time until its samplings were done, the all-reduce as it saw it, its kernels' summed durations;
+                 the accumulator's size; max / min over ranks.
   cpu_baseline — the CPU oracle (f64 restatement of the reference path, oracle/) timed on this box's host cores
                  on a bounded sample; reported, not optimised.
 """
@@ -105,6 +114,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--total-samplings", type=int, default=0,
+                    help="strong scaling: render exactly samplings 1..S in total, sharded over the GPUs and spread over --steps steps (BASELINE config 4: --gpus 8 --total-samplings 4096)")
     ap.add_argument("--batch", type=int, default=0, help="samplings per kernel launch (0 = the library's automatic choice: 4 at 1080p)")
     ap.add_argument("--scene", default="rtcamp6_v3_1")
     ap.add_argument("--max-leaf", type=int, default=0)
@@ -161,6 +172,12 @@ def main():
     dev = torch.device("cuda", mine[0][1])
 
     W, H, SPS = args.width, args.height, args.spp_per_step
+    S_TOTAL = args.total_samplings
+    if S_TOTAL:
+        # strong scaling: a fixed total of samplings 1..S_TOTAL, whatever N is.  A step covers SPS * world consecutive sampling
+        # indices as always; SPS is chosen so that --steps steps cover S_TOTAL, and the last step is clipped to it.
+        SPS = max(1, -(-S_TOTAL // (args.steps * world)))
+        args.steps = -(-S_TOTAL // (SPS * world))
     scene = ha.Scene(args.scene)
     rs = []
     for _, d in mine:
@@ -222,7 +239,10 @@ def main():
     def run_step(i):
         # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; rank g takes (s-1) % world == g
         for r, (g, _) in zip(rs, mine):
-            r.render(*step_range(i, SPS, world, g))
+            b, e, stride = step_range(i, SPS, world, g)
+            if S_TOTAL:
+                e = min(e, S_TOTAL + 1)       # --total-samplings: the last step ends at sampling S_TOTAL
+            r.render(b, e, stride)
 
     def barrier():
         if dist is not None:
@@ -254,24 +274,54 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(i)
+    # every context's render work is awaited before the collective is enqueued: costs one host round trip per context (~20 us), and
+    # buys the split of the timed region into "rendering" and "the all-reduce" on the line (per rank)
+    render_done = []
+    for r in rs:
+        r.synchronize()
+        render_done.append(time.perf_counter() - t0)
+    t_ar0 = time.perf_counter()
     all_reduce()
     sync_all()
     if one_device:
         h = acc.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         acc.copy_(h)
+    t_ar1 = time.perf_counter()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    # per rank: wall time until its own samplings were done, the all-reduce as it saw it (a rank that arrives early waits in it for
+    # the slowest one: the MIN over ranks is the collective's own duration), the kernels' summed HIP-event durations
+    per_rank = []
+    for r, (g, d), rd in zip(rs, mine, render_done):
+        s_ = r.stats()
+        per_rank.append({"rank": g, "device": d, "render_ms": round(rd * 1e3, 3), "allreduce_ms": round((t_ar1 - t_ar0) * 1e3, 3),
+                         "seed_kernel_ms": round(s_["seed_kernel_ms"], 3), "trace_kernel_ms": round(s_["trace_kernel_ms"], 3),
+                         "launches": int(s_["trace_launches"]), "paths": int(s_["paths"])})
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank)
+        per_rank = [x for part in gathered for x in part]
     st = r0.stats()
     acc_mean = float(acc.mean().item()) if one_device else float(r0.read_accumulator().mean())   # after the all-reduce: the total
     if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0:
         sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % acc_mean)
 
+    # ---- outside the timed region, rank 0: the post chain (renderer.rs:64-90 as two HIP kernels) on the all-reduced accumulator
+    post = None
+    if rank == 0 and not args.debug_skip:
+        n_s = S_TOTAL if S_TOTAL else SPS * world * args.steps
+        p0 = r0.stats()["post_kernel_ms"]
+        tp0 = time.perf_counter()
+        img = r0.resolve(max(1, n_s))
+        tp1 = time.perf_counter()
+        post = {"kernels": "tonemap_gamma_kernel + bilateral_quantise_kernel", "resolution": [W, H], "post_kernel_ms": round(r0.stats()["post_kernel_ms"] - p0, 4),
+                "hr_resolve_wall_ms": round((tp1 - tp0) * 1e3, 3), "image_mean_u8": round(float(img.mean()), 3),
+                "note": "hr_resolve on the all-reduced accumulator, once, outside the timed region: HIP-event time of the two kernels, and the call's wall time incl. the W x H x 3 byte copy to the host"}
     # ---- outside the timed region, rank 0: the trace kernel with the chip to itself, and the traversal-only workload
     alone_ms = None
     trav = None
@@ -298,19 +348,37 @@ def main():
         trav = (tc, ts["debug_kernel_ms"] / max(1, ts["debug_launches"]))
 
     if rank == 0:
-        total_paths = paths_per_step_gpu * world * args.steps
+        samplings_run = S_TOTAL if S_TOTAL else SPS * world * args.steps      # sampling indices 1..samplings_run, over all GPUs
+        total_paths = W * H * 4 * samplings_run
+        assert sum(x["paths"] for x in per_rank) == total_paths, (per_rank, total_paths)
         value = total_paths / elapsed / 1e6
+        accum_bytes = W * H * 3 * 4
+        render_ms = [x["render_ms"] for x in per_rank]
+        ar_ms = [x["allreduce_ms"] for x in per_rank]
         out = {
             "metric": "Mpaths/sec at 1920x1080x1024spp (rtcamp6 scene); achieved GB/s in BVH traversal",
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if S_TOTAL else "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
-            "config": {"workload": "%s %dx%d, %d samplings (x4 sub-samples) per step per GPU; K=64 steps = 1024 samplings" % (args.scene, W, H, SPS),
+            "config": {"workload": "%s %dx%d x %d samplings (x4 sub-samples = %d paths) in this run: %d steps x %d samplings per step per GPU x %d GPU(s)%s; "
+                                   "BASELINE's headline is the same image at 1024 samplings (--steps 64 at the default 16 per step), the rate does not depend on the count"
+                                   % (args.scene, W, H, samplings_run, total_paths, args.steps, SPS, world, (", last step clipped to --total-samplings %d" % S_TOTAL) if S_TOTAL else ""),
+                       "samplings_total": samplings_run, "paths_total": total_paths,
                        "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": paths_per_step_gpu * world,
                        "parallelism": "spp-sharded x%d, one all-reduce (%s)" % (world, how), "devices": sorted(set(d for _, d in mine)) if not launcher else [local_rank],
                        "estimator": "reference (no Russian roulette)" if not args.russian_roulette else "NON-PARITY: Russian roulette from iteration %d" % args.russian_roulette},
             "rays_per_s_M": None,
+            # the timed region, split: every rank's wall time until its own samplings were done, then ONE all-reduce of the accumulators
+            # (fp32 W x H x 3).  A rank that is done early waits inside the collective for the slowest one, so the collective's own
+            # duration is the MIN over ranks; a wide max - min spread of render_ms means one GPU was slower, not the exchange.
+            "multi_gpu": {"accumulator_bytes": accum_bytes,
+                          "render_ms": {"max": max(render_ms), "min": min(render_ms)},
+                          "allreduce_ms": {"max": max(ar_ms), "min": min(ar_ms)},
+                          "allreduce_share_of_timed_region": round(min(ar_ms) * 1e-3 / elapsed, 5),
+                          "per_rank": sorted(per_rank, key=lambda x: x["rank"]),
+                          "note": ("one process drives all contexts: render_ms of rank k is observed after ranks 0..k-1 were awaited (a lower bound for the "
+                                   "later ranks' own time is their kernels' summed durations)" if (not launcher and world > 1) else "one process per rank")},
         }
         launches = max(1, st["trace_launches"])
         avg_ms = st["trace_kernel_ms"] / launches
@@ -319,7 +387,11 @@ def main():
         quant = args.quant_nodes != 0
         node_b = 16 if quant else 32
         builder = {0: "host-sah", 1: "device-lbvh", 2: "device-ploc"}.get(args.bvh_builder, "?")
-        roof = {"bound": "hbm", "kernel": "trace_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+        # `bound`: what the PMC passes say limits the kernel (the CUs' L1 tag lookups / texture-addresser issue and lane divergence — the
+        # tree is L2-resident, physical HBM traffic is ~6 % of peak); `bound_contract` / `peak`: BASELINE's metric prices the traversal
+        # against the HBM peak, and that normalisation is what `achieved` / `frac` are (SURVEY.md 8(d)'s byte booking).
+        roof = {"bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel", "pair_bound": "seed_seg_kernel",
+                "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "frac_survey_8d": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
                 "bvh_builder": builder, "bvh_build_ms": round(st["bvh_build_ms"], 4),
@@ -341,15 +413,16 @@ def main():
             share = dict(zip(("shade", "refill", "box", "leaf"), [round(v / max(1.0, sum(pc)), 3) for v in pc]))
             trav_share = (pc[2] + pc[3]) / max(1.0, sum(pc))
             roof.update({
-                "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "definition": "bytes the kernel's lanes load for the tests they perform (%d B per node visit on the %s records, 48 B per triangle, 16 B per sphere, "
-                              "32 B per cuboid; test counts from the instrumented build of the same kernel on the same seeds) per launch / mean launch duration "
-                              "(HIP events), over the HBM3E peak.  The tree is L2-resident (see `traffic` and `l2`): HBM is not what bounds the kernel" % (node_b, "16-byte quantised" if quant else "32-byte fp32"),
-                "algorithmic_bytes_per_path": round(lb, 1), "algorithmic_bytes_per_launch": int(lb * paths_per_launch),
-                "survey_8d": {"bytes_per_path": round(sb, 1), "achieved": round(sgbs, 1), "frac": round(sgbs / HBM_PEAK_GBS, 4),
-                              "note": "normalised traversal rate: SURVEY.md §8(d) books 32 B per node test, 36 B per triangle, 16 B per sphere, 24 B per cuboid whatever the "
-                                      "record format.  Comparable across rounds and layouts; NOT a physical fraction of HBM bandwidth (a node visit loads 16 B here and the "
-                                      "tree is served by L2), so it may exceed 1"},
+                "achieved": round(sgbs, 1), "frac": round(sgbs / HBM_PEAK_GBS, 4), "frac_survey_8d": round(sgbs / HBM_PEAK_GBS, 4),
+                "definition": "SURVEY.md 8(d): 32 B per node test + 36 B per triangle test + 16 B per sphere test + 24 B per cuboid test that the kernel performs "
+                              "(test counts from the instrumented build of the same kernel on the same seeds) per launch / the kernel's mean launch duration (HIP events on "
+                              "its stream), over the HBM3E peak.  It is the BASELINE-mandated normalisation, comparable across rounds and record layouts; it is NOT a "
+                              "physical share of HBM bandwidth (the tree is L2-resident: see `traffic`, `l2`, `physical`), and with the chip to itself it passes 1",
+                "algorithmic_bytes_per_path": round(sb, 1), "algorithmic_bytes_per_launch": int(sb * paths_per_launch),
+                "loaded_bytes": {"bytes_per_path": round(lb, 1), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "note": "the bytes the lanes really request for those tests with this build's records (%d B per node visit on the %s records, 48 B per triangle, "
+                                         "16 B per sphere, 32 B per cuboid): the conservative figure, below the 8(d) booking because a node visit is a 16-byte load here"
+                                         % (node_b, "16-byte quantised" if quant else "32-byte fp32")},
                 "node_tests_per_ray": round(counters["node_tests"] / max(1, counters["rays"]), 2),
                 "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
                 "rays_per_path": round(counters["rays"] / npaths, 3),
@@ -360,21 +433,21 @@ def main():
                 "phase_share_of_wave_cycles": share,
                 # north_star's "traversal section": the box + leaf phases' share of the wave cycles applied to the kernel's time
                 "traversal_section": {"share_of_wave_cycles": round(trav_share, 3), "ms_per_launch": round(avg_ms * trav_share, 4),
-                                      "achieved": round(gbs / max(trav_share, 1e-9), 1), "frac": round(gbs / max(trav_share, 1e-9) / HBM_PEAK_GBS, 4),
-                                      "note": "all of the kernel's traversal bytes over the time its waves spend in the box and leaf phases (shade and refill excluded)"}})
+                                      "achieved": round(sgbs / max(trav_share, 1e-9), 1), "frac": round(sgbs / max(trav_share, 1e-9) / HBM_PEAK_GBS, 4),
+                                      "note": "all of the kernel's traversal bytes (8(d) booking) over the time its waves spend in the box and leaf phases (shade and refill excluded)"}})
             out["rays_per_s_M"] = round(value * counters["rays"] / npaths, 1)
             if alone_ms:
-                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(gbs * avg_ms / alone_ms, 1),
-                             "hbm_normalised_alone": round(gbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4),
+                roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(sgbs * avg_ms / alone_ms, 1),
+                             "hbm_normalised_alone": round(sgbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4),
                              "note": "achieved / frac: trace kernel running concurrently with the seed kernel of the next batch (the production schedule); "
-                                     "*_alone: the same kernel on the same workload with the chip to itself.  The loaded bytes are served by the CUs' L1 and "
-                                     "the L2 (physical HBM traffic: `traffic`, an eighth of them), so with the chip to itself their rate can pass the HBM "
+                                     "*_alone: the same kernel on the same workload with the chip to itself.  The bytes are served by the CUs' L1 and "
+                                     "the L2 (physical HBM traffic: `traffic`), so with the chip to itself their rate can pass the HBM "
                                      "peak: hbm_normalised_alone is NOT a fraction of anything physical — l2.frac_alone and physical.ta_busy_frac are"})
-                roof["survey_8d"]["normalised_alone"] = round(sgbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4)
+                roof["loaded_bytes"]["normalised_alone"] = round(gbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4)
             # L2 is the level that serves the tree: the same bytes against its aggregate bandwidth
-            roof["l2"] = {"achieved": roof["achieved"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4),
+            roof["l2"] = {"achieved": round(gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4),
                           "frac_alone": round(gbs * avg_ms / alone_ms / L2_PEAK_GBS, 4) if alone_ms else None,
-                          "note": "the same loaded bytes per second vs the aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s); part of them is served by the CUs' L1"}
+                          "note": "the loaded bytes per second vs the aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s); part of them is served by the CUs' L1"}
         if trav is not None:
             tc, tms = trav
             rays = max(1, tc["rays"])
@@ -415,6 +488,8 @@ def main():
                                  "valu_ceiling_Mpaths_per_s": round(chip_valu_per_s / valu / 1e6, 1), "frac": round(value / world * 1e6 * valu / chip_valu_per_s, 4),
                                  "source": pmc["source"], "stale": stale}
         out["roofline"] = roof
+        if post:
+            out["post_chain"] = post
         # The other kernel of the pair: per-path ISAAC-64 seeding.  Bound neither by HBM nor by MFMA but by LDS capacity x the
         # serial chain of ONE wave (SEED_CEILING_US_PER_GROUP above).
         seed_ms = st["seed_kernel_ms"] / max(1, st["seed_launches"])

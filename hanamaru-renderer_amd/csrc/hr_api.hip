@@ -159,7 +159,8 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
     const bool have = s0 != none && s1 > s0 && r0 != none && r1 > r0;
     if (have && g->fixed < 0) {
         const u64t p0 = g->prev_t0, p1 = g->prev_t1;
-        const u64t n0 = g->t0[0][other], n1 = g->t1[0][other];     // the next launch's seed kernel: running (n1 not final) or done
+        // the next launch's seed kernel: running (its waves are updating these stamps with atomicMin / atomicMax right now; n1 not final) or done
+        const u64t n0 = __hip_atomic_load(&g->t0[0][other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), n1 = __hip_atomic_load(&g->t1[0][other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float ov_seed = 0.0f, ov_trace = 0.0f;
         if (p1 > p0) {
             const u64t lo = p0 > s0 ? p0 : s0, hi = p1 < s1 ? p1 : s1;
@@ -541,7 +542,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     uint32_t total = 0;
     memcpy(&total, &hframe[6], sizeof total);
     if (total == 0 || total > (uint32_t)N) return fail(HR_ERR_DEVICE, "device BVH build: implausible record count %u for %d primitives", total, n);
-    if ((uint64_t)(total + 1u) * 8u * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "device BVH build: %u records per octant exceed the 2^28-byte offset range of the quantised records", total);
+    if (c->quant_nodes && (uint64_t)(total + 1u) * 8u * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "device BVH build: %u records per octant exceed the 2^28-byte offset range of the quantised records", total);
     c->bvh_build_ms = ms;
     d.nodes = nodes; d.num_nodes = total;
     d.qnodes = c->quant_nodes ? qnodes : nullptr;
@@ -1083,7 +1084,8 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     int rc = sync_all(c);
     if (rc) return rc;
     Counters h;
-    HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     memset(out, 0, sizeof *out);
     out->paths = c->counters ? h.paths : c->paths_rendered;
     out->rays = h.rays; out->node_tests = h.node_tests; out->tri_tests = h.tri_tests;
@@ -1094,7 +1096,8 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->debug_kernel_ms = c->debug_ms; out->debug_launches = c->debug_launches;
     {
         GovDev g;
-        HIP_TRY(hipMemcpy(&g, c->gov, sizeof g, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&g, c->gov, sizeof g, hipMemcpyDeviceToHost, c->stream));   // on the context's own stream: a null-stream copy could serialise against other contexts' launches
+        HIP_TRY(hipStreamSynchronize(c->stream));
         out->governor_level = (uint64_t)(g.level < 0 ? 0 : g.level); out->governor_decisions = g.decisions; out->governor_moves = g.moves;
     }
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;

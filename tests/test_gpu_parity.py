@@ -659,16 +659,45 @@ def test_bench_gpus_n_without_a_launcher(tmp_path):
     import torch
     par = j2["config"]["parallelism"]
     assert "spp-sharded x2" in par and ("RCCL group all-reduce" in par if torch.cuda.device_count() >= 2 else "FALLBACK" in par), par
-    # the bench line's roofline: loaded bytes can not exceed the §8(d) booking, nothing above 1, and the traversal-only workload is there
+    # the bench line's roofline: frac IS SURVEY 8(d)'s figure, the loaded bytes can not exceed that booking, and the traversal-only workload is there
     r = j1["roofline"]
-    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["frac"] <= r["survey_8d"]["frac"] and "frac_alone" not in r
+    assert r["bound"] == "l1_ta_issue" and r["bound_contract"] == "hbm" and r["pair_bound"] == "seed_seg_kernel" and r["peak"] == 8000.0
+    assert 0 < r["frac"] == r["frac_survey_8d"] and 0 < r["loaded_bytes"]["frac"] <= r["frac"] and "frac_alone" not in r
+    assert abs(r["achieved"] * 1e9 * r["avg_launch_ms"] * 1e-3 - r["algorithmic_bytes_per_launch"]) <= 2e-3 * r["algorithmic_bytes_per_launch"]
     assert 0 < r["l2"]["frac"] < 1 and 0 < r["l2"]["frac_alone"] < 1 and r["hbm_normalised_alone"] > 0   # (at 160x90 "alone" is not reliably the faster one)
     assert 0 < r["traversal_section"]["share_of_wave_cycles"] < 1 and r["traversal_only"]["Mrays_per_s"] > 0 and 0 < r["traversal_only"]["frac"] < 1
     assert "cpu_baseline" not in j1 and j1["config"]["estimator"].startswith("reference")
+    # the workload string states what was run, not a constant
+    assert j1["config"]["samplings_total"] == 8 and "x 8 samplings" in j1["config"]["workload"] and "4 steps x 2 samplings" in j1["config"]["workload"]
+    assert j2["config"]["samplings_total"] == 8 and j2["config"]["paths_total"] == 160 * 90 * 4 * 8
+    assert j1["post_chain"]["post_kernel_ms"] > 0 and j1["post_chain"]["resolution"] == [160, 90]
+    # the timed region's split, per rank
+    m = j2["multi_gpu"]
+    assert m["accumulator_bytes"] == 160 * 90 * 3 * 4 and len(m["per_rank"]) == 2 and [x["rank"] for x in m["per_rank"]] == [0, 1]
+    assert all(x["paths"] == 160 * 90 * 4 * 4 and x["render_ms"] > 0 and x["allreduce_ms"] > 0 and x["seed_kernel_ms"] > 0 for x in m["per_rank"])
+    assert m["render_ms"]["max"] >= m["render_ms"]["min"] > 0 and 0 < m["allreduce_share_of_timed_region"] < 1
     # three contexts, odd step count
     j3, m3 = _bench_line(_run_bench(["--gpus", "3", "--steps", "1", "--no-counters"]))
     _, m3ref = _bench_line(_run_bench(["--steps", "3", "--no-counters"]))
     assert j3["n_gpus"] == 3 and abs(m3 - m3ref) <= 1e-6 * m3ref
+
+
+def test_bench_gpus_8_and_total_samplings_on_one_device(tmp_path):
+    """The command lines of BASELINE configs 4 and 5 with everything but the node: `bench.py --gpus 8` without a launcher (ONE process,
+    eight contexts, hr_comm_init_local + hr_allreduce_accumulators — eight same-device contexts here, one RCCL group on an 8-GPU
+    node) and `--total-samplings S` (strong scaling: exactly samplings 1..S, sharded (s - 1) mod 8, last step clipped).  The summed
+    accumulator must equal a single-context run over the same sampling indices."""
+    j8, m8 = _bench_line(_run_bench(["--gpus", "8", "--steps", "2", "--no-counters"]))          # 2 steps x 2 samplings x 8 contexts = samplings 1..32
+    _, m1 = _bench_line(_run_bench(["--steps", "16", "--no-counters"]))
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "weak" and abs(m8 - m1) <= 1e-6 * m1, (m8, m1)
+    assert len(j8["multi_gpu"]["per_rank"]) == 8 and j8["config"]["samplings_total"] == 32
+    # strong scaling: 21 samplings over 8 contexts in 2 steps -> 2 per context per step, the second step clipped (ranks 0..4 get 3, 5..7 get 2)
+    js, ms = _bench_line(_run_bench(["--gpus", "8", "--steps", "2", "--total-samplings", "21", "--no-counters"]))
+    jr, mr = _bench_line(_run_bench(["--total-samplings", "21", "--steps", "3", "--no-counters"]))
+    assert js["scaling"] == "strong" and jr["scaling"] == "strong" and js["config"]["samplings_total"] == 21 == jr["config"]["samplings_total"]
+    assert js["config"]["paths_total"] == 160 * 90 * 4 * 21 and abs(ms - mr) <= 1e-6 * mr, (ms, mr)
+    assert sorted(x["paths"] // (160 * 90 * 4) for x in js["multi_gpu"]["per_rank"]) == [2, 2, 2, 3, 3, 3, 3, 3]
+    assert "clipped to --total-samplings 21" in js["config"]["workload"]
 
 
 def test_bench_multirank_path_on_one_gpu(tmp_path):
@@ -1067,6 +1096,42 @@ def test_rccl_allreduce_of_the_accumulator(gpu, scenes, ha):
         gpu.comm_destroy()
     with pytest.raises(ha.HipError):
         gpu.allreduce_accumulator()            # no communicator any more
+
+
+def test_rccl_group_path_of_one_process_driving_its_gpus(scenes, ha):
+    """The one-process form of the exchange — hr_comm_init_local + hr_allreduce_accumulators, what `python bench.py --gpus N` and the
+    CLI's --gpus use on a multi-GPU node — with ONE context: n = 1 is not "all contexts on one device" (that needs two), so the
+    call takes the RCCL branch: ncclCommInitAll over the device list, then ncclGroupStart / ncclAllReduce / ncclGroupEnd.  The
+    total must equal the context's own accumulator bit for bit; the communicator can be replaced and destroyed."""
+    sc, _ = scenes("cornell_mini")
+    r = ha.Renderer(0)
+    try:
+        r.upload_scene(sc)
+        r.set_resolution(96, 54)
+        r.render(1, 4)
+        own = r.read_accumulator()
+        ha.comm_init_local([r])
+        assert not r.total_device_ptr()
+        ha.allreduce_accumulators([r])
+        assert r.total_device_ptr() and r.total_device_ptr() != r.L.hr_accumulator_device_ptr(r._h)
+        assert np.array_equal(r.read_accumulator(), own) and own.sum() > 0
+        r.render(4, 6)
+        assert not r.total_device_ptr()
+        own2 = r.read_accumulator()
+        ha.allreduce_accumulators([r])                      # the communicator outlives a collective
+        assert np.array_equal(r.read_accumulator(), own2) and own2.sum() > own.sum()
+        assert r.resolve(5).std() > 1                       # hr_resolve reads the total
+        ha.comm_init_local([r])                             # a second init replaces the communicator (ncclCommDestroy + ncclCommInitAll)
+        ha.allreduce_accumulators([r])
+        assert np.array_equal(r.read_accumulator(), own2)
+        r.comm_destroy()
+        with pytest.raises(ha.HipError):
+            ha.allreduce_accumulators([r])
+        # a device listed twice next to another one is refused before RCCL sees it — only checkable with >= 2 devices; here: a null context
+        with pytest.raises(ha.HipError):
+            ha.comm_init_local([])
+    finally:
+        r.close()
 
 
 def test_same_device_group_sum(scenes, ha):
