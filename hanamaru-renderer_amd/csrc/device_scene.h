@@ -121,7 +121,7 @@ HD QNode qnode_sentinel(int octant) {
 struct alignas(16) Tri {
     float v0[3]; float e1x;
     float e1y, e1z, e2x, e2y;
-    float e2z; int32_t element; float pad0, pad1;
+    float e2z; int32_t element; uint32_t face; float pad1;   // face: index of the input triangle (over all meshes, in element order) — only the per-path event log reads it
 };
 
 // The records the kernels read for a triangle, derived from Tri (the fp32 triangle v0, v0 + e1, v0 + e2 IS the geometry: everything
@@ -168,11 +168,19 @@ struct CameraF {
     int32_t lens_shape;
 };
 
+// The camera once more in the reference's own precision (camera.rs:7-29 is f64): read only when a PRIMARY ray hits a sphere — the hit point
+// and normal are then taken from the exact camera ray (pt_core.h camera_ray_f64 / sphere_surface), not from its fp32 rounding.
+struct CameraD {
+    double eye[3], right[3], up[3], forward[3], phr[3], phu[3];
+    double lens_radius, focus_distance;
+};
+
 struct Scene {
     const QNode *qnodes;     // [8][num_nodes + 1], octant-major (host- and device-built trees alike); nullptr with option quant_nodes = 0
     float qmin[3], qstep[3]; // the grid of the quantised planes
     const Node *nodes;       // [8][num_nodes], octant-major
     const TriT *tris; const TriS *tri_shade;   // leaf-ordered, one pair per triangle reference
+    const uint32_t *tri_face;                  // leaf-ordered: index of the input triangle each reference belongs to (hr_debug_path_log only)
     const f4 *spheres; const int32_t *sphere_elem;
     const f4 *cuboids;       // 2 per cuboid: {min, element-as-int-bits}, {max, 0}
     const Material *materials;
@@ -190,6 +198,7 @@ struct Scene {
     const uint32_t *sky_quads;
     uint32_t sky_w, sky_h;
     CameraF cam;
+    const CameraD *camd;     // the camera in f64 (one small buffer in HBM)
 };
 
 // The priority governor's state, in device memory (hr_api.hip governor_kernel): the two kernels of a launch stamp their

@@ -78,14 +78,14 @@ static int ferr(std::string &err, int code, const char *fmt, ...) {
 }
 
 void HostScene::derive_triangles() {
-    tri_t.resize(tris.size()); tri_s.resize(tris.size());
-    for (size_t i = 0; i < tris.size(); i++) tri_derive(tris[i], tri_t[i], tri_s[i]);
+    tri_t.resize(tris.size()); tri_s.resize(tris.size()); tri_face.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) { tri_derive(tris[i], tri_t[i], tri_s[i]); tri_face[i] = tris[i].face; }
 }
 
 Scene HostScene::view() const {
     Scene d;
     memset(&d, 0, sizeof d);
-    d.nodes = nodes.data(); d.tris = tri_t.data(); d.tri_shade = tri_s.data();
+    d.nodes = nodes.data(); d.tris = tri_t.data(); d.tri_shade = tri_s.data(); d.tri_face = tri_face.data();
     d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
     for (int k = 0; k < 3; k++) { d.qmin[k] = qmin[k]; d.qstep[k] = qstep[k]; }
     d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.cuboids = cuboids.data();
@@ -96,6 +96,7 @@ Scene HostScene::view() const {
     d.sky_quads = sky_quads.empty() ? nullptr : sky_quads.data(); d.sky_w = sky_w; d.sky_h = sky_h;
     for (int k = 0; k < 3; k++) d.sky_intensity[k] = sky_intensity[k];
     d.cam = cam;
+    d.camd = &camd;
     return d;
 }
 
@@ -241,6 +242,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         d.e1x = (float)(s.v1[0] - s.v0[0]); d.e1y = (float)(s.v1[1] - s.v0[1]); d.e1z = (float)(s.v1[2] - s.v0[2]);
         d.e2x = (float)(s.v2[0] - s.v0[0]); d.e2y = (float)(s.v2[1] - s.v0[1]); d.e2z = (float)(s.v2[2] - s.v0[2]);
         d.element = s.elem;
+        d.face = bvh.order[0][i];
     }
     if (host_bvh) out.derive_triangles();   // (the device builders derive the records in their gather, in leaf order)
     out.spheres.resize(spheres.size()); out.sphere_elem.resize(spheres.size());
@@ -298,6 +300,12 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     f3(out.cam.eye, cam.eye); f3(out.cam.right, cam.right); f3(out.cam.up, cam.up); f3(out.cam.forward, cam.forward);
     f3(out.cam.phr, cam.plane_half_right); f3(out.cam.phu, cam.plane_half_up);
     out.cam.lens_radius = (float)cam.lens_radius; out.cam.focus_distance = (float)cam.focus_distance; out.cam.lens_shape = cam.lens_shape;
+    {
+        auto d3 = [](double *dst, const hr_vec3 &v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+        d3(out.camd.eye, cam.eye); d3(out.camd.right, cam.right); d3(out.camd.up, cam.up); d3(out.camd.forward, cam.forward);
+        d3(out.camd.phr, cam.plane_half_right); d3(out.camd.phu, cam.plane_half_up);
+        out.camd.lens_radius = cam.lens_radius; out.camd.focus_distance = cam.focus_distance;
+    }
     return HR_OK;
 }
 

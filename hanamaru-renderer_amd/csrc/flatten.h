@@ -19,6 +19,7 @@ struct HostScene {
     std::vector<Tri> tris;       // geometry records (leaf order with host_bvh, input order without): what the builders read
     std::vector<TriT> tri_t;     // derived from tris by derive_triangles(): what the kernels read (device_scene.h)
     std::vector<TriS> tri_s;
+    std::vector<uint32_t> tri_face;   // Tri::face per record
     void derive_triangles();
     std::vector<f4> spheres;
     std::vector<int32_t> sphere_elem;
@@ -32,6 +33,7 @@ struct HostScene {
     std::vector<uint32_t> sky_quads;   // Scene::sky_quads (empty when the faces differ in size)
     uint32_t sky_w = 0, sky_h = 0;
     CameraF cam;
+    CameraD camd;
     uint32_t bvh_max_depth = 0, bvh_leaves = 0;
     double bvh_sah_cost = 0;
     double scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};   // filled when host_bvh == false

@@ -137,15 +137,15 @@ __global__ void emit_kernel(int n, Work w, const float *frame, Node *nodes, QNod
 // primitive arrays -> leaf order per type (left-first depth-first order of the tree)
 // the triangle records the kernels read (device_scene.h), for triangles already in leaf order (host-built trees: the derivation runs
 // on the device for every builder, so that the same triangle gets the same bits whoever built the tree)
-__global__ void tri_derive_kernel(const Tri *in, uint32_t n, TriT *tris, TriS *tri_shade) {
+__global__ void tri_derive_kernel(const Tri *in, uint32_t n, TriT *tris, TriS *tri_shade, uint32_t *tri_face) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tri_derive(in[i], tris[i], tri_shade[i]);
+    if (i < n) { tri_derive(in[i], tris[i], tri_shade[i]); tri_face[i] = in[i].face; }
 }
-__global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_pos, int n, TriT *tris, TriS *tri_shade, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *cuboids) {
+__global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_pos, int n, TriT *tris, TriS *tri_shade, uint32_t *tri_face, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *cuboids) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t i = key_index(keys[k]), d = prim_pos[k];
-    if (i < p.num_tris) tri_derive(p.tris[p.ref_tri ? p.ref_tri[i] : i], tris[d], tri_shade[d]);
+    if (i < p.num_tris) { const Tri t = p.tris[p.ref_tri ? p.ref_tri[i] : i]; tri_derive(t, tris[d], tri_shade[d]); tri_face[d] = t.face; }
     else if (i < p.num_tris + p.num_spheres) {
         uint32_t l = i - p.num_tris;
         d -= p.num_tris;

@@ -320,7 +320,8 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
         const void *trace_variants[] = {(const void *)trace_kernel<false, 5, true>, (const void *)trace_kernel<false, 5, false>, (const void *)trace_kernel<false, 4, true>,
                                         (const void *)trace_kernel<false, 6, true>, (const void *)trace_kernel<true, 3, true>, (const void *)trace_kernel<true, 3, false>,
                                         (const void *)trace_kernel<false, 5, true, true>, (const void *)trace_kernel<false, 5, false, true>,
-                                        (const void *)trace_kernel<true, 3, true, true>, (const void *)trace_kernel<true, 3, false, true>};
+                                        (const void *)trace_kernel<true, 3, true, true>, (const void *)trace_kernel<true, 3, false, true>,
+                                        (const void *)trace_kernel<false, 3, true, false, true>, (const void *)trace_kernel<false, 3, false, false, true>};
         for (const void *f : trace_variants) {
             hipFuncAttributes fa;
             HIP_TRY(hipFuncGetAttributes(&fa, f));
@@ -446,6 +447,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     LBVH_ALLOC(qnodes, QNode, 8 * ((size_t)N + 1), true)
     LBVH_ALLOC(tris, TriT, p.num_tris, true)
     LBVH_ALLOC(tri_shade, TriS, p.num_tris, true)
+    LBVH_ALLOC(tri_face, uint32_t, p.num_tris, true)
     LBVH_ALLOC(spheres, f4, d.num_spheres, true)
     LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
     LBVH_ALLOC(cuboids, f4, 2 * (size_t)d.num_cuboids, true)
@@ -528,7 +530,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
         finish_kernel<<<(N + T - 1) / T, T, 0, st>>>(p, n, w, prim_pos);
         frame_kernel<<<1, 64, 0, st>>>(w, frame);
         emit_kernel<<<(8 * N + T - 1) / T, T, 0, st>>>(n, w, frame, nodes, qnodes);
-        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, tri_shade, spheres, sphere_elem, d.sphere_elem, cuboids);
+        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, tri_shade, tri_face, spheres, sphere_elem, d.sphere_elem, cuboids);
         e = hipGetLastError();
     }
     (void)hipEventRecord(eb, st);
@@ -548,7 +550,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     d.qnodes = c->quant_nodes ? qnodes : nullptr;
     for (int a = 0; a < 3; a++) { d.qmin[a] = hframe[a]; d.qstep[a] = hframe[3 + a]; }
 
-    d.tris = tris; d.tri_shade = tri_shade; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
+    d.tris = tris; d.tri_shade = tri_shade; d.tri_face = tri_face; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
     d.num_tris = p.num_tris;   // leaf-ordered records: one per reference (a split triangle appears once per piece)
     return HR_OK;
 }
@@ -578,6 +580,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.images, &d.images))) return r;
     if ((r = upload(c, hs.emitters, &d.emitters))) return r;
     if ((r = upload(c, hs.texels, &d.texels))) return r;
+    if ((r = upload(c, std::vector<CameraD>(1, hs.camd), &d.camd))) return r;
     if (!hs.sky_quads.empty()) { if ((r = upload(c, hs.sky_quads, &d.sky_quads))) return r; }
     else d.sky_quads = nullptr;
     c->bvh_build_ms = 0;
@@ -590,12 +593,15 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
         c->scene_allocs.push_back(tt);
         HIP_TRY(hipMalloc((void **)&tsh, std::max<size_t>(nt * sizeof(TriS), 16)));
         c->scene_allocs.push_back(tsh);
+        uint32_t *tfc = nullptr;
+        HIP_TRY(hipMalloc((void **)&tfc, std::max<size_t>(nt * sizeof(uint32_t), 16)));
+        c->scene_allocs.push_back(tfc);
         if (nt) {
-            lbvh::tri_derive_kernel<<<(unsigned)((nt + 255) / 256), 256, 0, c->stream>>>(tris_in, (uint32_t)nt, tt, tsh);
+            lbvh::tri_derive_kernel<<<(unsigned)((nt + 255) / 256), 256, 0, c->stream>>>(tris_in, (uint32_t)nt, tt, tsh, tfc);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
-        d.tris = tt; d.tri_shade = tsh;
+        d.tris = tt; d.tri_shade = tsh; d.tri_face = tfc;
         if ((r = upload(c, hs.nodes, &d.nodes))) return r;
         d.qnodes = nullptr;
         if (c->quant_nodes && hs.qnodes.size() * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "hr_upload_scene: the quantised BVH records exceed their 2^28-byte offset range (set quant_nodes = 0)");
@@ -1279,6 +1285,46 @@ int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
             o[1] = rec[rec_slot(lb, REC_HEAD + 2)];
             for (uint32_t d = 2; d < (uint32_t)DRAWS_PER_PATH; d++) o[d] = rec[rec_slot(lb, 2 * a + d)];
         }
+    return drain_events(c);
+}
+
+int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
+    // one sampling through the production pipeline — the seed kernel, then the LOG instantiation of trace_kernel (same traversal, same
+    // path_advance) — with every path's radiance, ray count and event log written out instead of being accumulated
+    if (!c || !host_out) return fail(HR_ERR_INVALID, "hr_debug_path_log: bad argument");
+    if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_debug_path_log: hr_set_resolution not called");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_debug_path_log: no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    RenderParams rp{};
+    rp.width = c->W; rp.height = c->H; rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
+    rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
+    rp.adv_den = c->adv_den; rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll; rp.kchunk = c->kchunk;
+    rp.pad[0] = c->seed_prio;
+    const uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    if ((rc = ensure_draws(c, tiles))) return rc;
+    if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u))) return rc;
+    rp.ovf_cap = c->ovf_cap;
+    if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
+    const size_t words = (size_t)c->W * c->H * 4u * 8u;
+    uint32_t *d_log = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_log, words * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d_log, 0, words * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_tile_counter, 0, sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) {
+        const uint32_t kch = c->kchunk ? c->kchunk : TRACE_KCHUNK;
+        const uint64_t units = (uint64_t)tiles * ((1u + kch - 1) / kch);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
+        dim3 g(grid), b(64 * TRACE_WAVES);
+        if (c->dsc.qnodes) hipLaunchKernelGGL((trace_kernel<false, 3, true, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+        else hipLaunchKernelGGL((trace_kernel<false, 3, false, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host_out, d_log, words * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_log);
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_path_log: %s", hipGetErrorString(e));
     return drain_events(c);
 }
 

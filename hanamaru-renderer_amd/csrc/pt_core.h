@@ -9,6 +9,10 @@
 // so that a wavefront can keep all 64 lanes in the traversal loop and refill finished lanes.
 #pragma once
 #include <math.h>
+#if defined(HR_PATH_VERBOSE)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #include "device_scene.h"
 #include "isaac_core.h"
@@ -285,7 +289,79 @@ struct Surf { V3f pos, n; float u, v; int32_t elem; };
 
 HD int32_t float_as_int(float f) { union { float f; int32_t i; } c; c.f = f; return c.i; }
 
-HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s) {
+// Sphere hits in the reference's precision.  hr_rsqrt_f64: v_rsq_f32 seed + one Newton step in f64 (1e-14), as hr_sqrt_f64.
+HD double hr_rsqrt_f64(double x) {
+    const double y0 = (double)HR_RSQ(fmaxf((float)x, 1e-30f));
+    return y0 * fma(-0.5 * x, y0 * y0, 1.5);
+}
+// Hit point and normal of a sphere hit, in f64 (scene.rs:58-66): the root is found again from the f64 ray — the closest-hit search's fp32
+// distance (sphere_test) only chose the sphere — so that neither the rounding of t (|t| 6e-8 along the ray) nor, for a primary ray, the
+// fp32 rounding of the camera ray (3e-8 x distance) reaches the normal, where a small sphere multiplies a position error by 1 / radius
+// and every further bounce off a small sphere multiplies it again (r = 0.1 at distance 5: x 100 per bounce — measured on the sphere
+// scenes by the per-path accounting of round 4: 1,800 ppm of the paths that took the reference's branches were off by more than 1e-3
+// before, 540 ppm after; what is left is the fp32 rounding of the sampled directions and of the draws themselves).
+struct SphHit { float px, py, pz, nx, ny, nz; };
+HD SphHit sphere_surface_f64(float sx, float sy, float sz, float sw, double ox, double oy, double oz, double dx, double dy, double dz) {
+    const double ax = ox - (double)sx, ay = oy - (double)sy, az = oz - (double)sz;
+    const double idd = 2.0 - fma(dx, dx, fma(dy, dy, dz * dz));
+    const double b = fma(ax, dx, fma(ay, dy, az * dz)) * idd;
+    const double qx = fma(-b, dx, ax), qy = fma(-b, dy, ay), qz = fma(-b, dz, az);
+    const double disc = fma((double)sw, (double)sw, -fma(qx, qx, fma(qy, qy, qz * qz))) * idd;
+    const double t = -b - hr_sqrt_f64(disc > 0.0 ? disc : 0.0);     // (a grazing hit the f64 ray just misses: the tangent point)
+    const double nx = fma(t, dx, ax), ny = fma(t, dy, ay), nz = fma(t, dz, az);
+    const double il = hr_rsqrt_f64(fma(nx, nx, fma(ny, ny, nz * nz)));
+    SphHit h;
+    h.px = (float)((double)sx + nx); h.py = (float)((double)sy + ny); h.pz = (float)((double)sz + nz);
+    h.nx = (float)(nx * il); h.ny = (float)(ny * il); h.nz = (float)(nz * il);
+    return h;
+}
+// NOT inlined on the device (as sphere_root: the f64 temporaries stay out of the shading code's register budget), one call per sphere hit;
+// the arguments are what the caller holds anyway — fp32 values and a pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_NOINLINE __device__ __attribute__((noinline))
+#else
+#define HR_NOINLINE inline
+#endif
+// any ray: the fp32 ray widened (exact)
+HR_NOINLINE SphHit sphere_surface(float sx, float sy, float sz, float sw, float ox, float oy, float oz, float dx, float dy, float dz) {
+    return sphere_surface_f64(sx, sy, sz, sw, (double)ox, (double)oy, (double)oz, (double)dx, (double)dy, (double)dz);
+}
+// a path's first ray: the camera ray itself, recomputed in f64 — camera.rs:83-96 for pixel (px, py), sub-sample `sub`, lens sample
+// (lens_x, lens_y) = the accepted (2u - 1, 2v - 1) of the record head (fp32: a lens offset is lens_radius x 3e-8 off, 1e-9 of a scene
+// unit); renderer.rs:34-36,53-54 for the normalised coordinate.  `cam`: the camera in the reference's precision (device_scene.h CameraD).
+HR_NOINLINE SphHit sphere_surface_primary(float sx, float sy, float sz, float sw, const CameraD *cam, uint32_t width, uint32_t height, uint32_t px, uint32_t py,
+                                          uint32_t sub, float lens_x, float lens_y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the pointer is wave-uniform, which a non-inlined function cannot know: made scalar by hand and read through the constant address
+    // space, so that the camera's 20 doubles are scalar loads into SGPRs (as vector loads they were 40 VGPRs and pushed the kernel into spills)
+    const unsigned long long cam_bits = (unsigned long long)cam;
+    typedef const __attribute__((address_space(4))) CameraD *CamConstPtr;
+    const CameraD c = *(CamConstPtr)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cam_bits >> 32)) << 32) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cam_bits));
+    width = (uint32_t)__builtin_amdgcn_readfirstlane((int)width); height = (uint32_t)__builtin_amdgcn_readfirstlane((int)height);
+#else
+    const CameraD &c = *cam;
+#endif
+    const double fx = (double)px, fy = (double)(height - py);
+    const double ox = (double)(sub & 1u) * 0.5 - 0.5, oy = (double)(sub >> 1) * 0.5 - 0.5;
+    const double m = (double)(width < height ? width : height);
+    double im = (double)HR_RCP((float)m);                       // one f64 reciprocal (v_rcp_f32 seed + two Newton steps) instead of two f64 divisions
+    im = im * (2.0 - m * im); im = im * (2.0 - m * im);
+    const double ncx = ((fx + ox) * 2.0 - (double)width) * im, ncy = ((fy + oy) * 2.0 - (double)height) * im;
+    const double lx = (double)lens_x * c.lens_radius, ly = (double)lens_y * c.lens_radius;
+    const double lpx = c.right[0] * lx + c.up[0] * ly, lpy = c.right[1] * lx + c.up[1] * ly, lpz = c.right[2] * lx + c.up[2] * ly;
+    const double vx = ncx * c.phr[0] + ncy * c.phu[0] + c.focus_distance * c.forward[0] - lpx;
+    const double vy = ncx * c.phr[1] + ncy * c.phu[1] + c.focus_distance * c.forward[1] - lpy;
+    const double vz = ncx * c.phr[2] + ncy * c.phu[2] + c.focus_distance * c.forward[2] - lpz;
+    const double il = hr_rsqrt_f64(fma(vx, vx, fma(vy, vy, vz * vz)));
+    return sphere_surface_f64(sx, sy, sz, sw, c.eye[0] + lpx, c.eye[1] + lpy, c.eye[2] + lpz, vx * il, vy * il, vz * il);
+}
+// what identifies a path's first ray to hit_surface (on == false: any other ray)
+struct PrimaryRay { bool on; uint32_t width, height, px, py, sub; float lens_x, lens_y; };
+HD PrimaryRay no_primary() { PrimaryRay q; q.on = false; q.width = q.height = q.px = q.py = q.sub = 0u; q.lens_x = q.lens_y = 0.0f; return q; }
+
+
+HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s, const PrimaryRay &pr) {
     s.pos = r.o + r.d * ts.t;
     s.u = ts.u; s.v = ts.v;
     if (ts.type == 0) {
@@ -295,14 +371,11 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
     } else if (ts.type == 1) {
         const f4 sp = sc.spheres[ts.prim];
         s.elem = sc.sphere_elem[ts.prim];
-        {   // the normal from the f64 offset of the hit from the centre (as sphere_test: o - c is exact in f64, and a small sphere far
-            // from the origin would otherwise divide the fp32 rounding of the position, ~|o| 6e-8, by its radius)
-            const double t = ts.t;
-            const double nx = ((double)r.o.x - (double)sp.x) + t * (double)r.d.x, ny = ((double)r.o.y - (double)sp.y) + t * (double)r.d.y, nz = ((double)r.o.z - (double)sp.z) + t * (double)r.d.z;
-            const double l2 = fma(nx, nx, fma(ny, ny, nz * nz));
-            const double y0 = (double)HR_RSQ(fmaxf((float)l2, 1e-30f));
-            const double il = y0 * fma(-0.5 * l2, y0 * y0, 1.5);
-            s.n = v3((float)(nx * il), (float)(ny * il), (float)(nz * il));
+        {
+            const SphHit h = pr.on ? sphere_surface_primary(sp.x, sp.y, sp.z, sp.w, sc.camd, pr.width, pr.height, pr.px, pr.py, pr.sub, pr.lens_x, pr.lens_y)
+                                   : sphere_surface(sp.x, sp.y, sp.z, sp.w, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
+            s.pos = v3(h.px, h.py, h.pz);
+            s.n = v3(h.nx, h.ny, h.nz);
         }
         if (want_uv) {  // scene.rs:67-71
             s.v = 1.0f - acosf(fminf(fmaxf(s.n.y, -1.0f), 1.0f)) * (1.0f / PI_F);
@@ -336,6 +409,8 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         }
     }
 }
+
+HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s) { hit_surface(sc, r, ts, want_uv, s, no_primary()); }
 
 // ---------------------------------------------------------------------------------------------
 // textures — texture.rs:29-63, color.rs:18-36
@@ -460,7 +535,10 @@ HD float bsdf_eval(int32_t surface, float param, float roughness, V3f view, V3f 
     return d * g_smith_joint(ln, vn, alpha2) * f_schlick(vh, param) * HR_RCP(4.0f * ln * vn);
 }
 // material.rs:154-199
-HD void sample_refraction(float r0, V3f pos, V3f view, V3f n, float ior, V3f &no, V3f &nd, float &refl) {
+// `transmitted`: true when the ray leaves along the refracted direction (false: Fresnel reflection or total internal reflection) —
+// only the per-path event log reads it (PathLog below); dead in every other instantiation
+HD void sample_refraction(float r0, V3f pos, V3f view, V3f n, float ior, V3f &no, V3f &nd, float &refl, bool &transmitted) {
+    transmitted = false;
     bool incoming = signbit(dot(view, n));
     V3f on = incoming ? n : -n;
     float nnt = incoming ? HR_RCP(ior) : ior;
@@ -474,15 +552,16 @@ HD void sample_refraction(float r0, V3f pos, V3f view, V3f n, float ior, V3f &no
     float a = nnt * cos_i - cos_t, b = nnt * cos_i + cos_t, c = nnt * cos_t - cos_i, d = nnt * cos_t + cos_i;
     float fr = 0.5f * (a * a * HR_RCP(b * b) + c * c * HR_RCP(d * d));
     if (r0 <= fr) { no = pos + OFFSET_F * on; nd = rdir; refl = 1.0f; }
-    else { no = pos - OFFSET_F * on; nd = tdir; refl = nnt * nnt; }
+    else { no = pos - OFFSET_F * on; nd = tdir; refl = nnt * nnt; transmitted = true; }
 }
 // material.rs:91-151; returns false for "sampled below the horizon" (None)
-HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3f n, V3f &no, V3f &nd, float &refl) {
+HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3f n, V3f &no, V3f &nd, float &refl, bool &transmitted) {
     V3f in = -view;
+    transmitted = false;
     switch (m.surface) {
         case 0: no = pos + n * OFFSET_F; nd = sample_diffuse(r0, r1, n); refl = 1.0f; return true;
         case 1: no = pos + n * OFFSET_F; nd = reflect(in, n); refl = 1.0f; return true;
-        case 2: sample_refraction(r0, pos, in, n, m.param, no, nd, refl); return true;
+        case 2: sample_refraction(r0, pos, in, n, m.param, no, nd, refl, transmitted); return true;
         case 3: {
             float alpha2 = m.roughness * m.roughness;
             V3f h = sample_ggx_half(r0, r1, n, alpha2);
@@ -496,7 +575,7 @@ HD bool bsdf_sample(const PointMat &m, float r0, float r1, V3f pos, V3f view, V3
         }
         default: {
             V3f h = sample_ggx_half(r0, r1, n, m.roughness * m.roughness);
-            sample_refraction(r0, pos, in, h, m.param, no, nd, refl);
+            sample_refraction(r0, pos, in, h, m.param, no, nd, refl, transmitted);
             return true;
         }
     }
@@ -583,6 +662,25 @@ HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
     return (ts.type == 0) ? sc.tri_shade[ts.prim].element : (ts.type == 1 ? sc.sphere_elem[ts.prim] : float_as_int(sc.cuboids[2 * ts.prim].w));
 }
 
+// Per-path event log (hr_debug_path_log: the parity accounting of tests/test_gpu_parity.py and profiles/r04_parity_report.json).  The
+// oracle keeps the same log (oracle.cpp PathLog): two paths "took the same branches" when their logs are equal.
+//   one byte per iteration i = 1..9 (renderer.rs:174), byte i - 1 of ev (i <= 8) / ev9:
+//     bits 0-2  0 = iteration not reached, 1 = the ray missed (sky), 2 + surface type = hit and sampled (2 Diffuse, 3 Specular, 4 Refraction,
+//               5 GGX, 6 GGXRefraction), 7 = hit, PointMaterial::sample returned None (GGX half vector below the horizon, material.rs:119-121)
+//     bit  3    Refraction / GGXRefraction: the ray was transmitted (0: Fresnel reflection or total internal reflection, material.rs:163-199)
+//     bits 4-7  NEE (Diffuse / GGX only): bit 4 + (k mod 4) set when the shadow ray towards emitter k passed the visibility test of renderer.rs:280
+//   hash: FNV-style hash over the element indices — and, for meshes, the input triangle indices — the main rays hit, in order (another
+//         sphere of the same material, or the neighbouring triangle with another normal, is another branch)
+//   rays: scene.intersect calls of the path (main + shadow rays)
+//   ev9 bits 8-15: how many of the path's main rays hit a SPHERE (the one primitive that multiplies a position error by 1 / radius)
+struct PathLog { unsigned long long ev; uint32_t ev9, hash, rays; };
+HD void plog_reset(PathLog &l) { l.ev = 0ull; l.ev9 = 0u; l.hash = 0x811c9dc5u; l.rays = 0u; }
+HD void plog_or(PathLog &l, uint32_t iter, uint32_t bits) {
+    if (iter <= 8u) l.ev |= (unsigned long long)bits << ((iter - 1u) * 8u);
+    else l.ev9 |= bits;
+}
+HD void plog_hit(PathLog &l, int32_t elem) { l.hash = (l.hash ^ (uint32_t)(elem + 1)) * 0x01000193u; }
+
 // returns true when the path is finished (accum final)
 // RR / rr_start: Russian roulette from that iteration on (off = the reference's estimator: renderer.rs:174-200 has none).  A template
 // parameter: the roulette's few instructions in the default kernel cost it 2 % next to the seed kernel (measured), so the default
@@ -595,23 +693,38 @@ HD float rr_uniform(uint32_t tile, uint32_t q, uint32_t salt, uint32_t iter) {
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-template <bool CNT, bool RR = false>
-HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *cn, uint32_t rr_start = 0u, uint32_t rr_salt = 0u) {
+template <bool CNT, bool RR = false, bool LOG = false>
+HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const float *recs, LaneCounters *cn, uint32_t rr_start = 0u, uint32_t rr_salt = 0u, PathLog *lg = nullptr) {
     if (CNT) cn->rays++;
+    if (LOG) lg->rays++;
     const bool hit = p.ts.prim >= 0;
+#if defined(HR_PATH_VERBOSE) && !defined(__HIP_DEVICE_COMPILE__)   // host emulation only: one line per finished ray of the path HR_V selects (tests/emu)
+    if (getenv("HR_V")) fprintf(stderr, "HIP it %u shadow %d hit %d t %.9g o %.9g %.9g %.9g d %.9g %.9g %.9g accum %.9g %.9g %.9g refl %.9g %.9g %.9g\n", path_iter(p), (int)path_in_shadow_phase(p), (int)hit, p.ts.t, p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.d.x, p.ray.d.y, p.ray.d.z, p.accum.x, p.accum.y, p.accum.z, p.refl.x, p.refl.y, p.refl.z);
+#endif
     if (!path_in_shadow_phase(p)) {
         const f2v r01 = *reinterpret_cast<const f2v *>(recs + rec_slot(path_draw_base(p), ((p.q >> 12) & 15u) + 2u * path_iter(p)));   // renderer.rs:175
         p.r0 = r01[0]; p.r1 = r01[1];
         if (!hit) {  // scene.rs:398 + renderer.rs:196,199
+            if (LOG) plog_or(*lg, path_iter(p), 1u);
             p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
             return true;
         }
         Surf s;
-        hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, hit_element(sc, p.ts)), s);
+        PrimaryRay pr = no_primary();
+        if (p.ts.type == 1 && path_iter(p) == 1u) {   // a primary ray on a sphere: hit point and normal from the camera ray itself, in f64
+            pr.on = true; pr.width = rp.width; pr.height = rp.height;
+            tile_lane_pixel(rp, p.tile, p.q & 63u, pr.px, pr.py, pr.sub);
+            const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(path_draw_base(p), REC_HEAD));
+            pr.lens_x = head.y; pr.lens_y = head.z;
+        }
+        hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, hit_element(sc, p.ts)), s, pr);
         PointMat m;
         material_at(sc, s.elem, s.u, s.v, m);
         p.view = -p.ray.d;
-        if (!bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, p.cur_refl)) return true;  // renderer.rs:190-193
+        bool transmitted;
+        const bool sampled = bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, p.cur_refl, transmitted);
+        if (LOG) { plog_hit(*lg, s.elem); if (p.ts.type == 1) lg->ev9 += 256u; if (p.ts.type == 0) plog_hit(*lg, (int32_t)(sc.tri_face[p.ts.prim] + 0x9e3779b9u)); plog_or(*lg, path_iter(p), sampled ? (2u + (uint32_t)m.surface) | (transmitted ? 8u : 0u) : 7u); }
+        if (!sampled) return true;  // renderer.rs:190-193
         p.accum = p.accum + p.refl * m.emission;          // renderer.rs:196
         p.refl = p.refl * m.albedo;                       // renderer.rs:183,295 (NEE scale) and the first factor of :197
         if (nee_available(m.surface) && sc.num_emitters > 0) {
@@ -639,6 +752,7 @@ HD bool path_advance(const Scene &sc, Path &p, const float *recs, LaneCounters *
             float inv_pdf = 4.0f * PI_F * em.r * em.r;
             float w = bsdf_eval(path_surface(p), p.param, p.roughness, p.view, p.n, p.ray.d) * g * inv_pdf;
             p.accum = p.accum + p.refl * (e * w);
+            if (LOG) plog_or(*lg, path_iter(p), 16u << (path_emitter(p) & 3u));
         }
         p.st += 256u;     // next emitter
         if (path_emitter(p) < sc.num_emitters) { nee_setup(sc, p); return false; }

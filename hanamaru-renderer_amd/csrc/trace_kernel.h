@@ -114,8 +114,11 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uin
     }
 }
 
-template <bool CNT, int MINW, bool QN, bool RR = false>
-__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter) {
+// LOG (hr_debug_path_log only): every path also leaves its event log (pt_core.h PathLog) and its own radiance in plog — eight 32-bit
+// words per path, indexed ((y * W + x) * 4 + sub-sample) for the launch's first sampling: {r, g, b (float bits), rays, ev low, ev high, ev9, hash}.
+// The same kernel, the same path_advance: what is logged is what hr_render computes.
+template <bool CNT, int MINW, bool QN, bool RR = false, bool LOG = false>
+__global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter, uint32_t *plog = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     LaneCounters lc = {0, 0, 0, 0, 0};
@@ -131,6 +134,8 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     p.q = PATH_IDLE;
     p.tile = 0;
     p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0;
+    PathLog lg;
+    plog_reset(lg);
     const uint32_t adv_den = rp.adv_den ? rp.adv_den : 2u;
     const uint32_t leaf_den = rp.leaf_den ? rp.leaf_den : 2u;
     uint32_t tick = threadIdx.x >> 6;   // wave-uniform count of box phases (the boost's duty cycle); the waves of a workgroup start out of step
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         }
         HR_PHASE_BEGIN(ws);
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
-            if (path_advance<CNT, RR>(sc, p, recs + (size_t)p.tile * tile_stride, &lc, rp.rr_start, rp.sampling_begin * 64u + rp.stride)) {
+            if (path_advance<CNT, RR, LOG>(sc, rp, p, recs + (size_t)p.tile * tile_stride, &lc, rp.rr_start, rp.sampling_begin * 64u + rp.stride, &lg)) {
                 // A finished path leaves its radiance in its own hand-off record (quad 0: the draws there have been consumed), and
                 // accumulate_kernel below sums the records of a pixel into the accumulator behind this kernel.  Until round 3 the path
                 // added its radiance straight into the accumulator with three agent-scope atomics (several waves, on other XCDs,
@@ -163,6 +168,13 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 // kernel beside it another 1.5 % (measured by leaving them out).  The store is one 16-byte write per path, the sum
                 // a 0.1-ms pass over 0.5 GB — and the summation order is fixed now: renders are bit-reproducible.
                 *reinterpret_cast<f4 *>(recs + (size_t)p.tile * tile_stride + rec_slot(path_draw_base(p), 0)) = f4{p.accum.x, p.accum.y, p.accum.z, 0.0f};
+                if (LOG && ((p.q >> 6) & 63u) == 0u) {   // the launch's first sampling
+                    uint32_t px, py, sub;
+                    tile_lane_pixel(rp, p.tile, p.q & 63u, px, py, sub);
+                    uint32_t *o = plog + (((size_t)py * rp.width + px) * 4u + sub) * 8u;
+                    o[0] = float_as_uint(p.accum.x); o[1] = float_as_uint(p.accum.y); o[2] = float_as_uint(p.accum.z); o[3] = lg.rays;
+                    o[4] = (uint32_t)lg.ev; o[5] = (uint32_t)(lg.ev >> 32); o[6] = lg.ev9; o[7] = lg.hash;
+                }
                 p.q = PATH_IDLE;
             }
         }
@@ -192,6 +204,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                         p.q = (k << 6) | j;   // slot inside the tile's batch (bits 0-5: lane of the tile -> pixel, sub-sample)
                         p.tile = cur_tile;
                         path_start(sc, rp, p, px, py, sub, recs + (size_t)cur_tile * tile_stride);
+                        if (LOG) plog_reset(lg);
                         npaths++;
                     }
                 }

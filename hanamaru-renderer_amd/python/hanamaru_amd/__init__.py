@@ -144,6 +144,7 @@ def hip_lib():
         L.hr_debug_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hr_debug_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.hr_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hr_debug_path_log.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.hr_comm_get_unique_id.argtypes = [C.c_void_p]
         L.hr_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.hr_comm_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -364,6 +365,15 @@ class Renderer:
         out = np.empty((num_paths, window), dtype=np.uint64)
         self._check(self.L.hr_debug_draws(self._h, sampling, first_path, num_paths, window, out.ctypes.data))
         return out
+
+    def debug_path_log(self, sampling):
+        """hr_debug_path_log: (radiance [H, W, 4, 3] float32, rays [H, W, 4] uint32, events [H, W, 4, 10] uint8 — nine event bytes + the count of sphere hits —, hash [H, W, 4] uint32) of every
+        path of one sampling, from the render kernel's logging instantiation."""
+        raw = np.zeros((self.height, self.width, 4, 8), dtype=np.uint32)
+        self._check(self.L.hr_debug_path_log(self._h, sampling, raw.ctypes.data))
+        rad = raw[..., 0:3].copy().view(np.float32)
+        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(self.height, self.width, 4, 12)[..., :10]
+        return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
 
     def debug_intersect(self, rays):
         r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 4
+#define HR_ABI_VERSION 5
 
 typedef enum hr_status {
     HR_OK = 0,
@@ -247,6 +247,14 @@ int hr_debug_draws(hr_ctx *ctx, uint32_t sampling, uint32_t first_path, uint32_t
  * sampling: out[((y*W + x)*4 + sub)*20 + d]; d=0,1 = accepted lens sample (2u-1, 2v-1) after the rejection
  * loop of camera.rs:66-81, d=2.. = the (f64,f64) pairs of renderer.rs:175 in order. */
 int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
+
+/* Per-path accounting of ONE sampling through the production pipeline (seed kernel + the render kernel's LOG instantiation: the same
+ * traversal and the same path state machine as hr_render; the accumulator is not touched).  out: W*H*4 records of eight 32-bit words,
+ * record ((y*W + x)*4 + sy*2 + sx) = { radiance r, g, b (float bits) of calc_pixel (renderer.rs:163-203), scene.intersect calls of the path
+ * (main + shadow rays), event log bytes 0-3, 4-7, 8 (one byte per iteration of renderer.rs:174, see pt_core.h PathLog: miss / surface type
+ * hit / sample returned None, reflected or transmitted, which emitters' shadow rays were visible), hash of the element indices hit }.
+ * The oracle keeps the same log (orc_path_log): tests/test_gpu_parity.py compares path by path. */
+int hr_debug_path_log(hr_ctx *ctx, uint32_t sampling, uint32_t *host_out);
 
 /* Closest-hit query for n rays (scene.rs:385-401 minus the material fetch).
  * rays: n * 6 floats (origin, direction).  out per ray: 8 floats

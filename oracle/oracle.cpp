@@ -196,6 +196,7 @@ struct PointMaterial {                 // material.rs:25-31
 };
 struct Intersection {                  // scene.rs:11-18
     V3 position; double distance; V3 normal; double u, v; PointMaterial material;
+    long face = -1;   // bookkeeping for the path log only: the mesh face of the closest triangle hit so far (not a field of scene.rs:11-18)
 };
 static Intersection intersection_empty() {  // scene.rs:26-39
     Intersection i;
@@ -253,6 +254,7 @@ struct Element {
     std::vector<V3> vertexes;     // mesh
     std::vector<size_t> faces;    // 3 per face
     std::unique_ptr<BvhNode> bvh; // BvhMesh
+    size_t face_base = 0;         // path log only: faces of the meshes before this one (element order) — the HIP side's input triangle index
 };
 
 struct Scene {
@@ -455,8 +457,10 @@ static bool intersect_for_mesh(const BvhNode &n, const Element &m, const Ray &ra
     bool any_hit = false;
     if (n.leaf()) {
         for (size_t fi : n.indexes)
-            if (intersect_polygon(m.vertexes[m.faces[fi * 3]], m.vertexes[m.faces[fi * 3 + 1]], m.vertexes[m.faces[fi * 3 + 2]], ray, isect, cn))
+            if (intersect_polygon(m.vertexes[m.faces[fi * 3]], m.vertexes[m.faces[fi * 3 + 1]], m.vertexes[m.faces[fi * 3 + 2]], ray, isect, cn)) {
                 any_hit = true;
+                isect.face = (long)fi;
+            }
     } else {
         for (int c = 0; c < 2; c++)
             if (intersect_for_mesh(*n.children[c], m, ray, isect, cn)) any_hit = true;
@@ -558,7 +562,7 @@ static double material_bsdf(const PointMaterial &m, V3 view, V3 normal, V3 light
     }
     return 0.0;  // unimplemented!() in the reference; unreachable because nee_available() gates the call
 }
-struct SampleResult { Ray ray; double reflectance; };
+struct SampleResult { Ray ray; double reflectance; bool transmitted = false; };   // transmitted: bookkeeping for the path log only
 static bool sample_refraction(double r0, V3 position, V3 view, V3 normal, double ior, SampleResult &out) {  // :154-199
     bool is_incoming = sign_negative(dot(view, normal));
     V3 oriented_normal = is_incoming ? normal : -normal;
@@ -584,6 +588,7 @@ static bool sample_refraction(double r0, V3 position, V3 view, V3 normal, double
         out.ray.origin = position - OFFSET * oriented_normal;
         out.ray.direction = refract_direction;
         out.reflectance = nnt * nnt;
+        out.transmitted = true;
     }
     return true;
 }
@@ -656,9 +661,12 @@ static Surface sample_on_surface(const Element &e, double r0, double r1) {
 }
 
 // renderer.rs:269-296
-static V3 next_event_estimation(const Scene &s, double r0, double r1, V3 position, V3 view, V3 normal, const PointMaterial &material, Counters *cn) {
+static V3 next_event_estimation(const Scene &s, double r0, double r1, V3 position, V3 view, V3 normal, const PointMaterial &material, Counters *cn,
+                                uint32_t *visible_mask = nullptr) {
     V3 accumulation;
+    size_t k_em = 0;
     for (size_t ei : s.emissions) {
+        const size_t k = k_em++;
         Surface surface = sample_on_surface(s.elements[ei], r0, r1);
         V3 shadow_vec = surface.position - position;
         V3 shadow_dir = normalize(shadow_vec);
@@ -673,13 +681,22 @@ static V3 next_event_estimation(const Scene &s, double r0, double r1, V3 positio
             double g = (dot_0 * dot_l) / distance_pow2;
             double pdf = surface.pdf;
             accumulation = accumulation + si.material.emission * material_bsdf(material, view, normal, shadow_dir) * g / pdf;
+            if (visible_mask) *visible_mask |= 16u << (k & 3u);
         }
     }
     return accumulation * material.albedo;
 }
 
+// Per-path event log — bookkeeping beside the algorithm, no influence on it.  Same encoding as the HIP path's log
+// (hanamaru-renderer_amd/csrc/pt_core.h PathLog): one byte per iteration of renderer.rs:174 — bits 0-2: 0 not reached, 1 miss, 2 + surface type =
+// hit and sampled, 7 = hit and PointMaterial::sample returned None; bit 3: transmitted (Refraction / GGXRefraction); bits 4-7: NEE visibility of
+// emitter k in bit 4 + (k mod 4) — plus an FNV-style hash of the element indices hit and the number of scene.intersect calls.
+struct PathLog {
+    uint8_t ev[9]; uint32_t hash, rays, sphere_hits;   // sphere_hits: main rays that hit a sphere (word 3, bits 8-15)
+    PathLog() { memset(ev, 0, sizeof ev); hash = 0x811c9dc5u; rays = 0; sphere_hits = 0; }
+};
 // renderer.rs:163-203
-static V3 calc_pixel(const Scene &s, double ncx, double ncy, uint32_t sampling, Counters *cn) {
+static V3 calc_pixel(const Scene &s, double ncx, double ncy, uint32_t sampling, Counters *cn, PathLog *lg = nullptr) {
     uint64_t seed[4] = {8700304ULL, (uint64_t)sampling, (uint64_t)((4.0 + ncx) * 100870.0), (uint64_t)((4.0 + ncy) * 100304.0)};
     Isaac64 rng;
     rng.from_seed(seed, 4);
@@ -691,18 +708,33 @@ static V3 calc_pixel(const Scene &s, double ncx, double ncy, uint32_t sampling, 
         double r1 = rng.next_f64();
         Intersection isect;
         if (cn) { if (it == 1) cn->rays_primary++; else cn->rays_bounce++; }
-        bool hit = scene_intersect(s, ray, isect, nullptr, cn);
+        long element = -1;
+        bool hit = scene_intersect(s, ray, isect, &element, cn);
+        if (lg) { lg->rays++; if (!hit) lg->ev[it - 1] = 1; }
+        static const bool verbose = getenv("HR_ORACLE_VERBOSE") != nullptr;   // debugging aid (read once): one line per ray of every path traced
+        if (verbose) fprintf(stderr, "ORC it %u hit %d t %.9g o %.9g %.9g %.9g d %.9g %.9g %.9g accum %.9g %.9g %.9g refl %.9g %.9g %.9g n %.9g %.9g %.9g\n", it, (int)hit, isect.distance, ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z, accumulation.x, accumulation.y, accumulation.z, reflectance.x, reflectance.y, reflectance.z, isect.normal.x, isect.normal.y, isect.normal.z);
         double current_reflectance = 1.0;
         if (hit) {
             if (cn) cn->surface_hits++;
             V3 view = -ray.direction;
             SampleResult result;
+            if (lg) {
+                lg->hash = (lg->hash ^ (uint32_t)(element + 1)) * 0x01000193u;
+                if (s.elements[element].kind == HR_SPHERE) lg->sphere_hits++;
+                if (s.elements[element].kind == HR_MESH)
+                    lg->hash = (lg->hash ^ ((uint32_t)(s.elements[element].face_base + (size_t)isect.face) + 0x9e3779b9u + 1u)) * 0x01000193u;
+            }
             if (material_sample(isect.material, r0, r1, isect.position, view, isect.normal, result)) {
-                if (nee_available(isect.material))
-                    accumulation = accumulation + reflectance * next_event_estimation(s, r0, r1, result.ray.origin, view, isect.normal, isect.material, cn);
+                uint32_t visible = 0;
+                if (nee_available(isect.material)) {
+                    accumulation = accumulation + reflectance * next_event_estimation(s, r0, r1, result.ray.origin, view, isect.normal, isect.material, cn, &visible);
+                    if (lg) lg->rays += (uint32_t)s.emissions.size();
+                }
+                if (lg) lg->ev[it - 1] = (uint8_t)((2u + (uint32_t)isect.material.surface) | (result.transmitted ? 8u : 0u) | visible);
                 ray = result.ray;
                 current_reflectance = result.reflectance;
             } else {
+                if (lg) lg->ev[it - 1] = 7;
                 break;
             }
         }
@@ -807,10 +839,13 @@ ORC_API int orc_scene_create(const hr_scene_desc *d, orc_scene **out) {
     }
     auto tex = [&](const hr_texture &t) { return Texture{V3(t.color), t.image >= 0 ? &s.images[t.image] : nullptr}; };
     s.elements.resize(d->num_elements);
+    size_t face_base = 0;
     for (uint32_t i = 0; i < d->num_elements; i++) {
         const hr_element &e = d->elements[i];
         Element &o = s.elements[i];
         o.kind = e.kind;
+        o.face_base = face_base;
+        if (e.kind == HR_MESH) face_base += e.num_faces;
         o.material = Material{e.material.surface, e.material.param, tex(e.material.albedo), tex(e.material.emission), tex(e.material.roughness)};
         o.center = V3(e.center); o.radius = e.radius;
         o.box = Aabb{V3(e.aabb_min), V3(e.aabb_max)};
@@ -978,6 +1013,43 @@ ORC_API int orc_calc_pixel(const orc_scene *os, uint32_t W, uint32_t H, uint32_t
     normalized_coord(W, H, x, y, sx, sy, ncx, ncy);
     V3 c = calc_pixel(os->s, ncx, ncy, sampling, nullptr);
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+    return 0;
+}
+
+// every path of ONE sampling with its event log (PathLog above): radiance[(y*W + x)*4 + sy*2 + sx][3] (f64), and per path rays, 9 event
+// bytes (padded to 12) and the element hash as words[.][5] = {rays, ev 0-3, ev 4-7, ev 8, hash} — the layout of hr_debug_path_log minus the radiance
+ORC_API int orc_path_log(const orc_scene *os, uint32_t W, uint32_t H, uint32_t sampling, int nthreads, double *radiance, uint32_t *words) {
+    if (!os || !radiance || !words || !W || !H) return -1;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    const Scene &s = os->s;
+    std::atomic<uint32_t> next{0};
+    const uint32_t total = W * H;
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= total) break;
+            const uint32_t x = i % W, y = i / W;
+            for (uint32_t sy = 0; sy < SUPERSAMPLING; sy++)
+                for (uint32_t sx = 0; sx < SUPERSAMPLING; sx++) {
+                    double ncx, ncy;
+                    normalized_coord(W, H, x, y, sx, sy, ncx, ncy);
+                    PathLog lg;
+                    const V3 c = calc_pixel(s, ncx, ncy, sampling, nullptr, &lg);
+                    const size_t p = (size_t)i * 4 + sy * 2 + sx;
+                    radiance[p * 3] = c.x; radiance[p * 3 + 1] = c.y; radiance[p * 3 + 2] = c.z;
+                    uint32_t *w = words + p * 5;
+                    w[0] = lg.rays;
+                    w[1] = lg.ev[0] | (uint32_t)lg.ev[1] << 8 | (uint32_t)lg.ev[2] << 16 | (uint32_t)lg.ev[3] << 24;
+                    w[2] = lg.ev[4] | (uint32_t)lg.ev[5] << 8 | (uint32_t)lg.ev[6] << 16 | (uint32_t)lg.ev[7] << 24;
+                    w[3] = lg.ev[8] | lg.sphere_hits << 8;
+                    w[4] = lg.hash;
+                }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto &t : th) t.join();
     return 0;
 }
 

@@ -33,11 +33,19 @@ struct ArrMem {
     void st8(int i, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) { m[i] = A; m[i + 1] = B; m[i + 2] = C; m[i + 3] = D; m[i + 4] = E; m[i + 5] = F; m[i + 6] = G; m[i + 7] = H; }
 };
 // one hand-off record (device_scene.h) and a window of raw outputs for the fix-up path
-struct ArrRec {   // lane 0 of a one-item block in the device layout [quad][64 lanes][4]
+struct ArrRec {   // one lane (base = 4 * lane) of a one-item block in the device layout [quad][64 lanes][4]
     float f[REC_ITEM_FLOATS];
-    void st4(int slot, float a, float b, float c, float d) { float *q = f + rec_slot(0, (uint32_t)slot); q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
-    float at(int slot) const { return f[rec_slot(0, (uint32_t)slot)]; }
+    uint32_t base = 0;
+    void st4(int slot, float a, float b, float c, float d) { float *q = f + rec_slot(base, (uint32_t)slot); q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+    float at(int slot) const { return f[rec_slot(base, (uint32_t)slot)]; }
 };
+// the path of pixel (x, y), sub-sample `sub` as the kernel addresses it: tile, lane of the tile (Path::q bits 0-5), record lane base
+static void emu_place_path(RenderParams &rp, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sub, Path &p, ArrRec &rec) {
+    rp.width = W; rp.height = H; rp.tiles_x = (W + 3) / 4; rp.tiles_y = (H + 3) / 4;
+    p.tile = (y / 4) * rp.tiles_x + x / 4;
+    p.q = ((y % 4) * 4 + x % 4) * 4 + sub;
+    rec.base = p.q * 4u;
+}
 struct ArrWindow { u64 t[ISAAC_TAIL]; void put(int step, u64 v) { t[255 - step] = v; } u64 ld(int k) const { return t[k]; } };
 
 // what the seed kernel (+ the fix-up kernel for the paths it queues) produces for one path: the record
@@ -336,13 +344,14 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
                     for (uint32_t sub = 0; sub < 4; sub++) {
                         ArrRec rec;
                         Path p;
-                        p.q = 0;
+                        RenderParams rpp = rp;
+                        emu_place_path(rpp, W, H, x, y, sub, p, rec);
                         path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
-                        path_start(sc, rp, p, x, y, sub, rec.f);
+                        path_start(sc, rpp, p, x, y, sub, rec.f);
                         LaneCounters lc = {0, 0, 0, 0, 0};
                         for (;;) {
                             while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
-                            if (path_advance<true>(sc, p, rec.f, &lc)) break;
+                            if (path_advance<true>(sc, rpp, p, rec.f, &lc)) break;
                         }
                         sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
                         cn[tid][0]++; cn[tid][1] += lc.rays; cn[tid][2] += lc.node_tests; cn[tid][3] += lc.tri_tests;
@@ -359,6 +368,49 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
     }
     if (counters)
         for (int k = 0; k < 6; k++) { counters[k] = 0; for (auto &c : cn) counters[k] += c[k]; }
+    return 0;
+}
+
+// hr_debug_path_log's layout from the emulated render: eight words per path {r, g, b (float bits), rays, ev 0-3, ev 4-7, ev 8, hash}
+// (path_advance<.., LOG> of pt_core.h — the code the kernel's LOG instantiation runs)
+int emu_path_log(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, int nthreads, uint32_t *out) {
+    Scene sc = e->view;
+    sc.qnodes = nullptr;
+    RenderParams rp{};
+    rp.width = W; rp.height = H;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            uint32_t y = next.fetch_add(1);
+            if (y >= H) break;
+            for (uint32_t x = 0; x < W; x++)
+                for (uint32_t sub = 0; sub < 4; sub++) {
+                    ArrRec rec;
+                    Path p;
+                    RenderParams rpp = rp;
+                    emu_place_path(rpp, W, H, x, y, sub, p, rec);
+                    path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
+                    path_start(sc, rpp, p, x, y, sub, rec.f);
+                    LaneCounters lc = {0, 0, 0, 0, 0};
+                    PathLog lg;
+                    plog_reset(lg);
+#if defined(HR_PATH_VERBOSE)
+                    if (getenv("HR_VPIX")) { if ((uint32_t)atoi(getenv("HR_VPIX")) == (y * W + x) * 4 + sub) setenv("HR_V", "1", 1); else unsetenv("HR_V"); }
+#endif
+                    for (;;) {
+                        while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
+                        if (path_advance<true, false, true>(sc, rpp, p, rec.f, &lc, 0u, 0u, &lg)) break;
+                    }
+                    uint32_t *o = out + (((size_t)y * W + x) * 4 + sub) * 8;
+                    o[0] = float_as_uint(p.accum.x); o[1] = float_as_uint(p.accum.y); o[2] = float_as_uint(p.accum.z); o[3] = lg.rays;
+                    o[4] = (uint32_t)lg.ev; o[5] = (uint32_t)(lg.ev >> 32); o[6] = lg.ev9; o[7] = lg.hash;
+                }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+    for (auto &t : th) t.join();
     return 0;
 }
 

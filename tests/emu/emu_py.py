@@ -25,6 +25,7 @@ def lib():
         L.emu_raw_draws_pc.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.c_void_p]
         L.emu_raw_draws_seg.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_path_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -59,6 +60,14 @@ class EmuScene:
         cn = (C.c_uint64 * 6)()
         lib().emu_render(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data, cn)
         return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests"], list(cn)))
+
+    def path_log(self, w, h, sampling, threads=0):
+        """(radiance [h, w, 4, 3] float32, rays, events [h, w, 4, 10] uint8 (nine event bytes + the count of sphere hits), element hash) — the layout of Renderer.debug_path_log"""
+        raw = np.zeros((h, w, 4, 8), dtype=np.uint32)
+        lib().emu_path_log(self._h, w, h, sampling, threads, raw.ctypes.data)
+        rad = raw[..., 0:3].copy().view(np.float32)
+        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(h, w, 4, 12)[..., :10]
+        return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
 
     def render_debug(self, w, h, mode):
         acc = np.zeros((h, w, 3), dtype=np.float32)

@@ -20,7 +20,7 @@ def test_hip_library_exports_header(ha):
     lib = C.CDLL(ha.HIP_LIB)
     for n in names:
         assert hasattr(lib, n), "libhanamaru_hip.so lacks %s" % n
-    assert ha.hip_lib().hr_abi_version() == 4
+    assert ha.hip_lib().hr_abi_version() == 5
 
 
 def test_host_library_exports_header(ha):

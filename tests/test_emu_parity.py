@@ -421,3 +421,32 @@ def test_device_builders_tree_quality(scenes, emu, emu_scenes):
         print("%s: node tests host SAH %d, LBVH %d (x%.2f), PLOC %d (x%.2f)" % (name, counts[0], counts[1], counts[1] / counts[0], counts[2], counts[2] / counts[0]))
     for name, (sah, lb, pl) in out.items():
         assert pl <= 1.15 * sah and pl < lb, (name, sah, lb, pl)
+
+
+@pytest.mark.parametrize("name,w,h", [("cornell_mini", 96, 64), ("rtcamp6_v3_1", 160, 90), ("spheres", 128, 72)])
+def test_per_path_event_log(emu_scenes, name, w, h):
+    """The per-path accounting of the GPU tier (test_per_path_parity_accounting) on the host emulation of the same per-lane code
+    (path_advance<.., LOG> of pt_core.h): the event log's encoding agrees with the oracle's, path by path — the same events, the same
+    elements and mesh triangles, the same number of rays — for all but a few paths per 100,000, and the logged radiances are the
+    emulated render's."""
+    import path_parity
+    _, o, e = emu_scenes(name)
+    g = e.path_log(w, h, 1)
+    r = o.path_log(w, h, 1)
+    acc, cn = e.render(w, h, 1, 2)
+    assert cn["rays"] == int(g[1].sum())                                        # the log's ray count is the counters' ray count
+    np.testing.assert_allclose(g[0].astype(np.float64).sum(axis=2), acc, rtol=1e-5, atol=1e-6)
+    ref, ocn = o.render(w, h, 1, 2, counters=True)
+    assert ocn["rays_primary"] + ocn["rays_bounce"] + ocn["rays_shadow"] == int(r[1].sum())
+    np.testing.assert_allclose(r[0].sum(axis=2), ref, rtol=1e-12, atol=1e-12)
+    a = path_parity.account(g, r)
+    sb = a["same_branch"]
+    assert sb["rays_equal"] and a["divergent_ppm"] <= 150.0, a
+    assert (r[2][..., 9] == g[2][..., 9])[(g[3] == r[3]) & (g[2][..., :9] == r[2][..., :9]).all(axis=-1)].all()   # sphere-hit counts of same-branch paths
+    first = r[2][..., 0] & 7
+    assert (first != 0).all() and set(np.unique(first)) <= {1, 2, 3, 4, 5, 6, 7}                                  # every path has a first event
+    if name != "spheres":
+        assert sb["max_rel_floor1"] <= 1e-3, sb                                  # no sphere chains: same branches, same radiance
+    else:
+        assert sb["no_sphere_bounce"]["over_1e-3_floor1_ppm"] == 0.0 and sb["over_1e-3_floor1_ppm"] <= 1500.0, sb
+        assert all(int(k) >= 2 for k in sb["over_1e-3_by_sphere_bounces_ppm"]), sb  # the tail needs at least two sphere bounces

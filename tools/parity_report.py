@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 import hanamaru_amd as ha  # noqa: E402
 import oracle_py as orc  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import path_parity  # noqa: E402  (the per-path accounting shared with tests/test_gpu_parity.py)
 
 
 def main():
@@ -53,6 +55,21 @@ def main():
             "node_tests_per_ray_reference_order": (cn["mesh_node_tests"] + cn["top_node_tests"]) / ref_rays,
             "gpu_seconds_incl_readback": round(t_gpu, 4), "oracle_seconds_all_cores": round(t_cpu, 3)})
         print(json.dumps(out["cases"][-1]))
+    # per-path accounting (round 4): every path of one sampling compared with the oracle's path — same branches or not, and how far apart
+    out["per_path"] = {"what": "hr_debug_path_log (the render kernel's logging instantiation) vs orc_path_log, sampling 1: a path is 'same' when its event log "
+                               "(per iteration: miss / surface type hit / sample None, reflected or transmitted, NEE visibility mask) and the hash of the elements "
+                               "and mesh triangles it hit equal the oracle's; relative errors are per channel against max(1, |oracle|) ('floor1') or against the "
+                               "path's own magnitude ('own')", "cases": []}
+    for name, w, h in [("rtcamp6_v3_1", 480, 270), ("rtcamp6_dodeca", 480, 270), ("spheres", 480, 270), ("cornell_mini", 320, 200), ("rtcamp6_v2", 320, 180),
+                       ("rtcamp5", 320, 180), ("tbf3", 320, 180), ("material_examples", 320, 180), ("rtcamp6_v1", 320, 180), ("rtcamp6_v3", 320, 180), ("simple", 320, 180)]:
+        sc = ha.Scene(name)
+        o = orc.OracleScene(sc.desc_ptr)
+        r.upload_scene(sc)
+        r.set_resolution(w, h)
+        a = path_parity.account(r.debug_path_log(1), o.path_log(w, h, 1))
+        a.update({"scene": name, "width": w, "height": h, "sampling": 1})
+        out["per_path"]["cases"].append(a)
+        print(json.dumps(a))
     json.dump(out, open(sys.argv[1], "w"), indent=1)
 
 
