@@ -315,53 +315,29 @@ HD SphHit sphere_surface_f64(float sx, float sy, float sz, float sw, double ox, 
     h.nx = (float)(nx * il); h.ny = (float)(ny * il); h.nz = (float)(nz * il);
     return h;
 }
-// NOT inlined on the device (as sphere_root: the f64 temporaries stay out of the shading code's register budget), one call per sphere hit;
-// the arguments are what the caller holds anyway — fp32 values and a pointer.
+// NOT inlined on the device (as sphere_root: the f64 temporaries stay out of the shading code's register budget), one call per sphere hit.
+// The ray is the fp32 ray plus a correction (do, dd): zero for any ray but a path's first — there it is what the fp32 rounding of the f64
+// camera ray took away (path_start computes the camera ray in f64 and parks the two residuals in dead slots of the path's record).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HR_NOINLINE __device__ __attribute__((noinline))
 #else
 #define HR_NOINLINE inline
 #endif
-// any ray: the fp32 ray widened (exact)
-HR_NOINLINE SphHit sphere_surface(float sx, float sy, float sz, float sw, float ox, float oy, float oz, float dx, float dy, float dz) {
-    return sphere_surface_f64(sx, sy, sz, sw, (double)ox, (double)oy, (double)oz, (double)dx, (double)dy, (double)dz);
+HR_NOINLINE SphHit sphere_surface(float sx, float sy, float sz, float sw, float ox, float oy, float oz, float dx, float dy, float dz, float dox, float doy, float doz,
+                                  float ddx, float ddy, float ddz) {
+    return sphere_surface_f64(sx, sy, sz, sw, (double)ox + (double)dox, (double)oy + (double)doy, (double)oz + (double)doz, (double)dx + (double)ddx,
+                              (double)dy + (double)ddy, (double)dz + (double)ddz);
 }
-// a path's first ray: the camera ray itself, recomputed in f64 — camera.rs:83-96 for pixel (px, py), sub-sample `sub`, lens sample
-// (lens_x, lens_y) = the accepted (2u - 1, 2v - 1) of the record head (fp32: a lens offset is lens_radius x 3e-8 off, 1e-9 of a scene
-// unit); renderer.rs:34-36,53-54 for the normalised coordinate.  `cam`: the camera in the reference's precision (device_scene.h CameraD).
-HR_NOINLINE SphHit sphere_surface_primary(float sx, float sy, float sz, float sw, const CameraD *cam, uint32_t width, uint32_t height, uint32_t px, uint32_t py,
-                                          uint32_t sub, float lens_x, float lens_y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the pointer is wave-uniform, which a non-inlined function cannot know: made scalar by hand and read through the constant address
-    // space, so that the camera's 20 doubles are scalar loads into SGPRs (as vector loads they were 40 VGPRs and pushed the kernel into spills)
-    const unsigned long long cam_bits = (unsigned long long)cam;
-    typedef const __attribute__((address_space(4))) CameraD *CamConstPtr;
-    const CameraD c = *(CamConstPtr)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cam_bits >> 32)) << 32) |
-                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cam_bits));
-    width = (uint32_t)__builtin_amdgcn_readfirstlane((int)width); height = (uint32_t)__builtin_amdgcn_readfirstlane((int)height);
-#else
-    const CameraD &c = *cam;
-#endif
-    const double fx = (double)px, fy = (double)(height - py);
-    const double ox = (double)(sub & 1u) * 0.5 - 0.5, oy = (double)(sub >> 1) * 0.5 - 0.5;
-    const double m = (double)(width < height ? width : height);
-    double im = (double)HR_RCP((float)m);                       // one f64 reciprocal (v_rcp_f32 seed + two Newton steps) instead of two f64 divisions
-    im = im * (2.0 - m * im); im = im * (2.0 - m * im);
-    const double ncx = ((fx + ox) * 2.0 - (double)width) * im, ncy = ((fy + oy) * 2.0 - (double)height) * im;
-    const double lx = (double)lens_x * c.lens_radius, ly = (double)lens_y * c.lens_radius;
-    const double lpx = c.right[0] * lx + c.up[0] * ly, lpy = c.right[1] * lx + c.up[1] * ly, lpz = c.right[2] * lx + c.up[2] * ly;
-    const double vx = ncx * c.phr[0] + ncy * c.phu[0] + c.focus_distance * c.forward[0] - lpx;
-    const double vy = ncx * c.phr[1] + ncy * c.phu[1] + c.focus_distance * c.forward[1] - lpy;
-    const double vz = ncx * c.phr[2] + ncy * c.phu[2] + c.focus_distance * c.forward[2] - lpz;
-    const double il = hr_rsqrt_f64(fma(vx, vx, fma(vy, vy, vz * vz)));
-    return sphere_surface_f64(sx, sy, sz, sw, c.eye[0] + lpx, c.eye[1] + lpy, c.eye[2] + lpz, vx * il, vy * il, vz * il);
-}
-// what identifies a path's first ray to hit_surface (on == false: any other ray)
-struct PrimaryRay { bool on; uint32_t width, height, px, py, sub; float lens_x, lens_y; };
-HD PrimaryRay no_primary() { PrimaryRay q; q.on = false; q.width = q.height = q.px = q.py = q.sub = 0u; q.lens_x = q.lens_y = 0.0f; return q; }
+// the residuals of a path's first ray (zero: any other ray)
+struct RayFix { V3f o, d; };
+HD RayFix no_ray_fix() { RayFix f; f.o = v3(0, 0, 0); f.d = v3(0, 0, 0); return f; }
+// where path_start parks them: six slots of the path's record that no iteration reads — a path whose accepted lens attempt is a consumes draws
+// 2a + 2 .. 2a + 19 (renderer.rs:175 for iterations 1 .. 9), the slots before are rejected lens attempts, the slots from 2a + 20 on spare
+// (a <= LENS_FAST - 1 = 4, REC_DRAWS = 28: at least 10 dead slots; the path's radiance goes to slots 0 .. 3 when it ENDS).  Pairs of slots
+// are 8 contiguous bytes (rec_slot), the first is even.
+HD uint32_t ray_fix_slot(uint32_t twice_a, uint32_t k) { uint32_t s = twice_a + 20u + 2u * k; return s >= (uint32_t)REC_DRAWS ? s - (uint32_t)REC_DRAWS : s; }
 
-
-HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s, const PrimaryRay &pr) {
+HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s, const RayFix &fix) {
     s.pos = r.o + r.d * ts.t;
     s.u = ts.u; s.v = ts.v;
     if (ts.type == 0) {
@@ -372,8 +348,7 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         const f4 sp = sc.spheres[ts.prim];
         s.elem = sc.sphere_elem[ts.prim];
         {
-            const SphHit h = pr.on ? sphere_surface_primary(sp.x, sp.y, sp.z, sp.w, sc.camd, pr.width, pr.height, pr.px, pr.py, pr.sub, pr.lens_x, pr.lens_y)
-                                   : sphere_surface(sp.x, sp.y, sp.z, sp.w, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
+            const SphHit h = sphere_surface(sp.x, sp.y, sp.z, sp.w, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, fix.o.x, fix.o.y, fix.o.z, fix.d.x, fix.d.y, fix.d.z);
             s.pos = v3(h.px, h.py, h.pz);
             s.n = v3(h.nx, h.ny, h.nz);
         }
@@ -410,7 +385,7 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
     }
 }
 
-HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s) { hit_surface(sc, r, ts, want_uv, s, no_primary()); }
+HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s) { hit_surface(sc, r, ts, want_uv, s, no_ray_fix()); }
 
 // ---------------------------------------------------------------------------------------------
 // textures — texture.rs:29-63, color.rs:18-36
@@ -613,18 +588,38 @@ HD uint32_t path_draw_base(const Path &p) { return ((p.q >> 6) & 63u) * REC_ITEM
 
 // camera.rs:83-96 with the lens rejection loop already resolved by the seed kernel (record head: attempt a, lens x, lens y).
 // In: p.q = slot of the path (bits 0-11); `recs` = the tile's block of records.
-HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, const float *recs) {
-    float fx = (float)px, fy = (float)(rp.height - py);
-    float ox = (float)(sub & 1u) * 0.5f - 0.5f, oy = (float)(sub >> 1) * 0.5f - 0.5f;
-    float m = (float)(rp.width < rp.height ? rp.width : rp.height);
-    float ncx = ((fx + ox) * 2.0f - (float)rp.width) * HR_RCP(m), ncy = ((fy + oy) * 2.0f - (float)rp.height) * HR_RCP(m);
-    const CameraF &c = sc.cam;
-    const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(path_draw_base(p), REC_HEAD));
-    float lx = head.y * c.lens_radius, ly = head.z * c.lens_radius;
-    p.q = (p.q & 0xfffu) | ((2u * float_as_uint(head.x)) << 12);
-    V3f lens_pos = v3(c.right) * lx + v3(c.up) * ly;
-    V3f dir = normalize(ncx * v3(c.phr) + ncy * v3(c.phu) + c.focus_distance * v3(c.forward) - lens_pos);
-    ray_set(p.ray, v3(c.eye) + lens_pos, dir);
+// The ray is computed in f64 (the reference's camera is f64: device_scene.h CameraD) and rounded ONCE: the fp32 ray the traversal walks is the
+// best fp32 ray there is, and what the rounding took away — (o64 - o32, d64 - d32), six floats — is parked in dead slots of the path's own
+// record (ray_fix_slot) for the one consumer that needs it: a primary ray that hits a sphere (hit_surface).  ~60 f64 operations per path.
+HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px, uint32_t py, uint32_t sub, float *recs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) CameraD *CamConstPtr;   // constant address space: the 20 doubles are scalar loads
+    const CameraD c = *(CamConstPtr)(unsigned long long)sc.camd;
+#else
+    const CameraD &c = *sc.camd;
+#endif
+    const uint32_t lb = path_draw_base(p);
+    const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(lb, REC_HEAD));
+    const uint32_t a2 = 2u * float_as_uint(head.x);
+    p.q = (p.q & 0xfffu) | (a2 << 12);
+    const double fx = (double)px, fy = (double)(rp.height - py);
+    const double sx = (double)(sub & 1u) * 0.5 - 0.5, sy = (double)(sub >> 1) * 0.5 - 0.5;
+    const double m = (double)(rp.width < rp.height ? rp.width : rp.height);
+    double im = (double)HR_RCP((float)m);                       // one f64 reciprocal (v_rcp_f32 seed + two Newton steps) instead of two f64 divisions
+    im = im * (2.0 - m * im); im = im * (2.0 - m * im);
+    const double ncx = ((fx + sx) * 2.0 - (double)rp.width) * im, ncy = ((fy + sy) * 2.0 - (double)rp.height) * im;   // renderer.rs:53-54
+    const double lx = (double)head.y * c.lens_radius, ly = (double)head.z * c.lens_radius;
+    const double lpx = c.right[0] * lx + c.up[0] * ly, lpy = c.right[1] * lx + c.up[1] * ly, lpz = c.right[2] * lx + c.up[2] * ly;
+    const double vx = ncx * c.phr[0] + ncy * c.phu[0] + c.focus_distance * c.forward[0] - lpx;
+    const double vy = ncx * c.phr[1] + ncy * c.phu[1] + c.focus_distance * c.forward[1] - lpy;
+    const double vz = ncx * c.phr[2] + ncy * c.phu[2] + c.focus_distance * c.forward[2] - lpz;
+    const double il = hr_rsqrt_f64(fma(vx, vx, fma(vy, vy, vz * vz)));
+    const double o64x = c.eye[0] + lpx, o64y = c.eye[1] + lpy, o64z = c.eye[2] + lpz, d64x = vx * il, d64y = vy * il, d64z = vz * il;
+    const V3f o = v3((float)o64x, (float)o64y, (float)o64z), d = v3((float)d64x, (float)d64y, (float)d64z);
+    *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 0u))) = f2v{(float)(o64x - (double)o.x), (float)(o64y - (double)o.y)};
+    *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 1u))) = f2v{(float)(o64z - (double)o.z), (float)(d64x - (double)d.x)};
+    *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 2u))) = f2v{(float)(d64y - (double)d.y), (float)(d64z - (double)d.z)};
+    ray_set(p.ray, o, d);
     ray_quantise(sc, p.ray);
     p.st = 1u;            // iteration 1, main ray
     p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
@@ -710,14 +705,15 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
             return true;
         }
         Surf s;
-        PrimaryRay pr = no_primary();
-        if (p.ts.type == 1 && path_iter(p) == 1u) {   // a primary ray on a sphere: hit point and normal from the camera ray itself, in f64
-            pr.on = true; pr.width = rp.width; pr.height = rp.height;
-            tile_lane_pixel(rp, p.tile, p.q & 63u, pr.px, pr.py, pr.sub);
-            const f4 head = *reinterpret_cast<const f4 *>(recs + rec_slot(path_draw_base(p), REC_HEAD));
-            pr.lens_x = head.y; pr.lens_y = head.z;
+        RayFix fix = no_ray_fix();
+        if (p.ts.type == 1 && path_iter(p) == 1u) {   // a primary ray on a sphere: hit point and normal from the f64 camera ray (path_start's residuals)
+            const uint32_t lb = path_draw_base(p), a2 = (p.q >> 12) & 15u;
+            const f2v fo = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 0u)));
+            const f2v fm = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 1u)));
+            const f2v fd = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 2u)));
+            fix.o = v3(fo[0], fo[1], fm[0]); fix.d = v3(fm[1], fd[0], fd[1]);
         }
-        hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, hit_element(sc, p.ts)), s, pr);
+        hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, hit_element(sc, p.ts)), s, fix);
         PointMat m;
         material_at(sc, s.elem, s.u, s.v, m);
         p.view = -p.ray.d;
