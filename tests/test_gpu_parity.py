@@ -28,10 +28,15 @@ ATOL_REL = 1e-2
 # ~2 x distance / radius = 100, so a path that meets two of them looks up the sky a fraction of a texel away from where the f64
 # reference does — a property of fp32 rays, not of a test; the more samplings a pixel holds, the likelier it holds such a path
 # (64 samplings at full size: 0.991, hence the crop gate below).
+# Round 4 replaced the explanation by a measurement (test_per_path_parity_accounting, profiles/r04_parity_report.json "per_path"): paths that
+# take another branch than the oracle's are 7 - 300 per million; the larger part of the sphere scenes' tail took the SAME branches and
+# bounced off two or more small spheres.  The sphere hit point / normal from the f64 root and, for primary rays, from the f64 camera ray
+# (pt_core.h sphere_surface, path_start) cut that tail by 3.3 (spheres: 1,804 -> 556 ppm of the paths); the gates moved up with it:
+# spheres 0.9950 -> 0.9975, rtcamp6_v2 0.9955 -> 0.9965, rtcamp5 0.9965 -> 0.9972, tbf3 0.9975 -> 0.9980, material_examples 0.9985 -> 0.9990.
 GATES = {
-    "rtcamp6_v3_1": (0.9998, 0.9995), "rtcamp6_dodeca": (0.9996, 0.9990), "rtcamp6_v3": (0.9998, 0.9995), "rtcamp6_v1": (0.9996, 0.9994),
-    "material_examples": (0.9997, 0.9985), "simple": (0.9998, 0.9995), "cornell_mini": (0.9997, 0.9995), "tbf3": (0.9995, 0.9975),
-    "rtcamp6_v2": (0.9990, 0.9955), "spheres": (0.9990, 0.9950), "rtcamp5": (0.9990, 0.9965),
+    "rtcamp6_v3_1": (0.9998, 0.9995), "rtcamp6_dodeca": (0.9996, 0.9992), "rtcamp6_v3": (0.9998, 0.9995), "rtcamp6_v1": (0.9996, 0.9994),
+    "material_examples": (0.9997, 0.9990), "simple": (0.9998, 0.9995), "cornell_mini": (0.9997, 0.9995), "tbf3": (0.9995, 0.9980),
+    "rtcamp6_v2": (0.9990, 0.9965), "spheres": (0.9990, 0.9975), "rtcamp5": (0.9990, 0.9972),
 }
 CROP_SLACK = (0.0015, 0.006)
 FRAC_OK = 0.9995   # the headline scene's gate, for the tests that render rtcamp6_v3_1
@@ -807,7 +812,7 @@ def test_config2_spheres_full_size_crops(gpu, scenes):
     gpu.set_option("counters", 1)
     # 64 samplings = 256 paths per pixel: a pixel is off by more than 1e-3 as soon as ONE of them took another branch (grazing
     # sphere rims), so the 1e-3 fraction falls with the sampling count while the 1e-2 fraction rises — gates for this count
-    _crop_parity(gpu, o, "spheres", 1920, 1080, 64, [(900, 190), (400, 160), (1150, 590), (0, 1016), (760, 900)], gates=(0.9992, 0.9890), crop_slack=(0.0015, 0.016))
+    _crop_parity(gpu, o, "spheres", 1920, 1080, 64, [(900, 190), (400, 160), (1150, 590), (0, 1016), (760, 900)], gates=(0.9992, 0.9950), crop_slack=(0.0015, 0.008))
     st = gpu.stats()
     gpu.set_option("counters", 0)
     assert st["paths"] == 1920 * 1080 * 4 * 64 and st["rng_overflow"] == 0 and st["tri_tests"] == 0 and st["sphere_tests"] > 0
