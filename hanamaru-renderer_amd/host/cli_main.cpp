@@ -159,7 +159,6 @@ int main(int argc, char **argv) {
         return hr_write_accumulator(ctx, part.data()) != 0 ? 1 : rc;
     };
 
-    // Renderer::render + report_progress (renderer.rs:25-46, 205-251) at batch granularity
     std::vector<uint8_t> rgb((size_t)width * height * 3);
     double begin = now_sec(), last_progress = begin, last_image = begin;
     uint32_t counter = 0, sampled = 0;
@@ -196,9 +195,13 @@ int main(int argc, char **argv) {
         sampled = 1;
         sampling = 0;
     }
-    // One chunk of samplings stays in flight while the host reports on the previous one (hr_mark / hr_wait), so the GPU
-    // never drains between progress lines.  The stop prediction of report_progress (renderer.rs:222-231) therefore looks two
-    // chunks ahead instead of one.
+    // Renderer::render's loop with report_progress (renderer.rs:32-43, 205-251) at chunk granularity: a chunk = `--batch` samplings
+    // (--batch 1: the reference's cadence, one "rendering:" line per sampling).  One chunk stays in flight while the host reports on the
+    // previous one (hr_mark / hr_wait), so the GPU never drains between progress lines.  What follows from that, and is the ONE deviation
+    // from renderer.rs:205-251: the time-limit prediction (renderer.rs:222-231: stop when used + 1.1 x last > limit) is made BEFORE a chunk
+    // is issued, i.e. it looks two chunks ahead (used + 2.2 x last) — the render stops one chunk earlier rather than one chunk late.
+    // A progress image (renderer.rs:243-251) holds exactly the samplings of the "rendering:" line before it, as in the reference: when one
+    // is due the chunk in flight is awaited and reported first, the image is written, and the pipeline starts again (one drain per image).
     struct Chunk { uint32_t begin, end; std::vector<uint64_t> ticket; };
     auto issue = [&](uint32_t s, Chunk &c) -> int {
         c.begin = s;
@@ -212,43 +215,56 @@ int main(int argc, char **argv) {
     Chunk cur{}, nxt{};
     bool have_cur = false, have_next = false;
     double chunk_sec = 0.0;   // duration of the last completed chunk (0 = not known yet)
+    double used = 0.0;
+    // wait for a chunk and print its line (renderer.rs:206-214)
+    auto report = [&](const Chunk &c) -> int {
+        for (uint32_t r = 0; r < ndev; r++)
+            if (hr_wait(ctxs[r], c.ticket[r]) != 0) { fprintf(stderr, "hr_wait: %s\n", hr_last_error()); return 1; }
+        sampled = c.end - 1;
+        const double now = now_sec();
+        used = now - begin;
+        chunk_sec = now - last_progress;
+        last_progress = now;
+        printf("rendering: %ux4 sampled (last %.3f sec). total: %.3f sec (%.2f %%).\n", sampled, chunk_sec, used, used / time_limit * 100.0);
+        return 0;
+    };
+    // renderer.rs:222-241: the final image takes the current counter
+    auto finish = [&](const char *why) -> int {
+        for (uint32_t r = 0; r < ndev; r++)
+            if (hr_synchronize(ctxs[r]) != 0) { fprintf(stderr, "hr_synchronize: %s\n", hr_last_error()); return 1; }
+        printf("%s\n", why);
+        printf("output final image: %03u.png\n", counter);
+        printf("remain: %.3f sec.\n", time_limit - used);
+        return save(sampled);
+    };
     if (first <= sampling) { if (issue(first, cur)) return 1; have_cur = true; }
     else if (!debug && sampled > 0) {   // resumed from a checkpoint that already holds every requested sampling: just resolve it
         printf("reached max sampling\n");
         if (save(sampled)) return 1;
     }
     while (have_cur) {
-        // keep the next chunk in flight unless the samplings run out or the time limit is already in sight
-        double pre = now_sec() - begin;
-        if (cur.end <= sampling && pre + chunk_sec * 2.2 <= time_limit) { if (issue(cur.end, nxt)) return 1; have_next = true; }
-        for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_wait(ctxs[r], cur.ticket[r]));
-        sampled = cur.end - 1;
-        double now = now_sec();
-        double used = now - begin, last = now - last_progress;
-        printf("rendering: %ux4 sampled (last %.3f sec). total: %.3f sec (%.2f %%).\n", sampled, last, used, used / time_limit * 100.0);
-        bool stop = false;
-        if (!have_next && sampled < sampling) { printf("reached time limit\n"); stop = true; }
-        else if (!have_next) { printf("reached max sampling\n"); stop = true; }
-        if (stop) {
-            for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
-            printf("output final image: %03u.png\n", counter);
-            printf("remain: %.3f sec.\n", time_limit - used);
-            if (save(sampled)) return 1;
+        // keep the next chunk in flight unless the samplings run out or the time limit is in sight
+        if (!have_next && cur.end <= sampling && (now_sec() - begin) + chunk_sec * 2.2 <= time_limit) { if (issue(cur.end, nxt)) return 1; have_next = true; }
+        if (report(cur)) return 1;
+        if (!have_next) {   // nothing in flight: the render ends here
+            if (finish(sampled >= sampling ? "reached max sampling" : "reached time limit")) return 1;
             break;
         }
-        if (now - last_image >= interval) {
-            // a progress image needs the accumulator of exactly `sampled` samplings: drain the chunk in flight first
+        if (now_sec() - last_image >= interval) {   // renderer.rs:243-251
+            if (report(nxt)) return 1;              // the chunk in flight: the image then holds exactly the samplings reported
+            have_next = false;
+            // nothing is in flight now: the reference's own rules apply as they stand (renderer.rs:222-241)
+            if (used + chunk_sec * 1.1 > time_limit) { if (finish("reached time limit")) return 1; break; }
+            if (sampled >= sampling) { if (finish("reached max sampling")) return 1; break; }
             for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
-            if (have_next) sampled = nxt.end - 1;
             printf("output progress image: %03u.png\n", counter);
             if (save(sampled)) return 1;
             counter++;
-            last_image = now_sec();
+            last_image = last_progress;             // `now` of the report that triggered it (renderer.rs:250)
+            if (issue(sampled + 1, cur)) return 1;
+            continue;
         }
-        chunk_sec = last;
-        last_progress = now;
         cur = nxt;
-        have_cur = have_next;
         have_next = false;
     }
     for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));

@@ -507,6 +507,82 @@ def test_cli_drop_in(tmp_path, scenes, orc):
     assert (d <= 2).mean() > 0.99 and abs(img.mean() - exp.mean()) < 0.5
 
 
+def _run_cli(tmp_path, args, timeout=600):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "hanamaru-renderer_amd", "hanamaru-hip")
+    assert os.path.exists(exe), "hanamaru-hip not built (run __graft_entry__.build())"
+    r = subprocess.run([exe] + [str(a) for a in args] + ["--assets", os.path.join(root, "assets")], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout
+    return r.stdout
+
+
+def _crops_match_oracle(img, o, orc, W, H, samplings, crops, size=16):
+    """An image the CLI wrote against orc.resolve of the oracle's accumulator of the same sampling count, on crops at full-image
+    coordinates: the post chain is a per-pixel map followed by a 3x3 filter, so the interior of a crop resolved alone equals the image."""
+    for (x0, y0) in crops:
+        ref = o.render_region(W, H, x0, y0, size, size, 1, samplings + 1, threads=0)
+        exp = orc.resolve(ref, samplings)[1:-1, 1:-1].astype(int)
+        got = img[y0 + 1:y0 + size - 1, x0 + 1:x0 + size - 1].astype(int)
+        d = np.abs(got - exp)
+        assert (d <= 2).mean() > 0.99 and (d <= 1).mean() > 0.97 and abs(got.mean() - exp.mean()) < 0.6, (x0, y0, samplings, d.max(), (d <= 1).mean())
+
+
+def test_cli_time_limit_stops_the_render(tmp_path, scenes, orc):
+    """report_progress's time-limit branch (renderer.rs:222-231) in the host driver: a sampling budget that cannot be reached within -t.
+    The render stops early ("reached time limit"), the final image takes number 000 and equals result.png, "remain:" is printed, the
+    sampling count reported is a whole number of chunks below -s — and the image is the resolve of exactly that many samplings (oracle)."""
+    import re
+    from PIL import Image
+    W, H, S, B = 160, 90, 1000000, 4
+    out = _run_cli(tmp_path, ["-w", W, "-h", H, "-s", S, "-t", "0.15", "-i", "1000", "--batch", B])
+    assert "reached time limit" in out and "reached max sampling" not in out and "output final image: 000.png" in out and "output progress image" not in out
+    remain = float(re.search(r"remain: (-?[0-9.]+) sec\.", out).group(1))
+    n = int(re.search(r"sampled: (\d+)x4 spp\.", out).group(1))
+    lines = re.findall(r"rendering: (\d+)x4 sampled \(last ([0-9.]+) sec\)\. total: ([0-9.]+) sec \(([0-9.]+) %\)\.", out)
+    assert 2 * B <= n < S and n % B == 0 and int(lines[-1][0]) == n and [int(x[0]) for x in lines] == list(range(B, n + 1, B))
+    assert remain < 0.15 and float(lines[-1][2]) < 0.15 + 0.1          # stopped before (or within one chunk of) the limit
+    img = np.asarray(Image.open(tmp_path / "result.png"))
+    assert img.shape == (H, W, 3) and np.array_equal(img, np.asarray(Image.open(tmp_path / "000.png"))) and not (tmp_path / "001.png").exists()
+    assert ("sampled: %dx4 spp." % n) in open(tmp_path / "result.txt").read()
+    _, o = scenes("rtcamp6_v3_1")
+    _crops_match_oracle(img, o, orc, W, H, n, [(40, 30), (100, 60)])
+
+
+def test_cli_progress_images_at_the_report_interval(tmp_path, scenes, orc):
+    """report_progress's interval branch (renderer.rs:243-251): with -i 0 an image is due at every report.  NNN.png with the counter bumped
+    only for progress images, the final image takes the next number and equals result.png, and every image holds exactly the samplings
+    of the "rendering:" line before it (the chunk in flight is awaited and reported first) — each checked against the oracle's resolve
+    of that many samplings.  --batch 1 gives the reference's own cadence: one "rendering:" line per sampling."""
+    import re
+    from PIL import Image
+    W, H = 96, 54
+    out = _run_cli(tmp_path, ["-w", W, "-h", H, "-s", 24, "-t", "1000", "-i", "0", "--batch", 8])
+    events = re.findall(r"rendering: (\d+)x4 sampled|output (progress|final) image: (\d+)\.png|(reached max sampling)|(reached time limit)", out)
+    seq = [("r", int(e[0])) if e[0] else (e[1][0], int(e[2])) if e[1] else ("max" if e[3] else "time", 0) for e in events]
+    assert seq == [("r", 8), ("r", 16), ("p", 0), ("r", 24), ("max", 0), ("f", 1)], seq
+    _, o = scenes("rtcamp6_v3_1")
+    i0, i1 = np.asarray(Image.open(tmp_path / "000.png")), np.asarray(Image.open(tmp_path / "001.png"))
+    assert np.array_equal(i1, np.asarray(Image.open(tmp_path / "result.png"))) and not (tmp_path / "002.png").exists() and not np.array_equal(i0, i1)
+    _crops_match_oracle(i0, o, orc, W, H, 16, [(10, 8), (60, 30)])
+    _crops_match_oracle(i1, o, orc, W, H, 24, [(10, 8), (60, 30)])
+    # the reference's cadence: one line per sampling; with two samplings in flight a progress image falls on every second one
+    sub = tmp_path / "b1"
+    sub.mkdir()
+    out = _run_cli(sub, ["-w", W, "-h", H, "-s", 5, "-t", "1000", "-i", "0", "--batch", 1])
+    events = re.findall(r"rendering: (\d+)x4 sampled \(last|output (progress|final) image: (\d+)\.png", out)
+    seq = [("r", int(e[0])) if e[0] else (e[1][0], int(e[2])) for e in events]
+    assert seq == [("r", 1), ("r", 2), ("p", 0), ("r", 3), ("r", 4), ("p", 1), ("r", 5), ("f", 2)], seq
+    _crops_match_oracle(np.asarray(Image.open(sub / "001.png")), o, orc, W, H, 4, [(30, 20)])
+    _crops_match_oracle(np.asarray(Image.open(sub / "002.png")), o, orc, W, H, 5, [(30, 20)])
+    # an interval that never passes: no progress image, the final one is 000.png
+    sub = tmp_path / "never"
+    sub.mkdir()
+    out = _run_cli(sub, ["-w", W, "-h", H, "-s", 9, "-t", "1000", "-i", "1000", "--batch", 2])
+    assert "output progress image" not in out and "output final image: 000.png" in out and len(re.findall(r"rendering: ", out)) == 5
+
+
 def test_no_systematic_bias_at_many_samplings(gpu, scenes):
     """32 samplings (128 paths per pixel): per-pixel Monte-Carlo noise is down by 5.7x, so a systematic difference
     between the fp32 kernels (hardware sin/cos/exp/log/rcp) and the f64 oracle would show in block means."""
