@@ -43,10 +43,8 @@ struct Builder {
     }
     double centroid(uint32_t i, int a) const { return 0.5 * (prims[i].bmin[a] + prims[i].bmax[a]); }
 
-    int build(uint32_t first, uint32_t count, uint32_t depth) {
-        int id = (int)nodes.size();
-        nodes.emplace_back();
-        max_depth = std::max(max_depth, depth);
+    // decides what becomes of the group [first, first + count): a leaf (returns false) or two groups split at `mid` along `axis`
+    bool split_group(int id, uint32_t first, uint32_t count, uint32_t &mid, int &axis) {
         Box box, cbox;
         box.reset(); cbox.reset();
         bool same_type = true;
@@ -58,8 +56,8 @@ struct Builder {
             if (p.type != prims[idx[first]].type) same_type = false;
         }
         nodes[id].box = box;
-        uint32_t mid = 0;
-        int axis = 0;
+        mid = 0;
+        axis = 0;
         bool split = false;
         if (!same_type) {
             // force type-homogeneous subtrees: peel off the first prim's type
@@ -140,17 +138,33 @@ struct Builder {
                 split = true;
             }
         }
-        if (!split) {
-            nodes[id].first = first; nodes[id].count = count; nodes[id].type = prims[idx[first]].type;
-            return id;
+        if (!split) { nodes[id].first = first; nodes[id].count = count; nodes[id].type = prims[idx[first]].type; }
+        return split;
+    }
+    // Nodes are allocated in depth-first preorder, left child first (build_bvh relies on index == memory order).  An explicit stack, not
+    // recursion: a split that peels one outlier off per level makes the tree as deep as the scene has primitives, and split_group's
+    // frame (the SAH bins) times that depth would not fit a thread's stack.
+    void build(uint32_t first0, uint32_t count0) {
+        struct Item { uint32_t first, count, depth; int parent; bool is_right; };
+        std::vector<Item> todo;
+        todo.push_back(Item{first0, count0, 0u, -1, false});
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            const int id = (int)nodes.size();
+            nodes.emplace_back();
+            if (it.parent >= 0) (it.is_right ? nodes[it.parent].right : nodes[it.parent].left) = id;
+            max_depth = std::max(max_depth, it.depth);
+            uint32_t mid = 0;
+            int axis = 0;
+            if (!split_group(id, it.first, it.count, mid, axis)) continue;
+            nodes[id].axis = axis;
+            todo.push_back(Item{mid, it.first + it.count - mid, it.depth + 1, id, true});     // (popped after the whole left subtree)
+            todo.push_back(Item{it.first, mid - it.first, it.depth + 1, id, false});
         }
-        nodes[id].axis = axis;
-        int l = build(first, mid - first, depth + 1);
-        int r = build(mid, first + count - mid, depth + 1);
-        nodes[id].left = l; nodes[id].right = r;
-        return id;
     }
 };
+
 
 static float round_down(double v, int ulps) {
     float f = (float)v;
@@ -183,7 +197,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
         return;
     }
     Builder b(prims, max_leaf);
-    b.build(0, (uint32_t)prims.size(), 0);
+    b.build(0, (uint32_t)prims.size());
     out.max_depth = b.max_depth;
     size_t N = b.nodes.size();
     out.num_nodes = (uint32_t)N;
@@ -194,7 +208,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, BuiltBvh &out)
         if (bn.left < 0) {
             uint32_t first = (uint32_t)out.order[bn.type].size();
             for (uint32_t k = 0; k < bn.count; k++) out.order[bn.type].push_back(prims[b.idx[bn.first + k]].index);
-            leaf_word[i] = ((uint32_t)(bn.type + 1) << 28) | (bn.count << 20) | first;
+            leaf_word[i] = hr::leaf_word((uint32_t)bn.type, bn.count, first);   // count <= max_leaf <= 15: build() splits every larger group
             out.num_leaves++;
         }
     }
@@ -300,10 +314,8 @@ struct TopBuilder {
             cen[i].v = _mm_mul_ps(_mm_set1_ps(0.5f), _mm_add_ps(box[i].mn, box[i].mx));
         }
     }
-    int32_t build(uint32_t first, uint32_t count) {
-        if (count == 1) return ~(int32_t)idx[first];
-        const int32_t id = (int32_t)left.size();
-        left.push_back(0); right.push_back(0);
+    // where the range [first, first + count), count >= 2, is split
+    uint32_t split_range(uint32_t first, uint32_t count) {
         uint32_t mid = first + 1;
         if (count > 2) {
             __m128 lo = _mm_set1_ps(FLT_MAX), hi = _mm_set1_ps(-FLT_MAX);
@@ -357,9 +369,28 @@ struct TopBuilder {
                 if (m2 > first && m2 < first + count) mid = m2;
             }
         }
-        const int32_t l = build(first, mid - first), r = build(mid, first + count - mid);
-        left[(size_t)id] = l; right[(size_t)id] = r;
-        return id;
+        return mid;
+    }
+    // inner nodes in preorder, left first; a single cluster c is the link ~c.  Explicit stack (see Builder::build: ploc_top may be 65,536,
+    // and a split that peels off one cluster per level is as deep as that).
+    void build(uint32_t first0, uint32_t count0) {
+        struct Item { uint32_t first, count; int32_t parent; bool is_right; };
+        std::vector<Item> todo;
+        todo.push_back(Item{first0, count0, -1, false});
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            int32_t link;
+            if (it.count == 1) link = ~(int32_t)idx[it.first];
+            else {
+                link = (int32_t)left.size();
+                left.push_back(0); right.push_back(0);
+                const uint32_t mid = split_range(it.first, it.count);
+                todo.push_back(Item{mid, it.first + it.count - mid, link, true});
+                todo.push_back(Item{it.first, mid - it.first, link, false});
+            }
+            if (it.parent >= 0) (it.is_right ? right : left)[(size_t)it.parent] = link;
+        }
     }
 };
 }  // namespace

@@ -37,7 +37,7 @@ struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(16) Node {
     float nearx, neary, farx, fary;
     float nearz, farz;
-    uint32_t a;       // box hit -> inner: next node; leaf: (type+1) << 28 | count << 20 | first  (type: 0 tri, 1 sphere, 2 cuboid)
+    uint32_t a;       // box hit -> inner: next node; leaf: the leaf word (leaf_word() below)
     uint32_t b;       // box missed (or leaf done) -> next node in this octant's order, NODE_END = finished
 };
 HD void node_set_box(Node &n, const float *mn, const float *mx, int octant) {
@@ -45,10 +45,20 @@ HD void node_set_box(Node &n, const float *mn, const float *mx, int octant) {
     n.neary = (octant & 2) ? mx[1] : mn[1]; n.fary = (octant & 2) ? mn[1] : mx[1];
     n.nearz = (octant & 4) ? mx[2] : mn[2]; n.farz = (octant & 4) ? mn[2] : mx[2];
 }
-// links: node indices are below 2^28 - 1, NODE_END = 2^28 - 1 ends the walk, everything from 2^28 up is a leaf word — one compare
-// tells a leaf word from a successor
-static const uint32_t NODE_END = 0x0fffffffu;
-HD bool node_word_is_leaf(uint32_t a) { return a >= 0x10000000u; }
+// links: successors (node indices, or byte offsets on the 16-byte records) are below 2^31 - 1, NODE_END = 2^31 - 1 ends the walk, and a
+// word with bit 31 set is a leaf word — one compare tells a leaf word from a successor.
+//   leaf word = 1 << 31 | type << 28 (0 triangle, 1 sphere, 2 cuboid) | count << 24 (1 .. 15 = option max_leaf's range) | first (24 bits):
+//   `count` primitives of one type from index `first` of that type's leaf-ordered array — 2^24 = 16.7 M references per type (until round 4
+//   the word was (type + 1) << 28 | count << 20 | first, 8 count bits and 20 index bits: scenes stopped at 2^20 primitives).
+static const uint32_t NODE_END = 0x7fffffffu;
+static const uint32_t LEAF_FLAG = 0x80000000u;
+static const uint32_t LEAF_FIRST_BITS = 24u, LEAF_MAX_COUNT = 15u;
+static const uint32_t MAX_PRIMS_PER_TYPE = 1u << LEAF_FIRST_BITS;
+HD bool node_word_is_leaf(uint32_t a) { return a >= LEAF_FLAG; }
+HD uint32_t leaf_word(uint32_t type, uint32_t count, uint32_t first) { return LEAF_FLAG | (type << 28) | (count << LEAF_FIRST_BITS) | first; }
+HD uint32_t leaf_type(uint32_t w) { return (w >> 28) & 3u; }
+HD uint32_t leaf_count(uint32_t w) { return (w >> LEAF_FIRST_BITS) & LEAF_MAX_COUNT; }
+HD uint32_t leaf_first(uint32_t w) { return w & (MAX_PRIMS_PER_TYPE - 1u); }
 
 // The trace kernel's node: 16 bytes, ONE load per visit.  The six planes are 16-bit coordinates on a grid over the scene's box
 // (plane = qmin + q * qstep per axis), rounded outward by at least one step — a box that only grows can add node visits, never
@@ -59,12 +69,12 @@ struct alignas(16) QNode {
     uint32_t xy_near;   // near.x | near.y << 16
     uint32_t xy_far;    // far.x  | far.y  << 16
     uint32_t z_nf;      // near.z | far.z  << 16
-    uint32_t link;      // inner: successor when the box is missed, as its BYTE OFFSET in qnodes[] (or NODE_END); leaf: (type+1) << 28 | count << 20 | first
+    uint32_t link;      // inner: successor when the box is missed, as its BYTE OFFSET in qnodes[] (or NODE_END); leaf: the leaf word
 };
 // The walk's position on the 16-byte records is a byte offset into the whole qnodes[8][N + 1] array (octant copy included): a visit's
 // address is base + offset with no arithmetic, the near child / the node behind a leaf is offset + 16, and a miss takes `link` as
-// it stands.  Offsets stay below 2^28 (leaf words start there): N + 1 <= 2^21 records per octant copy (flatten / the device builders
-// produce < 2^21 nodes: < 2^20 primitives).
+// it stands.  Offsets stay below 2^31 (leaf words have bit 31 set): N + 1 <= 2^24 records per octant copy (2 GiB of records; a tree over
+// 2^24 references with leaves of 4 has ~10^7 nodes).
 HD uint32_t qnode_offset(int octant, uint32_t records_per_copy, uint32_t index) { return ((uint32_t)octant * records_per_copy + index) * 16u; }
 HD uint32_t qnode_link(int octant, uint32_t records_per_copy, uint32_t successor_index) {
     return successor_index == NODE_END ? NODE_END : qnode_offset(octant, records_per_copy, successor_index);

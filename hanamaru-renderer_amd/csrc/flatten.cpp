@@ -203,12 +203,14 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
             return ferr(err, HR_ERR_INVALID, "element %u: unknown kind %d", ei, e.kind);
         }
     }
-    if (prims.size() >= (1u << 20) || tris.size() >= (1u << 20) || spheres.size() >= (1u << 20) || cuboids.size() / 2 >= (1u << 20))
-        return ferr(err, HR_ERR_UNSUPPORTED, "more than 2^20 primitives of one type");
+    // the leaf word holds a 24-bit index per type (device_scene.h); the device builders' per-node type counts give spheres and cuboids 20 bits
+    if (prims.size() >= MAX_PRIMS_PER_TYPE || tris.size() >= MAX_PRIMS_PER_TYPE || spheres.size() >= (1u << 20) || cuboids.size() / 2 >= (1u << 20))
+        return ferr(err, HR_ERR_UNSUPPORTED, "more than 2^24 primitives (or 2^20 spheres / cuboids)");
+    out.num_input_tris = (uint32_t)tris.size();
 
     BuiltBvh bvh;
     if (host_bvh) {
-        const bool split_ok = ratio > 0.0 && prims_split.size() < (1u << 20);
+        const bool split_ok = ratio > 0.0 && prims_split.size() < MAX_PRIMS_PER_TYPE;
         if (split_ok && !auto_split) {
             build_bvh(prims_split, max_leaf, bvh);
         } else {

@@ -16,6 +16,7 @@ struct HostScene {
     std::vector<QNode> qnodes; // [8][num_nodes + 1] (host builder only)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     uint32_t num_nodes = 0;
+    uint32_t num_input_tris = 0;   // triangles of the scene (tris.size() counts references: a split triangle appears once per piece)
     std::vector<Tri> tris;       // geometry records (leaf order with host_bvh, input order without): what the builders read
     std::vector<TriT> tri_t;     // derived from tris by derive_triangles(): what the kernels read (device_scene.h)
     std::vector<TriS> tri_s;

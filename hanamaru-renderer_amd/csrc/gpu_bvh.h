@@ -144,7 +144,7 @@ __global__ void tri_derive_kernel(const Tri *in, uint32_t n, TriT *tris, TriS *t
 __global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_pos, int n, TriT *tris, TriS *tri_shade, uint32_t *tri_face, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *cuboids) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    uint32_t i = key_index(keys[k]), d = prim_pos[k];
+    uint32_t i = key_index(p, keys[k]), d = prim_pos[k];
     if (i < p.num_tris) { const Tri t = p.tris[p.ref_tri ? p.ref_tri[i] : i]; tri_derive(t, tris[d], tri_shade[d]); tri_face[d] = t.face; }
     else if (i < p.num_tris + p.num_spheres) {
         uint32_t l = i - p.num_tris;

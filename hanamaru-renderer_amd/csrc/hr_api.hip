@@ -421,7 +421,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
         if (se == hipSuccess) se = hipStreamSynchronize(c->stream);
         if (se != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "device split clipping: %s", hipGetErrorString(se)); }
         const uint64_t refs = (uint64_t)last[0] + last[1];
-        if (refs > nt && refs + d.num_spheres + d.num_cuboids < (1ull << KEY_INDEX_BITS)) {
+        if (refs > nt && refs < MAX_PRIMS_PER_TYPE) {
             LBVH_ALLOC(ref_tri, uint32_t, refs, false)
             LBVH_ALLOC(ref_box, float, 6 * refs, false)
             split_emit_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(tris_in, nt, sp, split_offsets, ref_tri, ref_box);
@@ -429,6 +429,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
         }
     }
     const int n = (int)(p.num_tris + p.num_spheres + p.num_cuboids);
+    p.index_bits = key_index_bits_for((uint64_t)n);
     const int N = 2 * n - 1;
     LBVH_ALLOC(keys_in, mkey_t, n, false)
     LBVH_ALLOC(keys, mkey_t, n, false)
@@ -544,7 +545,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     uint32_t total = 0;
     memcpy(&total, &hframe[6], sizeof total);
     if (total == 0 || total > (uint32_t)N) return fail(HR_ERR_DEVICE, "device BVH build: implausible record count %u for %d primitives", total, n);
-    if (c->quant_nodes && (uint64_t)(total + 1u) * 8u * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "device BVH build: %u records per octant exceed the 2^28-byte offset range of the quantised records", total);
+    if (c->quant_nodes && (uint64_t)(total + 1u) * 8u * sizeof(QNode) >= (1ull << 31)) return fail(HR_ERR_UNSUPPORTED, "device BVH build: %u records per octant exceed the 2^31-byte offset range of the quantised records (set quant_nodes = 0)", total);
     c->bvh_build_ms = ms;
     d.nodes = nodes; d.num_nodes = total;
     d.qnodes = c->quant_nodes ? qnodes : nullptr;
@@ -604,10 +605,10 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
         d.tris = tt; d.tri_shade = tsh; d.tri_face = tfc;
         if ((r = upload(c, hs.nodes, &d.nodes))) return r;
         d.qnodes = nullptr;
-        if (c->quant_nodes && hs.qnodes.size() * sizeof(QNode) > (1ull << 28)) return fail(HR_ERR_UNSUPPORTED, "hr_upload_scene: the quantised BVH records exceed their 2^28-byte offset range (set quant_nodes = 0)");
+        if (c->quant_nodes && hs.qnodes.size() * sizeof(QNode) >= (1ull << 31)) return fail(HR_ERR_UNSUPPORTED, "hr_upload_scene: the quantised BVH records exceed their 2^31-byte offset range (set quant_nodes = 0)");
         if (c->quant_nodes && !hs.qnodes.empty() && (r = upload(c, hs.qnodes, &d.qnodes))) return r;
     }
-    c->st_nodes = d.num_nodes; c->st_tris = d.num_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
+    c->st_nodes = d.num_nodes; c->st_tris = hs.num_input_tris; c->st_spheres = d.num_spheres; c->st_cuboids = d.num_cuboids;
     c->have_scene = true;
     if ((r = govern_reset(c))) return r;   // another scene: the balance of the two kernels is another one
     return HR_OK;

@@ -33,8 +33,11 @@ static const uint32_t NO_PARENT = 0xffffffffu;   // parent[] of the root (the ar
 
 typedef unsigned long long mkey_t;
 typedef unsigned long long u64t;
-static const int KEY_INDEX_BITS = 20;   // flatten_scene admits < 2^20 primitives
-static const int KEY_AXIS_BITS = 14;    // 42-bit Morton code
+// sort key = type (2 bits) | Morton code | input index: up to 2^20 primitives 20 index bits and a 42-bit code (14 bits per axis), beyond
+// that (up to 2^24) 24 index bits and a 36-bit code (12 per axis) — Prims::index_bits says which
+static const int KEY_INDEX_BITS_SMALL = 20, KEY_INDEX_BITS_LARGE = 24;
+HD int key_index_bits_for(uint64_t primitives) { return primitives <= (1ull << KEY_INDEX_BITS_SMALL) ? KEY_INDEX_BITS_SMALL : KEY_INDEX_BITS_LARGE; }
+HD int key_axis_bits(int index_bits) { return (62 - index_bits) / 3; }
 static const int PLOC_RADIUS = 16;      // nearest-neighbour search window: +-16 positions (8: 1 % more node tests per ray, 0.4 ms less build time at 15 k primitives)
 
 struct Prims {   // input order: triangles (or their split references), then spheres, then cuboids
@@ -44,6 +47,7 @@ struct Prims {   // input order: triangles (or their split references), then sph
     const f4 *spheres; uint32_t num_spheres;
     const f4 *cuboids; uint32_t num_cuboids;
     float smin[3], sinv[3];  // scene bounds -> [0,1)^3
+    int index_bits;          // key_index_bits_for(all primitives the builder sees)
 };
 HD uint32_t type_offset(const Prims &p, uint32_t type) { return type == 0 ? 0u : type == 1 ? p.num_tris : p.num_tris + p.num_spheres; }
 
@@ -54,7 +58,7 @@ struct Work {
     uint32_t *flags;              // per internal node: arrival counter of the bottom-up fit (zeroed)
     float *bmin, *bmax;           // per node, 3 floats each
     uint32_t *info;               // per node: INFO_* bits | primitives in the subtree
-    u64t *tc;                     // per node: primitives per type in the subtree, 20 bits each
+    u64t *tc;                     // per node: primitives per type in the subtree: triangles bits 0-23, spheres 24-43, cuboids 44-63
     uint32_t *size;               // per node: records the subtree is emitted as (1 for a collapsed subtree)
     uint32_t *axis_low;           // per internal node: near/far axis | (lower child is the right one ? 4 : 0)
     uint32_t *word;               // per node: the leaf word (device_scene.h) of a leaf top, set by finish_node; else untouched
@@ -63,7 +67,9 @@ static const uint32_t INFO_COLLAPSED = 1u << 31;   // <= max_leaf primitives of 
 static const uint32_t INFO_UNIFORM = 1u << 30;     // all primitives of one type
 static const uint32_t INFO_COUNT = (1u << 24) - 1u;
 HD uint32_t info_type(uint32_t info) { return (info >> 28) & 3u; }
-HD uint32_t tc_of(u64t tc, uint32_t t) { return (uint32_t)(tc >> (20u * t)) & 0xfffffu; }
+// (triangle references < 2^24, spheres and cuboids < 2^20 each: flatten_scene's limits)
+HD uint32_t tc_shift(uint32_t t) { return t == 0u ? 0u : t == 1u ? 24u : 44u; }
+HD uint32_t tc_of(u64t tc, uint32_t t) { return (uint32_t)(tc >> tc_shift(t)) & (t == 0u ? 0xffffffu : 0xfffffu); }
 
 HD void prim_box(const Prims &p, uint32_t i, float *mn, float *mx, uint32_t &type) {
     if (i < p.num_tris && p.ref_box) {
@@ -94,21 +100,22 @@ HD mkey_t spread3(mkey_t x) {  // 21 bits -> every third bit
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
-// key = type (2 bits) | 42-bit Morton code | input index (20 bits): unique, and the types form contiguous runs
+// key = type (2 bits) | Morton code | input index: unique, and the types form contiguous runs
 HD mkey_t prim_key(const Prims &p, uint32_t i) {
     float mn[3], mx[3];
     uint32_t type;
     prim_box(p, i, mn, mx, type);
     mkey_t q[3];
-    const float top = (float)((1 << KEY_AXIS_BITS) - 1);
+    const int axis_bits = key_axis_bits(p.index_bits);
+    const float top = (float)((1 << axis_bits) - 1);
     for (int a = 0; a < 3; a++) {
         float c = (0.5f * (mn[a] + mx[a]) - p.smin[a]) * p.sinv[a];
         q[a] = (mkey_t)fminf(fmaxf(c * (top + 1.0f), 0.0f), top);
     }
     mkey_t m = (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);
-    return ((mkey_t)type << 62) | (m << KEY_INDEX_BITS) | i;
+    return ((mkey_t)type << 62) | (m << p.index_bits) | i;
 }
-HD uint32_t key_index(mkey_t k) { return (uint32_t)(k & ((1u << KEY_INDEX_BITS) - 1)); }
+HD uint32_t key_index(const Prims &p, mkey_t k) { return (uint32_t)(k & ((1ull << p.index_bits) - 1ull)); }
 
 HD int clz64(mkey_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -213,11 +220,11 @@ HD uint32_t split_tri(const Tri &t, const SplitParams &sp, float *out) {
 HD void fit_leaf(const Prims &p, const mkey_t *keys, int n, int k, const Work &w) {
     float mn[3], mx[3];
     uint32_t type;
-    prim_box(p, key_index(keys[k]), mn, mx, type);
+    prim_box(p, key_index(p, keys[k]), mn, mx, type);
     uint32_t node = (uint32_t)(n - 1 + k);
     for (int a = 0; a < 3; a++) { LBVH_ST(&w.bmin[node * 3 + a], mn[a]); LBVH_ST(&w.bmax[node * 3 + a], mx[a]); }
     LBVH_ST(&w.info[node], INFO_COLLAPSED | INFO_UNIFORM | (type << 28) | 1u);
-    LBVH_ST(&w.tc[node], (u64t)1 << (20u * type));
+    LBVH_ST(&w.tc[node], (u64t)1 << tc_shift(type));
     LBVH_ST(&w.size[node], 1u);
 }
 // internal node whose two subtrees are complete
@@ -377,7 +384,7 @@ HD uint32_t preorder_index(const Work &w, uint32_t node, int o) {
 // per node: leaf word of a leaf top; per primitive leaf (node >= n-1): where its primitive goes in the per-type arrays
 HD void finish_node(const Prims &p, int n, uint32_t node, const Work &w, uint32_t *prim_pos) {
     const uint32_t info = w.info[node], t = info_type(info);
-    if (is_leaf_top(w, node)) w.word[node] = ((t + 1u) << 28) | ((info & INFO_COUNT) << 20) | type_rank(w, node, t);
+    if (is_leaf_top(w, node)) w.word[node] = leaf_word(t, info & INFO_COUNT, type_rank(w, node, t));
     if (node >= (uint32_t)(n - 1)) prim_pos[node - (uint32_t)(n - 1)] = type_offset(p, t) + type_rank(w, node, t);
 }
 

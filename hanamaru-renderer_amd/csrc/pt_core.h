@@ -248,7 +248,7 @@ HD void trace_qnode(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters 
 }
 template <bool CNT>
 HD void trace_leaf(const Scene &sc, const Ray &r, TraceState &ts, LaneCounters *cn) {
-    const uint32_t type = (ts.leaf >> 28) - 1u, count = (ts.leaf >> 20) & 0xffu, first = ts.leaf & 0xfffffu;
+    const uint32_t type = leaf_type(ts.leaf), count = leaf_count(ts.leaf), first = leaf_first(ts.leaf);
     ts.leaf = 0;
     if (type == 0) {
         // two triangles per round so their loads are in flight together

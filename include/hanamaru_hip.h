@@ -116,7 +116,7 @@ typedef struct hr_stats {
     double trace_kernel_ms;    /* ... of the path-trace megakernel launches */
     double post_kernel_ms;
     uint64_t seed_launches, trace_launches;
-    uint64_t bvh_nodes, triangles, spheres, cuboids;
+    uint64_t bvh_nodes, triangles, spheres, cuboids;   /* triangles: of the scene (early split clipping may store one as several references) */
     /* counters build only: wave-level phase statistics of the trace kernel (invocations, lanes served) */
     uint64_t shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters;
     uint64_t phase_cycles[4];  /* counters build: wave-cycles in A shade, B refill, C box phase, C leaf phase */

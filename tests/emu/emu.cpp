@@ -150,7 +150,7 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
         std::vector<uint32_t> offsets(hs.tris.size() + 1, 0);
         for (size_t i = 0; i < hs.tris.size(); i++) offsets[i + 1] = offsets[i] + split_tri(hs.tris[i], sp, nullptr);
         const uint64_t refs = offsets.back();
-        if (refs > hs.tris.size() && refs + hs.spheres.size() + hs.cuboids.size() / 2 < (1ull << KEY_INDEX_BITS)) {
+        if (refs > hs.tris.size() && refs < MAX_PRIMS_PER_TYPE) {
             ref_tri.resize(refs); ref_box.resize(6 * refs);
             for (size_t i = 0; i < hs.tris.size(); i++) {
                 uint32_t cnt = split_tri(hs.tris[i], sp, ref_box.data() + 6 * (size_t)offsets[i]);
@@ -167,6 +167,7 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
         p.sinv[a] = ext > 0 ? (float)(1.0 / ext) : 0.0f;
     }
     const int n = (int)(p.num_tris + p.num_spheres + p.num_cuboids), N = 2 * n - 1;
+    p.index_bits = key_index_bits_for((uint64_t)n);
     std::vector<mkey_t> keys(n);
     for (int i = 0; i < n; i++) keys[i] = prim_key(p, (uint32_t)i);
     std::sort(keys.begin(), keys.end());
@@ -237,7 +238,7 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
     std::vector<f4> spheres(hs.spheres.size()), cuboids(hs.cuboids.size());
     std::vector<int32_t> sphere_elem(hs.sphere_elem.size());
     for (int k = 0; k < n; k++) {
-        uint32_t i = key_index(keys[k]), d = prim_pos[k];
+        uint32_t i = key_index(p, keys[k]), d = prim_pos[k];
         if (i < p.num_tris) tris[d] = hs.tris[p.ref_tri ? p.ref_tri[i] : i];
         else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris; d -= p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; }
         else { uint32_t l = i - p.num_tris - p.num_spheres; d -= p.num_tris + p.num_spheres; cuboids[2 * d] = hs.cuboids[2 * l]; cuboids[2 * d + 1] = hs.cuboids[2 * l + 1]; }
