@@ -123,6 +123,16 @@ struct hr_ctx {
     uint64_t next_ticket = 1;
 };
 
+// caller-owned accumulators (hr_bind_accumulator): one context per buffer.  accumulate_kernel adds a launch's radiance with plain loads and
+// stores (no atomics since round 3), so two contexts accumulating into one buffer would race silently: a second binding is refused.
+#include <map>
+#include <mutex>
+static std::mutex g_bound_mu;
+static std::map<const void *, const hr_ctx *> g_bound;
+static void unbind_accumulator(hr_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_bound_mu);
+    for (auto it = g_bound.begin(); it != g_bound.end();) it = it->second == c ? g_bound.erase(it) : std::next(it);
+}
 static void free_scene(hr_ctx *c) {
     for (void *p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
@@ -306,12 +316,14 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
     HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_seg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+#if defined(HR_EXPERIMENTS)
     HIP_TRY(hipFuncSetAttribute((const void *)seed_w5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_w5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)seed_ps_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEED_LDS_BYTES));
+#endif
     HIP_TRY(hipFuncSetAttribute((const void *)seed_debug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 8));
     // The seed kernel owns all 160 KiB of a CU's LDS and runs next to the trace kernel of the previous batch: a trace kernel that
     // uses ANY LDS (the compiler promotes small private arrays to LDS unless told not to, see the Makefile) could not share a CU
@@ -336,6 +348,7 @@ int hr_destroy(hr_ctx *c) {
     if (!c) return HR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    unbind_accumulator(c);
     free_scene(c);
     for (auto *ev : {&c->seed_events, &c->trace_events, &c->post_events, &c->debug_events})
         for (auto &e : *ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -623,6 +636,7 @@ int hr_set_resolution(hr_ctx *c, uint32_t w, uint32_t h) {
     // no target while the buffers are being replaced (a failed allocation leaves the context without one, not with dangling
     // pointers); a caller-bound accumulator was sized for the old resolution: it is unbound, the caller rebinds
     c->accum = nullptr; c->W = c->H = 0; c->total_valid = false;
+    unbind_accumulator(c);
     if (c->accum_own) { HIP_TRY(hipFree(c->accum_own)); c->accum_own = nullptr; }
     if (c->post_tmp) { HIP_TRY(hipFree(c->post_tmp)); c->post_tmp = nullptr; }
     if (c->d_rgb8) { HIP_TRY(hipFree(c->d_rgb8)); c->d_rgb8 = nullptr; }
@@ -643,6 +657,13 @@ int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
+    if (device_rgb) {
+        std::lock_guard<std::mutex> lk(g_bound_mu);
+        auto it = g_bound.find(device_rgb);
+        if (it != g_bound.end() && it->second != c) return fail(HR_ERR_INVALID, "hr_bind_accumulator: this buffer is already bound to another context (one context per accumulator: the launch's radiance is added with plain loads and stores)");
+    }
+    unbind_accumulator(c);
+    if (device_rgb) { std::lock_guard<std::mutex> lk(g_bound_mu); g_bound[device_rgb] = c; }
     c->accum = device_rgb ? device_rgb : c->accum_own;
     invalidate_totals(c);
     return HR_OK;
@@ -718,6 +739,7 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
         if (c->seed_prof) hipLaunchKernelGGL((seed_seg_kernel<true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
         else hipLaunchKernelGGL((seed_seg_kernel<false>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+#if defined(HR_EXPERIMENTS)
     } else if (c->seed_mode == 4) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
         if (c->seed_prof) hipLaunchKernelGGL((seed_w5_kernel<true>), dim3(grid), dim3(320), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
@@ -727,6 +749,7 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
 #define HR_LAUNCH_PS(P) hipLaunchKernelGGL(seed_ps_kernel<P>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
         switch (c->seed_prof) { case 1: HR_LAUNCH_PS(1); break; case 2: HR_LAUNCH_PS(2); break; case 3: HR_LAUNCH_PS(3); break; default: HR_LAUNCH_PS(0); break; }
 #undef HR_LAUNCH_PS
+#endif
     } else if (c->seed_mode == 1) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
 #define HR_LAUNCH_PC(HEAD) hipLaunchKernelGGL(seed_pc_kernel<HEAD>, dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
@@ -1220,6 +1243,9 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
     }
     if (k == "seed_mode") {
         if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4) return fail(HR_ERR_INVALID, "seed_mode must be 4 (five-wave four-run kernel), 3 (phase-shifted four-run kernel), 2 (three-run kernel), 1 (producer / consumer kernel with a state ring) or 0 (fused kernel)");
+#if !defined(HR_EXPERIMENTS)
+        if (value >= 3) return fail(HR_ERR_UNSUPPORTED, "seed_mode %d is a measured experiment (slower than the default): build with `make EXPERIMENTS=1` to have it", (int)value);
+#endif
         int rc = sync_all(c);
         if (rc) return rc;
         c->seed_mode = (int)value;

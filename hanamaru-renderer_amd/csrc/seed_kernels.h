@@ -594,6 +594,9 @@ __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens
     }
 }
 
+// The two kernels below (seed_mode 3 and 4) are measured experiments, both slower than the three-run kernel (profiles/NOTES.md): they are
+// compiled only into builds made with `make EXPERIMENTS=1` (-DHR_EXPERIMENTS); the product library does not carry them.
+#if defined(HR_EXPERIMENTS)
 // ---- phase-shifted four-run seeding (debug option seed_mode = 3) ----------------------------------------------------------------------------------
 // The three-run kernel's window is 11 blocks long because a half has 120 lanes to fill it with (its consumer wave and its producer
 // wave).  Here the two halves run HALF A PERIOD APART: while one consumer is in the middle of its round the other half's window is
@@ -1005,6 +1008,8 @@ __global__ __launch_bounds__(320) void seed_w5_kernel(RenderParams rp, int lens_
         seed_gov_end(rp, role.prod == 0u && lane == 0u);
     }
 }
+
+#endif   // HR_EXPERIMENTS
 
 // raw generator outputs for the parity tests: out[p * window + k] = k-th next_u64 of pixel-major path p
 struct RawTail {

@@ -72,3 +72,15 @@ def test_graft_entry_build_check_follows_the_header():
     src = open(os.path.join(root, "__graft_entry__.py")).read()
     assert "HR_ABI_VERSION" in src and not re.search(r"hr_abi_version\(\)\s*==\s*\d", src)
 
+
+
+def test_rust_mirror_carries_the_headers_layout():
+    """rust/hip_ffi.rs has never been compiled (no Rust toolchain here): its generated block of compile-time size / alignment assertions and
+    its field-offset test must be the ones tools/gen_rust_layout.py derives from include/hanamaru_hip.h with the C compiler, so that the first
+    `cargo build` fails loudly on a layout disagreement instead of mis-reading a scene."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_layout.py"), "--check"]).returncode == 0, "run tools/gen_rust_layout.py"
+    src = open(os.path.join(root, "rust", "hip_ffi.rs")).read()
+    assert "size_of::<HrElement>() == 232" in src and "pub const HR_ABI_VERSION: i32 = %d;" % int(re.search(r"#define\s+HR_ABI_VERSION\s+(\d+)", open(os.path.join(root, "include", "hanamaru_hip.h")).read()).group(1)) in src
