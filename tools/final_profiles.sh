@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r03
-TAG=${1:-r03}
+# Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r04
+TAG=${1:-r04}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -18,17 +18,15 @@ python bench.py --bvh-builder 1 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench
 python bench.py --bvh-builder 2 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
 # N > 1 exactly as the driver runs N = 1 (no launcher): one process, two contexts; on this 1-GPU box both share device 0
 python bench.py --gpus 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_gpus2_one_device.json.log 2>> $OUT/bench_full.err
+# the command lines of BASELINE configs 4 and 5 with everything but the node: eight contexts on this one device at full size (8 x 2 hand-off
+# buffers of 4.25 GB + 8 scenes in HBM), weak scaling as the driver runs it and the fixed totals of C4 / C5 cut to 64 / 32 samplings
+python bench.py --gpus 8 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_gpus8_one_device.json.log 2>> $OUT/bench_full.err
+python bench.py --gpus 8 --total-samplings 64 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_c4_strong_64_of_4096_one_device.json.log 2>> $OUT/bench_full.err
+python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --gpus 8 --total-samplings 32 --steps 2 --warmup 1 --max-tail-gib 5 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_c5_strong_32_of_1024_one_device.json.log 2>> $OUT/bench_full.err
 python bench.py --russian-roulette 3 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_russian_roulette_nonparity.json.log 2>> $OUT/bench_full.err
-python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian" 2>&1 | grep -E "^\.?parity|simple \+|device builder|russian roulette|passed|failed" > $OUT/${TAG}_parity_lines.txt
+python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian or per_path or post_chain" 2>&1 | grep -E "^\.?parity|simple \+|device builder|builder [0-9]|4 M tri|4K post|per-path|russian roulette|passed|failed" > $OUT/${TAG}_parity_lines.txt
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
-python tools/seedprof_ps.py > $OUT/${TAG}_seed_ps_phases.txt 2>&1
-python tools/seedprof.py 16 4 > $OUT/${TAG}_seed_w5_phases.txt 2>&1
-tools/bin/issueprobe > $OUT/${TAG}_issueprobe.txt 2>&1
-tools/bin/roundprobe2 > $OUT/${TAG}_roundprobe2.txt 2>&1
-tools/bin/roundprobe3 > $OUT/${TAG}_roundprobe3.txt 2>&1
-tools/bin/roundprobe4 > $OUT/${TAG}_roundprobe4_raw.txt 2>&1
-tools/bin/simdprobe > $OUT/${TAG}_simdprobe.txt 2>&1
 tools/prof_pmc.sh $OUT/pmc $TAG > $OUT/pmc.log 2>&1
 cp $OUT/pmc/summary.txt $OUT/${TAG}_pmc_summary.txt; cp $OUT/pmc/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
 tail -3 $OUT/pytest_gpu.log; cat $OUT/${TAG}_bench_full_unprofiled.json.log | head -c 400; echo; cat $OUT/${TAG}_bench_kernel_stats.md | head -12
