@@ -433,8 +433,10 @@ def main():
                 "phase_share_of_wave_cycles": share,
                 # north_star's "traversal section": the box + leaf phases' share of the wave cycles applied to the kernel's time
                 "traversal_section": {"share_of_wave_cycles": round(trav_share, 3), "ms_per_launch": round(avg_ms * trav_share, 4),
-                                      "achieved": round(sgbs / max(trav_share, 1e-9), 1), "frac": round(sgbs / max(trav_share, 1e-9) / HBM_PEAK_GBS, 4),
-                                      "note": "all of the kernel's traversal bytes (8(d) booking) over the time its waves spend in the box and leaf phases (shade and refill excluded)"}})
+                                      "achieved": round(gbs / max(trav_share, 1e-9), 1), "frac": round(gbs / max(trav_share, 1e-9) / HBM_PEAK_GBS, 4),
+                                      "survey_8d_normalised": round(sgbs / max(trav_share, 1e-9) / HBM_PEAK_GBS, 4),
+                                      "note": "the bytes the lanes load for the traversal (loaded_bytes) over the time the kernel's waves spend in the box and leaf phases (shade and "
+                                              "refill excluded), against the HBM peak; survey_8d_normalised: the same with SURVEY 8(d)'s byte booking — not a physical fraction, it may pass 1"}})
             out["rays_per_s_M"] = round(value * counters["rays"] / npaths, 1)
             if alone_ms:
                 roof.update({"avg_launch_ms_alone": round(alone_ms, 4), "achieved_alone": round(sgbs * avg_ms / alone_ms, 1),
