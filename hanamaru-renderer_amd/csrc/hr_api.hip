@@ -1392,10 +1392,20 @@ int hr_debug_trace(hr_ctx *c, uint32_t n, const float *rays, const float *shadow
     if (e == hipSuccess) {
         RenderParams rp{};
         rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll;
-        // the record format hr_render walks on this scene
-        if (c->dsc.qnodes) hipLaunchKernelGGL((trace_debug_kernel<true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
-        else hipLaunchKernelGGL((trace_debug_kernel<false>), dim3((n + 63) / 64), dim3(64), 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
+        // the record format hr_render walks on this scene; timed with HIP events (hr_stats.debug_kernel_ms), counted with option "counters"
+        EventPair ev{nullptr, nullptr};
+        (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);
+        (void)hipEventRecord(ev.a, c->stream);
+        const dim3 g((n + 63) / 64), b(64);
+        if (c->counters) {
+            if (c->dsc.qnodes) hipLaunchKernelGGL((trace_debug_kernel<true, true>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el, c->d_counters);
+            else hipLaunchKernelGGL((trace_debug_kernel<false, true>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el, c->d_counters);
+        } else if (c->dsc.qnodes) hipLaunchKernelGGL((trace_debug_kernel<true>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
+        else hipLaunchKernelGGL((trace_debug_kernel<false>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
         e = hipGetLastError();
+        (void)hipEventRecord(ev.b, c->stream);
+        c->debug_events.push_back(ev);
+        c->debug_launches++;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 8 * 4, hipMemcpyDeviceToHost);

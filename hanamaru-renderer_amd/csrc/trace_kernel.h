@@ -252,9 +252,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(RenderParams rp, const 
 // hr_debug_trace: closest-hit / shadow queries through the PRODUCTION traversal — traverse_wave on the record format the renderer
 // walks, box and leaf phases, two parked leaves, closest-hit culling, and for shadow queries (shadow_len > 0) the search limit of
 // nee_setup and shadow_early_out.  One wave = 64 rays; lanes whose walk is done idle, as lanes waiting for phase A do in the megakernel.
-template <bool QN>
+// CNT: the counters build (option "counters"): node / primitive tests and lanes per box pass of the queries — what tools/coherence_probe.py reads
+template <bool QN, bool CNT = false>
 __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams rp, uint32_t n, const float *__restrict__ rays, const float *__restrict__ shadow_len,
-                                                         float *__restrict__ out, int32_t *__restrict__ out_elem) {
+                                                         float *__restrict__ out, int32_t *__restrict__ out_elem, Counters *cnt = nullptr) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     const bool active = i < n;
     const uint32_t j = active ? i : 0u;
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams 
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     uint32_t tick = 0;
-    traverse_wave<false, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws, tick, rp.trace_boost);
+    traverse_wave<CNT, QN>(sc, rp, p, active, n_active, 0u, rp.leaf_den ? rp.leaf_den : 2u, lc, ws, tick, rp.trace_boost);
+    if (CNT) { if (active) lc.rays++; flush_counters<CNT>(cnt, threadIdx.x & 63u, active ? 1u : 0u, lc, ws); }
     if (!active) return;
     float *o = out + (size_t)i * 8;
     int32_t elem = -1;
