@@ -319,7 +319,10 @@ def test_textured_emitter_and_image_roughness(scenes):
         assert np.allclose(hit["emission"], _bilinear_numpy(sc2.image(0), 0.25, 0.5) * np.array(e.material.emission.color.tuple()), rtol=1e-12)
 
 
-@pytest.mark.parametrize("x0,y0", [(200, 100), (300, 930), (936, 562), (1300, 420)])
+@pytest.mark.parametrize("x0,y0", [(200, 100), (300, 930), (936, 562), (1300, 420),
+                                   # round 4: every material of the scene — green armadillo (GGX), glass armadillo (Refraction), blue and magenta
+                                   # armadillos, the bunny's wire (GGX, lit from inside), the frame, the mirror's picture of the lamps, the floor's lettering
+                                   (420, 660), (820, 840), (1440, 700), (1180, 500), (900, 460), (1540, 300), (1200, 230), (760, 1000)])
 def test_oracle_reproduces_the_reference_binarys_committed_render(scenes, orc, x0, y0):
     """tests/golden/reference_rtcamp6_1000x4spp.png is the output of the REAL reference binary (committed in its repository,
     README.md:19: default scene, 1920x1080, -s 1000).  The oracle renders small crops of that exact configuration (seeds
