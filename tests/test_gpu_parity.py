@@ -459,6 +459,8 @@ def test_error_paths(ha):
     with pytest.raises(ha.HipError) as e:
         r.render(1, 2)
     assert e.value.code == -4          # no target
+    raw = np.zeros((4, 4, 4, 8), dtype=np.uint32)
+    assert r.L.hr_debug_path_log(r._h, 1, raw.ctypes.data) == -4 and r.L.hr_debug_path_log(r._h, 1, None) == -1
     r.set_resolution(4, 4)
     r.render(5, 5)                     # empty range is a no-op
     assert not r.read_accumulator().any()
