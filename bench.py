@@ -135,7 +135,7 @@ def main():
     import numpy as np
     import torch
     import hanamaru_amd as ha
-    from hanamaru_amd.sharding import step_range
+    from hanamaru_amd.sharding import step_range, strong_plan, strong_step_range
 
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     launcher = env_world > 1
@@ -176,8 +176,7 @@ def main():
     if S_TOTAL:
         # strong scaling: a fixed total of samplings 1..S_TOTAL, whatever N is.  A step covers SPS * world consecutive sampling
         # indices as always; SPS is chosen so that --steps steps cover S_TOTAL, and the last step is clipped to it.
-        SPS = max(1, -(-S_TOTAL // (args.steps * world)))
-        args.steps = -(-S_TOTAL // (SPS * world))
+        SPS, args.steps = strong_plan(S_TOTAL, args.steps, world)
     scene = ha.Scene(args.scene)
     rs = []
     for _, d in mine:
@@ -239,9 +238,7 @@ def main():
     def run_step(i):
         # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; rank g takes (s-1) % world == g
         for r, (g, _) in zip(rs, mine):
-            b, e, stride = step_range(i, SPS, world, g)
-            if S_TOTAL:
-                e = min(e, S_TOTAL + 1)       # --total-samplings: the last step ends at sampling S_TOTAL
+            b, e, stride = strong_step_range(i, SPS, world, g, S_TOTAL) if S_TOTAL else step_range(i, SPS, world, g)   # --total-samplings: the last step ends at sampling S_TOTAL
             r.render(b, e, stride)
 
     def barrier():

@@ -16,3 +16,16 @@ def step_range(step, samplings_per_rank, world, rank):
 def samplings_of(step, samplings_per_rank, world, rank):
     b, e, s = step_range(step, samplings_per_rank, world, rank)
     return list(range(b, e, s))
+
+
+def strong_plan(total_samplings, steps, world):
+    """bench.py --total-samplings S (strong scaling: BASELINE config 4 is S = 4096 over 8 GPUs): (samplings per step per rank, steps)
+    such that `steps` steps of samplings_per_rank * world consecutive sampling indices cover 1..S — the last step is clipped to S."""
+    sps = max(1, -(-total_samplings // (steps * world)))
+    return sps, -(-total_samplings // (sps * world))
+
+
+def strong_step_range(step, samplings_per_rank, world, rank, total_samplings):
+    """step_range with the end clipped to the total: hr_render(begin, end, stride) arguments (an empty range when begin >= end)."""
+    b, e, s = step_range(step, samplings_per_rank, world, rank)
+    return b, min(e, total_samplings + 1), s

@@ -59,6 +59,24 @@ def test_sharding_covers_every_sampling_once():
             assert sorted(seen) == list(range(1, 3 * sps * world + 1))
 
 
+def test_strong_scaling_plan_covers_exactly_the_total():
+    """bench.py --total-samplings S: whatever S, step count and world size, the ranks' clipped ranges over all steps are the samplings
+    1..S, each exactly once, rank r holding those with (s - 1) mod world == r (BASELINE config 4: S = 4096, world 8; config 5: 1024)."""
+    from hanamaru_amd.sharding import strong_plan, strong_step_range
+    for total, steps, world in [(4096, 32, 8), (1024, 16, 8), (21, 2, 8), (21, 3, 1), (1, 64, 8), (7, 64, 2), (1000, 7, 4), (64, 2, 8), (5, 1, 8)]:
+        sps, nsteps = strong_plan(total, steps, world)
+        assert 1 <= nsteps <= max(steps, 1) and sps * world * nsteps >= total > sps * world * (nsteps - 1)
+        seen = []
+        for step in range(nsteps):
+            for rank in range(world):
+                b, e, st = strong_step_range(step, sps, world, rank, total)
+                got = list(range(b, e, st))
+                assert all((s - 1) % world == rank for s in got) and len(got) <= sps
+                seen += got
+        assert sorted(seen) == list(range(1, total + 1)), (total, steps, world)
+    assert strong_plan(4096, 32, 8) == (16, 32)          # the command of DESIGN.md 7: 16 samplings per step per GPU, as the weak-scaling default
+
+
 @pytest.mark.timeout(300)
 def test_two_ranks_equal_one(tmp_path, emu, ha):
     world = 2
