@@ -192,6 +192,7 @@ struct Scene {
     const TriT *tris; const TriS *tri_shade;   // leaf-ordered, one pair per triangle reference
     const uint32_t *tri_face;                  // leaf-ordered: index of the input triangle each reference belongs to (hr_debug_path_log only)
     const f4 *spheres; const int32_t *sphere_elem;
+    const f4 *sphere_lo;     // per sphere: what rounding its f64 centre and radius to `spheres[]` took away (c - (float)c, r - (float)r) — hit_surface only
     const f4 *cuboids;       // 2 per cuboid: {min, element-as-int-bits}, {max, 0}
     const Material *materials;
     const uint32_t *texels;

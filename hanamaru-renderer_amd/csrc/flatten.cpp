@@ -88,7 +88,7 @@ Scene HostScene::view() const {
     d.nodes = nodes.data(); d.tris = tri_t.data(); d.tri_shade = tri_s.data(); d.tri_face = tri_face.data();
     d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
     for (int k = 0; k < 3; k++) { d.qmin[k] = qmin[k]; d.qstep[k] = qstep[k]; }
-    d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.cuboids = cuboids.data();
+    d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.sphere_lo = sphere_lo.data(); d.cuboids = cuboids.data();
     d.materials = materials.data(); d.texels = texels.data(); d.images = images.data(); d.emitters = emitters.data();
     d.num_nodes = num_nodes; d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
     d.num_cuboids = (uint32_t)(cuboids.size() / 2); d.num_elements = (uint32_t)materials.size(); d.num_emitters = (uint32_t)emitters.size();
@@ -105,7 +105,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     if (!sd->elements || sd->num_elements == 0) return ferr(err, HR_ERR_INVALID, "scene has no elements");
     struct TriD { double v0[3], v1[3], v2[3]; int32_t elem; };
     std::vector<TriD> tris;
-    std::vector<f4> spheres; std::vector<int32_t> sphere_elem;
+    std::vector<f4> spheres, sphere_lo; std::vector<int32_t> sphere_elem;
     std::vector<f4> cuboids;
     std::vector<BuildPrim> prims;        // one reference per primitive
     std::vector<BuildPrim> prims_split;  // triangles cut by early split clipping (when enabled), other primitives as they are
@@ -156,6 +156,10 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
             prims_split.push_back(p);
             spheres.push_back(f4{(float)e.center.x, (float)e.center.y, (float)e.center.z, (float)e.radius});
             sphere_elem.push_back((int32_t)ei);
+            {   // a small sphere divides an error of its centre by its radius: the f64 hit point / normal code gets the centre the reference has
+                const f4 &q = spheres.back();
+                sphere_lo.push_back(f4{(float)(e.center.x - (double)q.x), (float)(e.center.y - (double)q.y), (float)(e.center.z - (double)q.z), (float)(e.radius - (double)q.w)});
+            }
             // Scene::emissions (scene.rs:356-358): nee_available() (spheres only, scene.rs:89) && emission tint != 0
             if (e.material.emission.color.x != 0.0 || e.material.emission.color.y != 0.0 || e.material.emission.color.z != 0.0) {
                 Emitter em{};
@@ -247,8 +251,8 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         d.face = bvh.order[0][i];
     }
     if (host_bvh) out.derive_triangles();   // (the device builders derive the records in their gather, in leaf order)
-    out.spheres.resize(spheres.size()); out.sphere_elem.resize(spheres.size());
-    for (size_t i = 0; i < spheres.size(); i++) { out.spheres[i] = spheres[bvh.order[1][i]]; out.sphere_elem[i] = sphere_elem[bvh.order[1][i]]; }
+    out.spheres.resize(spheres.size()); out.sphere_elem.resize(spheres.size()); out.sphere_lo.resize(spheres.size());
+    for (size_t i = 0; i < spheres.size(); i++) { out.spheres[i] = spheres[bvh.order[1][i]]; out.sphere_elem[i] = sphere_elem[bvh.order[1][i]]; out.sphere_lo[i] = sphere_lo[bvh.order[1][i]]; }
     out.cuboids.resize(cuboids.size());
     for (size_t i = 0; i < cuboids.size() / 2; i++) { out.cuboids[2 * i] = cuboids[2 * bvh.order[2][i]]; out.cuboids[2 * i + 1] = cuboids[2 * bvh.order[2][i] + 1]; }
 

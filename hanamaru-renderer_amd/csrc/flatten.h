@@ -24,6 +24,7 @@ struct HostScene {
     void derive_triangles();
     std::vector<f4> spheres;
     std::vector<int32_t> sphere_elem;
+    std::vector<f4> sphere_lo;         // Scene::sphere_lo
     std::vector<f4> cuboids;
     std::vector<Material> materials;
     std::vector<ImageRef> images;

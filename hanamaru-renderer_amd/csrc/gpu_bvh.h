@@ -141,7 +141,7 @@ __global__ void tri_derive_kernel(const Tri *in, uint32_t n, TriT *tris, TriS *t
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { tri_derive(in[i], tris[i], tri_shade[i]); tri_face[i] = in[i].face; }
 }
-__global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_pos, int n, TriT *tris, TriS *tri_shade, uint32_t *tri_face, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *cuboids) {
+__global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_pos, int n, TriT *tris, TriS *tri_shade, uint32_t *tri_face, f4 *spheres, int32_t *sphere_elem, const int32_t *sphere_elem_in, f4 *sphere_lo, const f4 *sphere_lo_in, f4 *cuboids) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t i = key_index(p, keys[k]), d = prim_pos[k];
@@ -149,7 +149,7 @@ __global__ void gather_kernel(Prims p, const mkey_t *keys, const uint32_t *prim_
     else if (i < p.num_tris + p.num_spheres) {
         uint32_t l = i - p.num_tris;
         d -= p.num_tris;
-        spheres[d] = p.spheres[l]; sphere_elem[d] = sphere_elem_in[l];
+        spheres[d] = p.spheres[l]; sphere_elem[d] = sphere_elem_in[l]; sphere_lo[d] = sphere_lo_in[l];
     } else {
         uint32_t l = i - p.num_tris - p.num_spheres;
         d -= p.num_tris + p.num_spheres;

@@ -464,6 +464,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     LBVH_ALLOC(tri_face, uint32_t, p.num_tris, true)
     LBVH_ALLOC(spheres, f4, d.num_spheres, true)
     LBVH_ALLOC(sphere_elem, int32_t, d.num_spheres, true)
+    LBVH_ALLOC(sphere_lo, f4, d.num_spheres, true)
     LBVH_ALLOC(cuboids, f4, 2 * (size_t)d.num_cuboids, true)
     size_t sort_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys, n, 0, 64, c->stream);
@@ -544,7 +545,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
         finish_kernel<<<(N + T - 1) / T, T, 0, st>>>(p, n, w, prim_pos);
         frame_kernel<<<1, 64, 0, st>>>(w, frame);
         emit_kernel<<<(8 * N + T - 1) / T, T, 0, st>>>(n, w, frame, nodes, qnodes);
-        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, tri_shade, tri_face, spheres, sphere_elem, d.sphere_elem, cuboids);
+        gather_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, prim_pos, n, tris, tri_shade, tri_face, spheres, sphere_elem, d.sphere_elem, sphere_lo, d.sphere_lo, cuboids);
         e = hipGetLastError();
     }
     (void)hipEventRecord(eb, st);
@@ -564,7 +565,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     d.qnodes = c->quant_nodes ? qnodes : nullptr;
     for (int a = 0; a < 3; a++) { d.qmin[a] = hframe[a]; d.qstep[a] = hframe[3 + a]; }
 
-    d.tris = tris; d.tri_shade = tri_shade; d.tri_face = tri_face; d.spheres = spheres; d.sphere_elem = sphere_elem; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
+    d.tris = tris; d.tri_shade = tri_shade; d.tri_face = tri_face; d.spheres = spheres; d.sphere_elem = sphere_elem; d.sphere_lo = sphere_lo; d.cuboids = cuboids;   // the input-order copies stay in scene_allocs until the next upload
     d.num_tris = p.num_tris;   // leaf-ordered records: one per reference (a split triangle appears once per piece)
     return HR_OK;
 }
@@ -589,6 +590,7 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.tris, &tris_in))) return r;
     if ((r = upload(c, hs.spheres, &d.spheres))) return r;
     if ((r = upload(c, hs.sphere_elem, &d.sphere_elem))) return r;
+    if ((r = upload(c, hs.sphere_lo, &d.sphere_lo))) return r;
     if ((r = upload(c, hs.cuboids, &d.cuboids))) return r;
     if ((r = upload(c, hs.materials, &d.materials))) return r;
     if ((r = upload(c, hs.images, &d.images))) return r;

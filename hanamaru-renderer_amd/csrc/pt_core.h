@@ -301,17 +301,20 @@ HD double hr_rsqrt_f64(double x) {
 // scenes by the per-path accounting of round 4: 1,800 ppm of the paths that took the reference's branches were off by more than 1e-3
 // before, 540 ppm after; what is left is the fp32 rounding of the sampled directions and of the draws themselves).
 struct SphHit { float px, py, pz, nx, ny, nz; };
-HD SphHit sphere_surface_f64(float sx, float sy, float sz, float sw, double ox, double oy, double oz, double dx, double dy, double dz) {
-    const double ax = ox - (double)sx, ay = oy - (double)sy, az = oz - (double)sz;
+// (cx, cy, cz, cr): the sphere in f64 — its fp32 record plus what rounding it took away (Scene::sphere_lo).  The reference holds centres in
+// f64; an fp32 centre is off by 3e-8 |c|, and the normal of an r = 0.1 sphere by ten times that — measured (round 4, per-path accounting):
+// it was the LARGEST term left in the sphere scenes' same-branch error (563 -> 95 ppm of the paths beyond 1e-3 in `spheres`).
+HD SphHit sphere_surface_f64(double cx, double cy, double cz, double cr, double ox, double oy, double oz, double dx, double dy, double dz) {
+    const double ax = ox - cx, ay = oy - cy, az = oz - cz;
     const double idd = 2.0 - fma(dx, dx, fma(dy, dy, dz * dz));
     const double b = fma(ax, dx, fma(ay, dy, az * dz)) * idd;
     const double qx = fma(-b, dx, ax), qy = fma(-b, dy, ay), qz = fma(-b, dz, az);
-    const double disc = fma((double)sw, (double)sw, -fma(qx, qx, fma(qy, qy, qz * qz))) * idd;
+    const double disc = fma(cr, cr, -fma(qx, qx, fma(qy, qy, qz * qz))) * idd;
     const double t = -b - hr_sqrt_f64(disc > 0.0 ? disc : 0.0);     // (a grazing hit the f64 ray just misses: the tangent point)
     const double nx = fma(t, dx, ax), ny = fma(t, dy, ay), nz = fma(t, dz, az);
     const double il = hr_rsqrt_f64(fma(nx, nx, fma(ny, ny, nz * nz)));
     SphHit h;
-    h.px = (float)((double)sx + nx); h.py = (float)((double)sy + ny); h.pz = (float)((double)sz + nz);
+    h.px = (float)(cx + nx); h.py = (float)(cy + ny); h.pz = (float)(cz + nz);
     h.nx = (float)(nx * il); h.ny = (float)(ny * il); h.nz = (float)(nz * il);
     return h;
 }
@@ -323,10 +326,10 @@ HD SphHit sphere_surface_f64(float sx, float sy, float sz, float sw, double ox, 
 #else
 #define HR_NOINLINE inline
 #endif
-HR_NOINLINE SphHit sphere_surface(float sx, float sy, float sz, float sw, float ox, float oy, float oz, float dx, float dy, float dz, float dox, float doy, float doz,
-                                  float ddx, float ddy, float ddz) {
-    return sphere_surface_f64(sx, sy, sz, sw, (double)ox + (double)dox, (double)oy + (double)doy, (double)oz + (double)doz, (double)dx + (double)ddx,
-                              (double)dy + (double)ddy, (double)dz + (double)ddz);
+HR_NOINLINE SphHit sphere_surface(float sx, float sy, float sz, float sw, float lx, float ly, float lz, float lw, float ox, float oy, float oz, float dx, float dy, float dz,
+                                  float dox, float doy, float doz, float ddx, float ddy, float ddz) {
+    return sphere_surface_f64((double)sx + (double)lx, (double)sy + (double)ly, (double)sz + (double)lz, (double)sw + (double)lw, (double)ox + (double)dox,
+                              (double)oy + (double)doy, (double)oz + (double)doz, (double)dx + (double)ddx, (double)dy + (double)ddy, (double)dz + (double)ddz);
 }
 // the residuals of a path's first ray (zero: any other ray)
 struct RayFix { V3f o, d; };
@@ -348,7 +351,8 @@ HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool wa
         const f4 sp = sc.spheres[ts.prim];
         s.elem = sc.sphere_elem[ts.prim];
         {
-            const SphHit h = sphere_surface(sp.x, sp.y, sp.z, sp.w, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, fix.o.x, fix.o.y, fix.o.z, fix.d.x, fix.d.y, fix.d.z);
+            const f4 lo = sc.sphere_lo[ts.prim];
+            const SphHit h = sphere_surface(sp.x, sp.y, sp.z, sp.w, lo.x, lo.y, lo.z, lo.w, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, fix.o.x, fix.o.y, fix.o.z, fix.d.x, fix.d.y, fix.d.z);
             s.pos = v3(h.px, h.py, h.pz);
             s.n = v3(h.nx, h.ny, h.nz);
         }

@@ -237,13 +237,14 @@ static void device_build_host(HostScene &hs, int max_leaf, int builder, double s
     std::vector<Tri> tris(p.num_tris);
     std::vector<f4> spheres(hs.spheres.size()), cuboids(hs.cuboids.size());
     std::vector<int32_t> sphere_elem(hs.sphere_elem.size());
+    std::vector<f4> sphere_lo(hs.sphere_lo.size());
     for (int k = 0; k < n; k++) {
         uint32_t i = key_index(p, keys[k]), d = prim_pos[k];
         if (i < p.num_tris) tris[d] = hs.tris[p.ref_tri ? p.ref_tri[i] : i];
-        else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris; d -= p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; }
+        else if (i < p.num_tris + p.num_spheres) { uint32_t l = i - p.num_tris; d -= p.num_tris; spheres[d] = hs.spheres[l]; sphere_elem[d] = hs.sphere_elem[l]; sphere_lo[d] = hs.sphere_lo[l]; }
         else { uint32_t l = i - p.num_tris - p.num_spheres; d -= p.num_tris + p.num_spheres; cuboids[2 * d] = hs.cuboids[2 * l]; cuboids[2 * d + 1] = hs.cuboids[2 * l + 1]; }
     }
-    hs.tris.swap(tris); hs.derive_triangles(); hs.spheres.swap(spheres); hs.sphere_elem.swap(sphere_elem); hs.cuboids.swap(cuboids);
+    hs.tris.swap(tris); hs.derive_triangles(); hs.spheres.swap(spheres); hs.sphere_elem.swap(sphere_elem); hs.sphere_lo.swap(sphere_lo); hs.cuboids.swap(cuboids);
     // leaves / depth of the emitted tree for the stats call
     hs.bvh_leaves = 0; hs.bvh_max_depth = 0;
     std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}};
