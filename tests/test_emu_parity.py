@@ -450,3 +450,26 @@ def test_per_path_event_log(emu_scenes, name, w, h):
     else:
         assert sb["no_sphere_bounce"]["over_1e-3_floor1_ppm"] == 0.0 and sb["over_1e-3_floor1_ppm"] <= 1500.0, sb
         assert all(int(k) >= 2 for k in sb["over_1e-3_by_sphere_bounces_ppm"]), sb  # the tail needs at least two sphere bounces
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_scenes_path_by_path(ha, orc, emu, seed):
+    """Fuzz tier (tests/random_scenes.py): every element kind x surface type x textured / constant parameters, overlapping and nested —
+    combinations the reference's scenes do not contain.  The host emulation of the per-lane code against the oracle, path by path: the
+    same rays per path on every same-branch path, few divergent paths, no systematic difference."""
+    import path_parity
+    import random_scenes
+    sc = random_scenes.build(ha, seed)
+    o = orc.OracleScene(sc.desc_ptr)
+    e = emu.EmuScene(sc.desc_ptr)
+    w, h = 96, 54
+    a = path_parity.account(e.path_log(w, h, 1), o.path_log(w, h, 1))
+    sb = a["same_branch"]
+    print("random scene %d: divergent %.0f ppm %s, same-branch over 1e-3 %.0f ppm, max %.3g, mean %.6g / %.6g" % (
+        seed, a["divergent_ppm"], a["divergent_by_class_ppm"], sb["over_1e-3_floor1_ppm"], sb["max_rel_floor1"], a["mean_radiance"]["gpu"], a["mean_radiance"]["oracle"]))
+    assert sb["rays_equal"] and a["divergent_ppm"] <= 3000.0 and sb["over_1e-3_floor1_ppm"] <= 3000.0, a
+    assert abs(a["mean_radiance"]["gpu"] - a["mean_radiance"]["oracle"]) <= 5e-3 * a["mean_radiance"]["oracle"], a["mean_radiance"]
+    acc, _ = e.render(w, h, 1, 3)
+    ref, _ = o.render(w, h, 1, 3)
+    rel = np.abs(acc - ref) / np.maximum(1.0, np.abs(ref))
+    assert np.isfinite(acc).all() and (rel <= 1e-2).mean() >= 0.997, (rel <= 1e-2).mean()
