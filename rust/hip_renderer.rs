@@ -78,6 +78,8 @@ impl Flat {
 
 impl HipRenderer {
     pub fn new(sampling: u32, time_limit_sec: f64, report_interval_sec: f64) -> HipRenderer {
+        // the #[repr(C)] mirrors of hip_ffi.rs were generated for this ABI (their sizes are compile-time assertions there)
+        assert_eq!(unsafe { hr_abi_version() }, HR_ABI_VERSION, "libhanamaru_hip.so and hip_ffi.rs disagree about the ABI version");
         let mut ctx: *mut HrCtx = ptr::null_mut();
         check(unsafe { hr_create(0, &mut ctx) });
         let now = time::now();
