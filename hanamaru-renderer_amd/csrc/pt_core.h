@@ -338,7 +338,29 @@ HD RayFix no_ray_fix() { RayFix f; f.o = v3(0, 0, 0); f.d = v3(0, 0, 0); return 
 // 2a + 2 .. 2a + 19 (renderer.rs:175 for iterations 1 .. 9), the slots before are rejected lens attempts, the slots from 2a + 20 on spare
 // (a <= LENS_FAST - 1 = 4, REC_DRAWS = 28: at least 10 dead slots; the path's radiance goes to slots 0 .. 3 when it ENDS).  Pairs of slots
 // are 8 contiguous bytes (rec_slot), the first is even.
+// The six slots are consecutive (modulo REC_DRAWS) from the even slot 2a + 20: a quad (16 contiguous bytes) and a pair (8), in the order the
+// alignment of the first slot dictates — two stores / two loads per path, two 32-byte sectors of its record.
 HD uint32_t ray_fix_slot(uint32_t twice_a, uint32_t k) { uint32_t s = twice_a + 20u + 2u * k; return s >= (uint32_t)REC_DRAWS ? s - (uint32_t)REC_DRAWS : s; }
+HD void ray_fix_store(float *recs, uint32_t lb, uint32_t twice_a, V3f fo, V3f fd) {
+    if ((twice_a & 2u) == 0u) {   // 2a + 20 is a multiple of 4: quad, then pair
+        *reinterpret_cast<f4 *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 0u))) = f4{fo.x, fo.y, fo.z, fd.x};
+        *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 2u))) = f2v{fd.y, fd.z};
+    } else {                      // pair, then quad
+        *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 0u))) = f2v{fo.x, fo.y};
+        *reinterpret_cast<f4 *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 1u))) = f4{fo.z, fd.x, fd.y, fd.z};
+    }
+}
+HD void ray_fix_load(const float *recs, uint32_t lb, uint32_t twice_a, V3f &fo, V3f &fd) {
+    if ((twice_a & 2u) == 0u) {
+        const f4 q = *reinterpret_cast<const f4 *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 0u)));
+        const f2v r = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 2u)));
+        fo = v3(q.x, q.y, q.z); fd = v3(q.w, r[0], r[1]);
+    } else {
+        const f2v r = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 0u)));
+        const f4 q = *reinterpret_cast<const f4 *>(recs + rec_slot(lb, ray_fix_slot(twice_a, 1u)));
+        fo = v3(r[0], r[1], q.x); fd = v3(q.y, q.z, q.w);
+    }
+}
 
 HD void hit_surface(const Scene &sc, const Ray &r, const TraceState &ts, bool want_uv, Surf &s, const RayFix &fix) {
     s.pos = r.o + r.d * ts.t;
@@ -620,9 +642,8 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
     const double il = hr_rsqrt_f64(fma(vx, vx, fma(vy, vy, vz * vz)));
     const double o64x = c.eye[0] + lpx, o64y = c.eye[1] + lpy, o64z = c.eye[2] + lpz, d64x = vx * il, d64y = vy * il, d64z = vz * il;
     const V3f o = v3((float)o64x, (float)o64y, (float)o64z), d = v3((float)d64x, (float)d64y, (float)d64z);
-    *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 0u))) = f2v{(float)(o64x - (double)o.x), (float)(o64y - (double)o.y)};
-    *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 1u))) = f2v{(float)(o64z - (double)o.z), (float)(d64x - (double)d.x)};
-    *reinterpret_cast<f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 2u))) = f2v{(float)(d64y - (double)d.y), (float)(d64z - (double)d.z)};
+    ray_fix_store(recs, lb, a2, v3((float)(o64x - (double)o.x), (float)(o64y - (double)o.y), (float)(o64z - (double)o.z)),
+                  v3((float)(d64x - (double)d.x), (float)(d64y - (double)d.y), (float)(d64z - (double)d.z)));
     ray_set(p.ray, o, d);
     ray_quantise(sc, p.ray);
     p.st = 1u;            // iteration 1, main ray
@@ -712,10 +733,7 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         RayFix fix = no_ray_fix();
         if (p.ts.type == 1 && path_iter(p) == 1u) {   // a primary ray on a sphere: hit point and normal from the f64 camera ray (path_start's residuals)
             const uint32_t lb = path_draw_base(p), a2 = (p.q >> 12) & 15u;
-            const f2v fo = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 0u)));
-            const f2v fm = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 1u)));
-            const f2v fd = *reinterpret_cast<const f2v *>(recs + rec_slot(lb, ray_fix_slot(a2, 2u)));
-            fix.o = v3(fo[0], fo[1], fm[0]); fix.d = v3(fm[1], fd[0], fd[1]);
+            ray_fix_load(recs, lb, a2, fix.o, fix.d);
         }
         hit_surface(sc, p.ray, p.ts, material_needs_uv(sc, hit_element(sc, p.ts)), s, fix);
         PointMat m;
