@@ -268,3 +268,19 @@ def test_a_perturbed_literal_is_caught(ha, orc, path, delta):
     sc = ha.Scene(path[0])
     with pytest.raises(AssertionError):
         compare(fx, sc.desc, ha, ha.ASSET_ROOT, orc)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/main.rs"), reason="the reference is only present in the build container")
+def test_fixture_is_what_the_extractor_reads_from_the_reference():
+    """provenance of tests/golden/scene_literals.json: re-running tools/extract_scene_literals.py on the reference's main.rs gives the committed
+    data, number for number (build container only — the GPU box has no /root/reference)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "extract_scene_literals.py"), "/root/reference/src/main.rs"], stdout=subprocess.PIPE, text=True, check=True).stdout
+    fresh = json.loads(out)
+    for name, data in FIX.items():
+        if name.startswith("_"):
+            continue
+        assert fresh[name] == data, name
+    assert sorted(k for k, v in fresh.items() if isinstance(v, dict) and "error" in v) == sorted(FIX["_not_extracted"])
