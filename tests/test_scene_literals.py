@@ -21,7 +21,7 @@ FIX = json.load(open(os.path.join(HERE, "golden", "scene_literals.json")))
 SURFACE = {"Diffuse": 0, "Specular": 1, "Refraction": 2, "GGX": 3, "GGXRefraction": 4}
 # scene name of the host library -> function of the reference
 SCENES = {"simple": "simple", "material_examples": "material_examples", "rtcamp5": "rtcamp5", "tbf3": "tbf3", "rtcamp6_v1": "rtcamp6_v1",
-          "rtcamp6_v2": "rtcamp6_v2", "rtcamp6_v3": "rtcamp6_v3"}
+          "rtcamp6_v2": "rtcamp6_v2", "rtcamp6_v3": "rtcamp6_v3", "rtcamp6_v3_1": "rtcamp6_v3_1"}
 
 
 # ---- the reference's arithmetic, restated (each operation in the reference's order, so that results are equal to the last bit)
@@ -196,6 +196,11 @@ def compare(fx, desc, ha, assets, orc):
         assert np.array_equal(_image(desc, desc.skybox.face_image[k]), ha.decode_image(os.path.join(assets, fx["skybox"]["dir"], face))), "skybox face %d" % k
     elems, attempts = replay(fx, assets, orc)
     assert desc.num_elements == len(elems), (desc.num_elements, len(elems))
+    compare_elements(elems, desc, ha, assets)
+    return elems, attempts
+
+
+def compare_elements(elems, desc, ha, assets):
     for i, want in enumerate(elems):
         e = desc.elements[i]
         where = "element %d (%s)" % (i, want["kind"])
@@ -220,7 +225,6 @@ def compare(fx, desc, ha, assets, orc):
             assert (t.image >= 0) == (img is not None), (where, k)
             if img is not None:
                 assert np.array_equal(_image(desc, t.image), ha.decode_image(os.path.join(assets, img))), (where, k, img)
-    return elems, attempts
 
 
 def _image(desc, i):
@@ -254,7 +258,21 @@ def test_spheres_scene_is_the_rtcamp6_v2_generator_with_two_materials(ha, orc):
             assert e.material.surface == 0 and v3(e.material.emission.color) == pytest.approx(want["material"]["emission"][0], abs=1e-15)
 
 
-@pytest.mark.parametrize("path,delta", [(("simple", "fixed", 1, "radius"), 1e-9), (("simple", "camera", "fov"), 1e-7), (("material_examples", "fixed", 3, "material", "param"), 1e-6),
+def test_config5_scene_is_the_headline_scene_plus_the_dodecahedron(ha, orc):
+    """BASELINE config 5 is build-defined: rtcamp6_v3_1 — camera, skybox, all eleven elements as the reference's literals
+    give them — plus models/fractal_dodecahedron.obj with the Refraction-1.5 material of main.rs:910-915."""
+    fx = FIX["rtcamp6_v3_1"]
+    elems, _ = replay(fx, ha.ASSET_ROOT, orc)
+    sc = ha.Scene("rtcamp6_dodeca")
+    assert sc.desc.num_elements == len(elems) + 1 == 12
+    compare_elements(elems, sc.desc, ha, ha.ASSET_ROOT)
+    extra = sc.desc.elements[11]
+    assert extra.kind == 2 and extra.num_faces == 7200 and extra.material.surface == 2 and extra.material.param == 1.5
+    cam = camera_new(fx["camera"])
+    np.testing.assert_allclose(v3(sc.desc.camera.eye), cam["eye"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("path,delta", [(("simple", "fixed", 1, "radius"), 1e-9), (("rtcamp6_v3_1", "added", 3, "matrix", 0, 1), 1e-9), (("rtcamp6_v3_1", "camera", "eye", 0), 1e-9), (("simple", "camera", "fov"), 1e-7), (("material_examples", "fixed", 3, "material", "param"), 1e-6),
                                         (("tbf3", "skybox", "intensity", 2), 1e-6), (("rtcamp6_v2", "loops", 0, "draws", 1, 0), 1e-6),
                                         (("rtcamp5", "fixed", 0, "matrix", 1, 1), 1e-7), (("rtcamp6_v1", "fixed", 0, "material", "emission", "color", 0), 1e-6)])
 def test_a_perturbed_literal_is_caught(ha, orc, path, delta):

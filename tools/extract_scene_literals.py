@@ -47,7 +47,7 @@ class Sym:
     def __neg__(self): return Sym(["neg", self.tree])
 
 
-TOKEN = re.compile(r'\s*(?:(\d+\.\d*(?:[eE][-+]?\d+)?|\d+)|("(?:[^"\\]|\\.)*")|([A-Za-z_][A-Za-z0-9_]*)|(::|\.\.|[-+*/(){}\[\],.:;&!<>=]))')
+TOKEN = re.compile(r'\s*(?:(\d+\.\d*(?:[eE][-+]?\d+)?|\d+)|("(?:[^"\\]|\\.)*")|([A-Za-z_][A-Za-z0-9_]*)|(::|\.\.|==|[-+*/%(){}\[\],.:;&!<>=]))')
 
 
 def tokenize(s):
@@ -84,6 +84,13 @@ class Parser:
         return tok
 
     def expr(self):
+        v = self.additive()
+        if self.peek()[1] == "==":             # `i % 2 == 0` in an if-expression
+            self.eat()
+            return v == self.additive()
+        return v
+
+    def additive(self):
         v = self.term()
         while self.peek()[1] in ("+", "-"):
             op = self.eat()[1]
@@ -96,9 +103,12 @@ class Parser:
 
     def term(self):
         v = self.unary()
-        while self.peek()[1] in ("*", "/"):
+        while self.peek()[1] in ("*", "/", "%"):
             op = self.eat()[1]
             r = self.unary()
+            if op == "%":
+                v = math.fmod(v, r)
+                continue
             if isinstance(v, tuple) and v[0] == "matrix" and isinstance(r, tuple) and r[0] == "matrix":
                 v = ("matrix", v[1] + r[1])       # a product of Matrix44 factors: kept as the list of factors, in order
             elif isinstance(v, tuple) and v[0] == "vec":
@@ -170,6 +180,17 @@ class Parser:
             v = self.expr()
             self.eat(")")
             return v
+        if kind == "id" and val == "if":       # if cond { a } else { b }: both arms are parsed, the condition (a constant here) picks one
+            self.eat()
+            cond = self.expr()
+            self.eat("{")
+            a = self.expr()
+            self.eat("}")
+            self.eat("else")
+            self.eat("{")
+            b = self.expr()
+            self.eat("}")
+            return a if cond else b
         if kind == "id":
             path = [self.eat()[1]]
             while self.peek()[1] == "::":
@@ -351,11 +372,25 @@ def extract_scene(body):
     while True:
         ma = re.compile(r"scene\.add\(").search(rest, i)
         mw = re.compile(r"while count < (\d+)\s*\{").search(rest, i)
-        cands = [m for m in (ma, mw) if m]
+        mc = re.compile(r"let count = (\d+);\s*while i < count\s*\{").search(rest, i)     # a counted loop (no draws): unrolled here
+        cands = [m for m in (ma, mw, mc) if m]
         if not cands:
             break
         m = min(cands, key=lambda x: x.start())
-        if m is ma:
+        if m is mc:
+            end = balanced(rest, m.end() - 1, "{", "}")
+            blk = rest[m.end():end]
+            call = blk.index("scene.add(")
+            cend = balanced(blk, call + len("scene.add"), "(", ")")
+            for it in range(int(m.group(1))):
+                lenv = dict(env)
+                lenv["i"], lenv["count"] = float(it), float(m.group(1))
+                for lm in re.finditer(r"let (\w+)\s*=\s*([^;]+);", blk[:call]):
+                    lenv[lm.group(1)] = parse_expr(lm.group(2), lenv)
+                out["added"].append(element(parse_expr(blk[call + len("scene.add("):cend], lenv)))
+                out["order"].append("add:%d" % (len(out["added"]) - 1))
+            i = end
+        elif m is ma:
             end = balanced(rest, m.end() - 1, "(", ")")
             out["added"].append(element(parse_expr(rest[m.end():end], env)))
             out["order"].append("add:%d" % (len(out["added"]) - 1))
