@@ -318,15 +318,12 @@ HD SphHit sphere_surface_f64(double cx, double cy, double cz, double cr, double 
     h.nx = (float)(nx * il); h.ny = (float)(ny * il); h.nz = (float)(nz * il);
     return h;
 }
-// NOT inlined on the device (as sphere_root: the f64 temporaries stay out of the shading code's register budget), one call per sphere hit.
 // The ray is the fp32 ray plus a correction (do, dd): zero for any ray but a path's first — there it is what the fp32 rounding of the f64
-// camera ray took away (path_start computes the camera ray in f64 and parks the two residuals in dead slots of the path's record).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define HR_NOINLINE __device__ __attribute__((noinline))
-#else
-#define HR_NOINLINE inline
-#endif
-HR_NOINLINE SphHit sphere_surface(float sx, float sy, float sz, float sw, float lx, float ly, float lz, float lw, float ox, float oy, float oz, float dx, float dy, float dz,
+// camera ray took away (path_start computes the camera ray in f64 and parks the two residuals in dead slots of the path's record); the
+// sphere is its fp32 record plus (lx, ly, lz, lw) = Scene::sphere_lo.  Inlined (unlike sphere_root, which sits in the leaf phase): as a
+// called function its 20 arguments and the call's clobbers cost the shading code three spilled VGPRs and 1.5 % of the kernel (same-box A/B,
+// round 4); inlined, the f64 block is one spill and the kernel 12.9 -> 12.75 ms alone.
+HD SphHit sphere_surface(float sx, float sy, float sz, float sw, float lx, float ly, float lz, float lw, float ox, float oy, float oz, float dx, float dy, float dz,
                                   float dox, float doy, float doz, float ddx, float ddy, float ddz) {
     return sphere_surface_f64((double)sx + (double)lx, (double)sy + (double)ly, (double)sz + (double)lz, (double)sw + (double)lw, (double)ox + (double)dox,
                               (double)oy + (double)doy, (double)oz + (double)doz, (double)dx + (double)ddx, (double)dy + (double)ddy, (double)dz + (double)ddz);
