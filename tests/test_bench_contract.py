@@ -1,0 +1,51 @@
+"""CPU tier: the bench line committed with this round's profiles carries every field the driver's contract names, and its roofline
+arithmetic is self-consistent (the figures are re-derived from the line's own counts).  Guards bench.py's JSON against drifting away
+from the contract between GPU runs — the line itself is produced on the GPU box (profiles/rNN_bench_full_unprofiled.json.log)."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_full_unprofiled.json.log")))
+    assert files, "no committed bench line"
+    return [json.loads(ln) for ln in open(files[-1]) if ln.startswith("{")][-1], files[-1]
+
+
+def test_committed_bench_line_follows_the_contract():
+    j, path = _latest_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, (k, path)
+    assert j["unit"] == "Mpaths/s" and j["higher_is_better"] is True and j["vs_baseline"] is None and j["dtype"] == "f32" and j["n_gpus"] == 1
+    assert "workload" in j["config"] and "model" not in j["config"] and "rtcamp6_v3_1 1920x1080" in j["config"]["workload"]
+    # value = paths / time: steps x samplings per step x W x H x 4 over steps x ms_per_step
+    assert abs(j["config"]["paths_total"] / (j["steps"] * j["ms_per_step"] * 1e-3) / 1e6 - j["value"]) <= 2e-3 * j["value"]
+    assert j["config"]["paths_total"] == 1920 * 1080 * 4 * j["config"]["samplings_total"]
+    r = j["roofline"]
+    for k in ("bound", "bound_contract", "achieved", "peak", "unit", "frac", "frac_survey_8d", "traffic", "kernel", "pair_bound", "algorithmic_bytes_per_path", "avg_launch_ms"):
+        assert k in r, k
+    assert r["bound_contract"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["kernel"] == "trace_kernel" and r["frac"] == r["frac_survey_8d"]
+    # 32 B per node test + 36 B per triangle test (+ 16 / 24 per sphere / cuboid test: ~24 B per path in this scene)
+    per_path = r["rays_per_path"] * (32 * r["node_tests_per_ray"] + 36 * r["tri_tests_per_ray"])
+    assert per_path <= r["algorithmic_bytes_per_path"] <= per_path + 60
+    achieved = r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+    assert abs(achieved - r["achieved"]) <= 2e-3 * achieved and abs(r["achieved"] / r["peak"] - r["frac"]) <= 1e-3
+    assert 0 < r["loaded_bytes"]["frac"] <= r["frac"] and isinstance(r["traffic"], int) and r["traffic"] > 0 and r["traffic_stale"] is False
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpaths/s" and "sample" in c
+    m = j["multi_gpu"]
+    assert m["accumulator_bytes"] == 1920 * 1080 * 3 * 4 and len(m["per_rank"]) == 1 and m["per_rank"][0]["paths"] == j["config"]["paths_total"]
+
+
+def test_committed_rocprof_summary_agrees_with_the_line():
+    """profiles/rNN_bench_kernel_stats.md (rocprofv3 --kernel-trace --stats of the same command) and the line's HIP-event duration of the
+    dominant kernel agree (the contract asks for that): within 3 %."""
+    j, path = _latest_line()
+    md = open(path.replace("_bench_full_unprofiled.json.log", "_bench_kernel_stats.md")).read()
+    row = [ln for ln in md.splitlines() if "trace_kernel<false, 5, true" in ln][0].split("|")
+    avg_ms = float(row[4])
+    assert abs(avg_ms - j["roofline"]["avg_launch_ms"]) <= 0.03 * avg_ms, (avg_ms, j["roofline"]["avg_launch_ms"])
+    seed = [ln for ln in md.splitlines() if "seed_seg_kernel" in ln][0].split("|")
+    assert abs(float(seed[4]) - j["roofline"]["seed_kernel_avg_ms"]) <= 0.03 * float(seed[4])
