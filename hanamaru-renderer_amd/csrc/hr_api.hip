@@ -181,8 +181,12 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
             if (hi > lo) ov_trace = (float)(hi - lo) / (float)(r1 - r0);
         }
         const int L = (int)g->lvl[0][slot];
-        if (ov_seed > 0.7f && ov_trace > 0.7f && L == (int)g->lvl[1][slot] && L >= 0 && L < GOV_LEVELS) {
-            const float seed_t = (float)(s1 - s0), trace_t = (float)(r1 - r0), m = seed_t > trace_t ? seed_t : trace_t;
+        const float seed_t = (float)(s1 - s0), trace_t = (float)(r1 - r0), m = seed_t > trace_t ? seed_t : trace_t;
+        // (a trace kernel that takes much longer than a seed kernel can never have one beside it for 70 % of its time — rtcamp6_v2 / _v1: 48 and
+        // 38 ms against 26 — and is the slower kernel beyond doubt: such launches count too.  Until round 4 they did not, and the governor sat
+        // at level 0, the wrong end, on exactly the scenes where the trace kernel needs the slots: +2.5 % there.)
+        const bool beside = ov_trace > 0.7f || trace_t > 1.25f * seed_t;
+        if (ov_seed > 0.7f && beside && L == (int)g->lvl[1][slot] && L >= 0 && L < GOV_LEVELS) {
             g->known[L] = g->known[L] > 0 ? 0.5f * (g->known[L] + m) : m;
             g->decisions++;
             if (L == g->level) {   // (a launch that started before the last change of level: noted, nothing decided from it)
