@@ -149,6 +149,8 @@ def main():
     if launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not one_device and torch.cuda.device_count() > local_rank:
+            torch.cuda.set_device(local_rank)      # before the process group exists: its barriers run on this rank's own GPU
         dist.init_process_group(backend="gloo" if one_device else "nccl", rank=rank, world_size=world)
     if one_device:
         local_rank = 0
