@@ -70,6 +70,25 @@ def main():
         a.update({"scene": name, "width": w, "height": h, "sampling": 1})
         out["per_path"]["cases"].append(a)
         print(json.dumps(a))
+    # the same accounting at BASELINE's image size: every path of two samplings of configs 3, 5 (at 1080p) and 2 — 8.3 M paths per case,
+    # so that a ppm figure rests on thousands of paths instead of a handful
+    out["per_path_full_size"] = {"what": "as per_path, 1920x1080 (8,294,400 paths per sampling), samplings 1 and 1000", "cases": []}
+    for name in ("rtcamp6_v3_1", "rtcamp6_dodeca", "spheres"):
+        sc = ha.Scene(name)
+        o = orc.OracleScene(sc.desc_ptr)
+        r.upload_scene(sc)
+        r.set_resolution(1920, 1080)
+        for sampling in (1, 1000):
+            t0 = time.time()
+            g = r.debug_path_log(sampling)
+            t1 = time.time()
+            ref = o.path_log(1920, 1080, sampling)
+            t2 = time.time()
+            a = path_parity.account(g, ref)
+            a.update({"scene": name, "width": 1920, "height": 1080, "sampling": sampling, "gpu_seconds_incl_readback": round(t1 - t0, 3), "oracle_seconds_all_cores": round(t2 - t1, 2)})
+            out["per_path_full_size"]["cases"].append(a)
+            print(json.dumps(a))
+            del g, ref
     json.dump(out, open(sys.argv[1], "w"), indent=1)
 
 
