@@ -356,6 +356,24 @@ def test_per_path_parity_accounting(gpu, scenes, name):
     assert f3 >= predicted, (name, f3, predicted)
 
 
+def test_per_path_parity_at_full_size(gpu, scenes):
+    """The same accounting on EVERY path of one sampling of the headline configuration (1920x1080: 8,294,400 paths; the report in
+    profiles/ holds samplings 1 and 1000, this test takes another one): tens of ppm divergent, a handful of same-branch paths beyond
+    1e-3 in eight million, equal ray counts on every same-branch path."""
+    import path_parity
+    sc, o = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(1920, 1080)
+    a = path_parity.account(gpu.debug_path_log(517), o.path_log(1920, 1080, 517))
+    sb = a["same_branch"]
+    print("per-path full size: %d paths, divergent %.2f ppm %s; same-branch over 1e-3: %.2f ppm, max %.3g, p99.9 %.3g" % (
+        a["paths"], a["divergent_ppm"], a["divergent_by_class_ppm"], sb["over_1e-3_floor1_ppm"], sb["max_rel_floor1"], sb["p999_rel_floor1"]))
+    assert a["paths"] == 1920 * 1080 * 4 and sb["rays_equal"]
+    assert a["divergent_ppm"] <= 40.0 and sb["over_1e-3_floor1_ppm"] <= 3.0 and sb["max_rel_floor1"] <= 0.05 and sb["p999_rel_floor1"] <= 5e-5, a
+    assert abs(a["mean_radiance"]["gpu"] - a["mean_radiance"]["oracle"]) <= 2e-4 * a["mean_radiance"]["oracle"]
+
+
+
 @pytest.mark.parametrize("seed,builder", [(1, 0), (2, 0), (3, 0), (4, 0), (5, 2), (6, 1), (7, 0), (8, 2)])
 def test_random_scenes_path_by_path(gpu, ha, orc, seed, builder):
     """Fuzz tier (tests/random_scenes.py): every element kind x surface type x textured / constant albedo, emission and roughness,
