@@ -509,9 +509,10 @@ int hh_load_obj(const char *path, const double *matrix, hr_vec3 **vertexes, uint
     std::vector<uint64_t> f;
     if (!load_obj(path, m, v, f)) return HR_ERR_INVALID;
     *vertexes = (hr_vec3 *)malloc(v.size() * sizeof(hr_vec3) + 1);
-    memcpy(*vertexes, v.data(), v.size() * sizeof(hr_vec3));
     *faces = (uint64_t *)malloc(f.size() * sizeof(uint64_t) + 1);
-    memcpy(*faces, f.data(), f.size() * sizeof(uint64_t));
+    if (!*vertexes || !*faces) { free(*vertexes); free(*faces); *vertexes = nullptr; *faces = nullptr; set_error("hh_load_obj: out of memory"); return HR_ERR_INVALID; }
+    if (!v.empty()) memcpy(*vertexes, v.data(), v.size() * sizeof(hr_vec3));   // an OBJ file without vertices or faces is legal: empty arrays
+    if (!f.empty()) memcpy(*faces, f.data(), f.size() * sizeof(uint64_t));
     *num_vertexes = v.size();
     *num_faces = f.size() / 3;
     return HR_OK;
