@@ -107,6 +107,14 @@ static inline uint32_t f64_as_u32(double v) {
     if (v >= 4294967295.0) return 4294967295u;
     return (uint32_t)v;
 }
+// Rust `f64 as usize` on a 64-bit target: truncation toward zero, saturating at both ends, NaN -> 0 (the language's defined behaviour since
+// Rust 1.45; a plain C cast of a negative double is undefined and wraps on x86).  It matters for the seed words of renderer.rs:165-166:
+// (4 + nc) goes negative when an image is more than four times as wide as high (or as high as wide) — there the word is 0.
+static inline uint64_t f64_as_usize(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551615.0) return ~0ULL;
+    return (uint64_t)v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // rand 0.4.3 StdRng = Isaac64Rng (public-domain ISAAC-64 by Bob Jenkins)
@@ -697,7 +705,7 @@ struct PathLog {
 };
 // renderer.rs:163-203
 static V3 calc_pixel(const Scene &s, double ncx, double ncy, uint32_t sampling, Counters *cn, PathLog *lg = nullptr) {
-    uint64_t seed[4] = {8700304ULL, (uint64_t)sampling, (uint64_t)((4.0 + ncx) * 100870.0), (uint64_t)((4.0 + ncy) * 100304.0)};
+    uint64_t seed[4] = {8700304ULL, (uint64_t)sampling, f64_as_usize((4.0 + ncx) * 100870.0), f64_as_usize((4.0 + ncy) * 100304.0)};
     Isaac64 rng;
     rng.from_seed(seed, 4);
     Ray ray = ray_with_dof(s.camera, ncx, ncy, rng);
@@ -1058,7 +1066,7 @@ ORC_API int orc_path_draws(uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint3
                            int count) {
     double ncx, ncy;
     normalized_coord(W, H, x, y, sx, sy, ncx, ncy);
-    uint64_t seed[4] = {8700304ULL, (uint64_t)sampling, (uint64_t)((4.0 + ncx) * 100870.0), (uint64_t)((4.0 + ncy) * 100304.0)};
+    uint64_t seed[4] = {8700304ULL, (uint64_t)sampling, f64_as_usize((4.0 + ncx) * 100870.0), f64_as_usize((4.0 + ncy) * 100304.0)};
     Isaac64 rng;
     rng.from_seed(seed, 4);
     for (int i = 0; i < count; i++) out[i] = rng.next_u64();

@@ -67,7 +67,8 @@ def _check_scene(name, acc, ref, what=""):
 def test_isaac64_raw_outputs_bit_exact(gpu, scenes, orc):
     sc, _ = scenes("cornell_mini")
     gpu.upload_scene(sc)
-    for (w, h, sampling) in [(480, 270, 1), (33, 17, 7), (1920, 1080, 1024)]:
+    # the strips: 4 + nc < 0 on their far side, where the reference's `as usize` saturates to a zero seed word (test_isaac64.py)
+    for (w, h, sampling) in [(480, 270, 1), (33, 17, 7), (1920, 1080, 1024), (64, 1, 9), (1, 64, 3), (257, 3, 4000000000)]:
         gpu.set_resolution(w, h)
         n = min(w * h * 4, 256)
         first = (w * h * 4 - n) if sampling == 7 else 0
@@ -1303,6 +1304,37 @@ def test_seed_kernels_agree_on_odd_shapes(gpu, scenes):
                 assert np.array_equal(outs[0], o), (w, h, begin, end, stride, np.abs(outs[0] - o).max())
     finally:
         gpu.set_debug_option("seed_mode", 2)
+
+
+def test_ragged_sizes_and_large_sampling_indices_path_by_path(gpu, scenes):
+    """Edge cases of the loop bounds against the ORACLE (the test above compares kernels with each other): images smaller than a tile,
+    widths and heights that are not multiples of the 4x4 tile, single rows and columns, and sampling indices up to the end of the u32
+    range (the index is a seed word, renderer.rs:165-168) — every path of every case takes the oracle's branches or is one of a handful
+    of classified divergences, and the same-branch radiances agree as they do at 1920x1080.
+    The strips (64x1, 1x64, 257x3) found a real difference when this test was written: normalized_coord is divided by min(w, h)
+    (renderer.rs:53-54), so 4 + nc is negative on the far side of an image more than four times as wide as high, and the seed word
+    `((4.0 + nc) * k) as usize` saturates to 0 in Rust — the oracle's C cast wrapped and the GPU's clamped, so 4 - 36 % of a strip's
+    paths drew other random numbers.  Both now spell the Rust rule out (tests/test_isaac64.py::test_seed_words_saturate_on_strips)."""
+    import path_parity
+    sc, o = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    total = bad = 0
+    worst = 0.0
+    for (w, h), sampling in [((1, 1), 1), ((3, 2), 7), ((5, 17), 4294967295), ((2, 5), 65536), ((7, 19), 4000000000), ((33, 17), 123456789), ((130, 67), 2147483648),
+                             ((97, 41), 4294967294), ((64, 1), 65536), ((1, 64), 4000000000), ((257, 3), 123456789)]:
+        gpu.set_resolution(w, h)
+        g = gpu.debug_path_log(sampling)
+        a = path_parity.account(g, o.path_log(w, h, sampling))
+        assert g[0].shape == (h, w, 4, 3) and np.isfinite(g[0]).all() and a["paths"] == w * h * 4 and a["same_branch"]["rays_equal"]
+        if sampling < 4294967295:     # hr_render takes [begin, end): the last u32 index is reachable by the path log only
+            gpu.clear()
+            gpu.render(sampling, sampling + 1)
+            rad = g[0]
+            assert np.array_equal(gpu.read_accumulator(), ((rad[:, :, 0] + rad[:, :, 1]) + (rad[:, :, 2] + rad[:, :, 3])).astype(np.float32))
+        total += a["paths"]; bad += a["divergent"]
+        worst = max(worst, a["same_branch"]["max_rel_floor1"])
+    print("ragged sizes: %d paths, %d divergent, worst same-branch error %.3g" % (total, bad, worst))
+    assert bad <= 4 and worst <= 2e-3, (total, bad, worst)
 
 
 def test_cli_multi_device_in_one_process(tmp_path):

@@ -44,6 +44,29 @@ def test_path_seed_probe_vector(orc):
     assert f == [0.2285200597432051, 0.5250368802542618, 0.6681100348683542, 0.41564599708796934]
 
 
+def test_seed_words_saturate_on_strips(orc, emu):
+    """renderer.rs:165-166: `((4.0 + nc) * k) as usize`.  nc is divided by min(w, h) (renderer.rs:53-54), so on an image more than four
+    times as wide as high (or as high as wide) 4 + nc goes negative on the far side — and Rust's float-to-integer `as` saturates: the
+    seed word is 0 there (a C cast would be undefined: it wraps on x86 and clamps on the GPU).  Oracle and kernel code both follow the
+    Rust rule, explicitly."""
+    # 64x1: frag.x = 0 .. 63, nc.x = (x - 0.5) * 2 - 64 (sub-sample 0) -> negative 4 + nc.x for x <= 30
+    for x, s_word in [(0, 0), (30, 0), (31, int((4.0 + ((31 - 0.5) * 2 - 64)) * 100870.0)), (63, int((4.0 + ((63 - 0.5) * 2 - 64)) * 100870.0))]:
+        ncy = ((1 - 0.5) * 2 - 1) / 1.0
+        t_word = int((4.0 + ncy) * 100304.0)
+        ref = orc.isaac64([8700304, 9, s_word, t_word], 64)
+        assert np.array_equal(orc.path_draws(64, 1, x, 0, 0, 0, 9, 64), ref), x
+        assert np.array_equal(emu.raw_draws(64, 1, x, 0, 0, 9, 64), ref), x
+    # 1x64: frag.y = 64 - y; the bottom rows have 4 + nc.y < 0
+    for y, neg in [(0, False), (33, False), (34, True), (63, True)]:
+        ncy = ((64 - y - 0.5) * 2 - 64) / 1.0
+        t_word = 0 if neg else int((4.0 + ncy) * 100304.0)
+        assert (4.0 + ncy < 0) == neg
+        s_word = int((4.0 + ((0 - 0.5) * 2 - 1) / 1.0) * 100870.0)
+        ref = orc.isaac64([8700304, 3, s_word, t_word], 64)
+        assert np.array_equal(orc.path_draws(1, 64, 0, y, 0, 0, 3, 64), ref), y
+        assert np.array_equal(emu.raw_draws(1, 64, 0, y, 0, 3, 64), ref), y
+
+
 def test_u64_to_f64_range(orc):
     assert orc.u64_to_f64(0) == 0.0
     assert orc.u64_to_f64(2**64 - 1) == 1.0 - 2.0**-52
