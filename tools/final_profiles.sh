@@ -5,6 +5,10 @@ OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl\|libdrm" | tail -5 > $OUT/pytest_gpu.log
+# the PMC passes first: every bench line below reads its `traffic` from profiles/${TAG}_pmc_traffic.json and checks the kernel sources' hash against it
+tools/prof_pmc.sh $OUT/pmc $TAG > $OUT/pmc.log 2>&1
+cp $OUT/pmc/summary.txt $OUT/${TAG}_pmc_summary.txt; cp $OUT/pmc/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
+cp $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_traffic.json profiles/
 # the bench line and the kernel-trace statistics of the SAME run
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o ${TAG} -- python bench.py > $OUT/${TAG}_bench_full.json.log 2> $OUT/bench_full.err
 DB=$(find $OUT/prof -name "*_results.db" | head -1)
@@ -27,6 +31,4 @@ python bench.py --russian-roulette 3 --steps 16 --no-cpu-baseline > $OUT/${TAG}_
 python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian or per_path or post_chain" 2>&1 | grep -E "^\.?parity|simple \+|device builder|builder [0-9]|4 M tri|4K post|per-path|russian roulette|passed|failed" > $OUT/${TAG}_parity_lines.txt
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
-tools/prof_pmc.sh $OUT/pmc $TAG > $OUT/pmc.log 2>&1
-cp $OUT/pmc/summary.txt $OUT/${TAG}_pmc_summary.txt; cp $OUT/pmc/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
 tail -3 $OUT/pytest_gpu.log; cat $OUT/${TAG}_bench_full_unprofiled.json.log | head -c 400; echo; cat $OUT/${TAG}_bench_kernel_stats.md | head -12
