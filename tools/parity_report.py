@@ -72,20 +72,21 @@ def main():
         print(json.dumps(a))
     # the same accounting at BASELINE's image size: every path of two samplings of configs 3, 5 (at 1080p) and 2 — 8.3 M paths per case,
     # so that a ppm figure rests on thousands of paths instead of a handful
-    out["per_path_full_size"] = {"what": "as per_path, 1920x1080 (8,294,400 paths per sampling), samplings 1 and 1000", "cases": []}
-    for name in ("rtcamp6_v3_1", "rtcamp6_dodeca", "spheres"):
+    out["per_path_full_size"] = {"what": "as per_path, every path of whole samplings at 1920x1080 (8,294,400 paths; samplings 1 and 1000) and at 7680x4320 (132,710,400 paths; sampling 2)", "cases": []}
+    for name, W, H, samplings in (("rtcamp6_v3_1", 1920, 1080, (1, 1000)), ("rtcamp6_dodeca", 1920, 1080, (1, 1000)), ("spheres", 1920, 1080, (1, 1000)),
+                                 ("rtcamp6_v3_1", 7680, 4320, (2,))):       # 8K: 132.7 M paths of one sampling (the oracle takes ~2.5 minutes)
         sc = ha.Scene(name)
         o = orc.OracleScene(sc.desc_ptr)
         r.upload_scene(sc)
-        r.set_resolution(1920, 1080)
-        for sampling in (1, 1000):
+        r.set_resolution(W, H)
+        for sampling in samplings:
             t0 = time.time()
             g = r.debug_path_log(sampling)
             t1 = time.time()
-            ref = o.path_log(1920, 1080, sampling)
+            ref = o.path_log(W, H, sampling)
             t2 = time.time()
             a = path_parity.account(g, ref)
-            a.update({"scene": name, "width": 1920, "height": 1080, "sampling": sampling, "gpu_seconds_incl_readback": round(t1 - t0, 3), "oracle_seconds_all_cores": round(t2 - t1, 2)})
+            a.update({"scene": name, "width": W, "height": H, "sampling": sampling, "gpu_seconds_incl_readback": round(t1 - t0, 3), "oracle_seconds_all_cores": round(t2 - t1, 2)})
             out["per_path_full_size"]["cases"].append(a)
             print(json.dumps(a))
             del g, ref
