@@ -117,6 +117,17 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     out.materials.assign(sd->num_elements, Material{});
     out.emitters.clear();
     auto f3 = [](float *dst, const hr_vec3 &v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; };
+    // Non-finite geometry: the reference would panic in its BVH build (`partial_cmp().unwrap()` on a NaN, bvh.rs:107-211); across a C ABI
+    // that is an error return, before a NaN can reach a comparator of the builders here.
+    auto fin3 = [](const hr_vec3 &v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
+    for (uint32_t ei = 0; ei < sd->num_elements; ei++) {
+        const hr_element &e = sd->elements[ei];
+        if (e.kind == HR_SPHERE && !(fin3(e.center) && std::isfinite(e.radius))) return ferr(err, HR_ERR_INVALID, "element %u: sphere centre / radius is not finite", ei);
+        if (e.kind == HR_CUBOID && !(fin3(e.aabb_min) && fin3(e.aabb_max))) return ferr(err, HR_ERR_INVALID, "element %u: cuboid bounds are not finite", ei);
+        if (e.kind == HR_MESH && e.vertexes)
+            for (uint64_t v = 0; v < e.num_vertexes; v++)
+                if (!fin3(e.vertexes[v])) return ferr(err, HR_ERR_INVALID, "element %u: vertex %llu is not finite", ei, (unsigned long long)v);
+    }
     double split_min_sa = 0.0;   // early split clipping leaves references alone whose box is below 1e-4 of the scene's
     if (ratio > 0.0 && host_bvh) {
         double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
@@ -302,6 +313,9 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
         }
     }
     const hr_camera &cam = sd->camera;
+    if (!(fin3(cam.eye) && fin3(cam.right) && fin3(cam.up) && fin3(cam.forward) && fin3(cam.plane_half_right) && fin3(cam.plane_half_up) &&
+          std::isfinite(cam.lens_radius) && std::isfinite(cam.focus_distance)))
+        return ferr(err, HR_ERR_INVALID, "camera is not finite");
     memset(&out.cam, 0, sizeof out.cam);
     f3(out.cam.eye, cam.eye); f3(out.cam.right, cam.right); f3(out.cam.up, cam.up); f3(out.cam.forward, cam.forward);
     f3(out.cam.phr, cam.plane_half_right); f3(out.cam.phu, cam.plane_half_up);

@@ -580,13 +580,13 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
-    free_scene(c);
 
     HostScene hs;
     std::string ferr;
     const bool gpu_build = c->bvh_builder != 0;
     rc = flatten_scene(sd, hs, ferr, c->max_leaf, gpu_build ? 0.0 : c->split_ratio, !gpu_build);
-    if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());
+    if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());   // a description that is refused leaves the scene in place
+    free_scene(c);
     Scene &d = c->dsc;
     d = hs.view();
     int r;

@@ -8,6 +8,7 @@ required for anything that renders — there is no CPU fallback (`Renderer` rais
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -118,6 +119,15 @@ def hip_lib():
     if _hip is None:
         if not os.path.exists(HIP_LIB):
             raise RuntimeError("libhanamaru_hip.so not built — run __graft_entry__.build() / make -C hanamaru-renderer_amd")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.  Loaded after this library's (the system's, through DT_NEEDED)
+        # it becomes a second runtime that finds no GPU ("No HIP GPUs are available"); loaded first, its SONAME satisfies this
+        # library's dependency and both share it.  A process that will use torch next to this wrapper (bench.py binds torch tensors and
+        # torch.distributed; some tests do) must therefore have torch loaded before the first CDLL below — do it here, once.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(HIP_LIB)
         L.hr_last_error.restype = C.c_char_p
         L.hr_abi_version.restype = C.c_int

@@ -137,7 +137,9 @@ int hr_abi_version(void);
 int hr_create(int device_id, hr_ctx **out);
 int hr_destroy(hr_ctx *ctx);
 
-/* Scene: copies + converts to fp32 SoA, builds the device BVH, uploads. */
+/* Scene: copies + converts to fp32 SoA, builds the device BVH, uploads.  HR_ERR_INVALID for a description the reference could not render
+ * either (no elements, a mesh without data, an image index out of range, non-finite geometry or camera — the reference panics in its BVH
+ * build on a NaN): the scene uploaded before stays in place. */
 int hr_upload_scene(hr_ctx *ctx, const hr_scene_desc *scene);
 
 /* Output target (ImageBuffer dims, renderer.rs:26-28).  Allocates + zeroes the fp32 RGB accumulator. */

@@ -473,3 +473,31 @@ def test_random_scenes_path_by_path(ha, orc, emu, seed):
     ref, _ = o.render(w, h, 1, 3)
     rel = np.abs(acc - ref) / np.maximum(1.0, np.abs(ref))
     assert np.isfinite(acc).all() and (rel <= 1e-2).mean() >= 0.997, (rel <= 1e-2).mean()
+
+
+def test_non_finite_scene_input_is_rejected(ha, emu):
+    """flatten_scene (shared by the HIP library and this emulation): a NaN or an infinity in the geometry or the camera is HR_ERR_INVALID
+    at upload — the reference would panic in its BVH build (partial_cmp().unwrap(), bvh.rs) — instead of reaching a builder's comparator."""
+    import random_scenes
+    import ctypes as C
+    ok = random_scenes.build(ha, 5, spheres=3, cuboids=2, meshes=1)
+    emu.EmuScene(ok.desc_ptr)                          # the untouched scene builds
+
+    def rejected(mutate):
+        sc = random_scenes.build(ha, 5, spheres=3, cuboids=2, meshes=1)
+        d = C.cast(sc.desc_ptr, C.POINTER(ha.SceneDesc)).contents
+        mutate(d)
+        with pytest.raises(RuntimeError):
+            emu.EmuScene(sc.desc_ptr)
+
+    def first(d, kind):
+        return next(d.elements[i] for i in range(d.num_elements) if d.elements[i].kind == kind)
+
+    def nan_vertex(d):
+        first(d, ha.MESH).vertexes[2].y = float("nan")
+    rejected(lambda d: setattr(first(d, ha.SPHERE), "radius", float("inf")))
+    rejected(lambda d: setattr(first(d, ha.SPHERE).center, "x", float("nan")))
+    rejected(lambda d: setattr(first(d, ha.CUBOID).aabb_max, "z", float("-inf")))
+    rejected(nan_vertex)
+    rejected(lambda d: setattr(d.camera.eye, "y", float("nan")))
+    rejected(lambda d: setattr(d.camera, "focus_distance", float("inf")))

@@ -540,6 +540,18 @@ def test_error_paths(ha):
         r.render_debug(7)
     with pytest.raises(ha.HipError):
         r.debug_draws(1, 0, 4, 65)       # window larger than the stored tail
+    # non-finite geometry is refused at upload (tests/test_emu_parity.py has the whole list); the scene uploaded before stays usable
+    import ctypes as C
+    import random_scenes
+    bad = random_scenes.build(ha, 5, spheres=3, cuboids=2, meshes=1)
+    d = C.cast(bad.desc_ptr, C.POINTER(ha.SceneDesc)).contents
+    next(d.elements[i] for i in range(d.num_elements) if d.elements[i].kind == ha.SPHERE).center.x = float("nan")
+    with pytest.raises(ha.HipError) as e:
+        r.upload_scene(bad)
+    assert e.value.code == -1 and "not finite" in str(e.value)
+    r.clear()
+    r.render(1, 2)
+    assert np.isfinite(r.read_accumulator()).all() and r.read_accumulator().any()
     r.close()
 
 
