@@ -999,6 +999,44 @@ def test_config5_4k_crops(gpu, scenes):
     assert np.abs(capped.astype(np.float64) - whole).max() <= 1e-4 * max(1.0, float(np.abs(whole).max()))
 
 
+def test_config5_full_length_through_the_cli(tmp_path, scenes, orc):
+    """BASELINE config 5 end to end at its FULL length on one GPU: `hanamaru-hip --scene rtcamp6_dodeca -w 3840 -h 2160 -s 1024` —
+    3.4e10 paths (half a minute), the reference's log lines, and the 4K PNG that comes out of accumulate -> Reinhard -> gamma ->
+    bilateral -> u8 compared with the oracle's post chain of its own 1,024-sampling accumulator on crops at full-image coordinates
+    (the dodecahedron, the bunny's ear, the frame against the sky, floor + armadillo, open sky)."""
+    import re
+    from PIL import Image
+    W, H, S = 3840, 2160, 1024
+    out = _run_cli(tmp_path, ["--scene", "rtcamp6_dodeca", "-w", W, "-h", H, "-s", S, "-t", "100000", "-i", "100000"], timeout=900)
+    assert "reached max sampling" in out and ("sampled: %dx4 spp." % S) in out and "output final image: 000.png" in out
+    m = re.search(r"gpu: ([0-9.]+) Mpaths/s wall", out)
+    img = np.asarray(Image.open(tmp_path / "result.png"))
+    assert img.shape == (H, W, 3)
+    print("config 5 full length through the CLI: %s Mpaths/s wall, image mean %.3f" % (m.group(1) if m else "?", img.mean()))
+    assert m and float(m.group(1)) > 600.0         # a sanity floor far below the bench's rate (scene set-up and PNG excluded by the CLI's own clock)
+    _, o = scenes("rtcamp6_dodeca")
+    _crops_match_oracle(img, o, orc, W, H, S, [(1970, 170), (1870, 540), (3060, 660), (1640, 1580), (400, 340)])
+
+
+def test_config4_full_length_through_the_cli(tmp_path, scenes, orc):
+    """BASELINE config 4 at its FULL length (1920x1080 x 4,096 samplings = 3.4e10 paths) through the CLI with the samplings sharded over
+    two contexts (`--gpu-ids 0,0`: all this box has is one device, so both shards run on it and hr_allreduce_accumulators sums them with
+    its same-device kernel instead of RCCL — the sharding, the strides and the sum are those of the 8-GPU run): the PNG against the
+    oracle's post chain of its own 4,096-sampling accumulator on crops."""
+    import re
+    from PIL import Image
+    W, H, S = 1920, 1080, 4096
+    out = _run_cli(tmp_path, ["-w", W, "-h", H, "-s", S, "-t", "100000", "-i", "100000", "--gpu-ids", "0,0"], timeout=900)
+    assert "reached max sampling" in out and ("sampled: %dx4 spp." % S) in out
+    m = re.search(r"gpu: ([0-9.]+) Mpaths/s wall", out)
+    img = np.asarray(Image.open(tmp_path / "result.png"))
+    assert img.shape == (H, W, 3)
+    print("config 4 full length through the CLI, two shards on one device: %s Mpaths/s wall, image mean %.3f" % (m.group(1) if m else "?", img.mean()))
+    assert m and float(m.group(1)) > 600.0
+    _, o = scenes("rtcamp6_v3_1")
+    _crops_match_oracle(img, o, orc, W, H, S, [(940, 330), (1250, 420), (700, 760), (100, 100)])
+
+
 def test_config5_4k_post_chain(gpu, scenes, orc):
     """BASELINE config 5's post chain at its full size: hr_resolve (tonemap_gamma_kernel + bilateral_quantise_kernel, renderer.rs:64-90) at
     3840x2160 against orc.resolve on the SAME accumulator — the rendered one, then a synthetic high-dynamic-range one (values from 0 to
