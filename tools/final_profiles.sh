@@ -28,7 +28,7 @@ python bench.py --gpus 8 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}
 python bench.py --gpus 8 --total-samplings 64 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_c4_strong_64_of_4096_one_device.json.log 2>> $OUT/bench_full.err
 python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --gpus 8 --total-samplings 32 --steps 2 --warmup 1 --max-tail-gib 5 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_c5_strong_32_of_1024_one_device.json.log 2>> $OUT/bench_full.err
 python bench.py --russian-roulette 3 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_russian_roulette_nonparity.json.log 2>> $OUT/bench_full.err
-python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian or per_path or post_chain" 2>&1 | grep -E "^\.?parity|simple \+|device builder|builder [0-9]|4 M tri|4K post|per-path|russian roulette|passed|failed" > $OUT/${TAG}_parity_lines.txt
+python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian or per_path or post_chain or full_length or ragged" 2>&1 | grep -E "^\.?parity|simple \+|device builder|builder [0-9]|4 M tri|4K post|per-path|russian roulette|config [45] full|ragged sizes|passed|failed" > $OUT/${TAG}_parity_lines.txt
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
 tail -3 $OUT/pytest_gpu.log; cat $OUT/${TAG}_bench_full_unprofiled.json.log | head -c 400; echo; cat $OUT/${TAG}_bench_kernel_stats.md | head -12
