@@ -555,6 +555,33 @@ def test_error_paths(ha):
     r.close()
 
 
+def test_no_device_memory_growth_over_context_cycles(ha):
+    """create -> upload (host and device builders in turn) -> render -> replace the scene in place -> render -> destroy, twenty times: the
+    device's free memory after every cycle is what it was after the first (the HIP runtime keeps its own pools; nothing of ours grows)."""
+    import torch
+    a, b = ha.Scene("rtcamp6_v3_1"), ha.Scene("cornell_mini")
+
+    def free():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    marks = []
+    for i in range(20):
+        r = ha.Renderer(0)
+        r.set_option("bvh_builder", i % 3)
+        r.upload_scene(a if i % 2 else b)
+        r.set_resolution(640 + i, 360)
+        r.render(1, 9)
+        r.resolve(8)
+        r.upload_scene(b if i % 2 else a)
+        r.set_resolution(320, 200 + i)
+        r.render(1, 3)
+        r.read_accumulator()
+        r.close()
+        marks.append(free())
+    assert max(marks[1:]) - min(marks[1:]) <= 64 << 20, [m >> 20 for m in marks]
+
+
 def test_bound_accumulator_is_exclusive(scenes, ha):
     """hr_bind_accumulator: a caller-owned accumulator belongs to ONE context (the launch's radiance is added with plain loads and stores);
     a second context that tries to bind the same buffer is refused, and the buffer is free again once the first lets go of it."""
