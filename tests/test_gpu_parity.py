@@ -582,6 +582,38 @@ def test_no_device_memory_growth_over_context_cycles(ha):
     assert max(marks[1:]) - min(marks[1:]) <= 64 << 20, [m >> 20 for m in marks]
 
 
+def test_two_contexts_driven_from_two_host_threads(ha):
+    """A context is not thread-safe, but two contexts may be driven by two host threads at once (the one-process multi-GPU host does
+    exactly that when it wants to): the accumulators are bit for bit what each context renders alone, and each thread reads its own
+    hr_last_error."""
+    import threading
+    sa, sb = ha.Scene("rtcamp6_v3_1"), ha.Scene("cornell_mini")
+
+    def work(scene, w, h, n, out, key):
+        r = ha.Renderer(0)
+        try:
+            r.upload_scene(scene)
+            r.set_resolution(w, h)
+            for i in range(n):
+                r.render(1 + 4 * i, 5 + 4 * i)
+            out[key] = r.read_accumulator()
+            try:
+                r.set_option("nonsense-" + key, 1)
+            except ha.HipError as e:
+                out[key + "-err"] = str(e)
+        finally:
+            r.close()
+
+    alone, both = {}, {}
+    work(sa, 320, 180, 6, alone, "a")
+    work(sb, 200, 120, 9, alone, "b")
+    ta = threading.Thread(target=work, args=(sa, 320, 180, 6, both, "a"))
+    tb = threading.Thread(target=work, args=(sb, 200, 120, 9, both, "b"))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert np.array_equal(alone["a"], both["a"]) and np.array_equal(alone["b"], both["b"]) and alone["a"].any() and alone["b"].any()
+    assert "nonsense-a" in both["a-err"] and "nonsense-b" in both["b-err"]
+
+
 def test_bound_accumulator_is_exclusive(scenes, ha):
     """hr_bind_accumulator: a caller-owned accumulator belongs to ONE context (the launch's radiance is added with plain loads and stores);
     a second context that tries to bind the same buffer is refused, and the buffer is free again once the first lets go of it."""
