@@ -16,8 +16,9 @@
  * entry points from `Renderer::render`.  See INTEGRATION.md for the Rust `extern "C"` block.
  *
  * Conventions: every function returns 0 (HR_OK) or a negative hr_status; hr_last_error() gives text.
- * No exceptions cross the boundary.  A context is bound to ONE GPU and is not thread-safe; multi-GPU
- * is one context (one process) per GPU, sharded by sampling index (hr_render's `stride`).
+ * No exceptions cross the boundary.  A context is bound to ONE GPU and is not thread-safe; different contexts may be driven by
+ * different host threads at the same time (hr_last_error is per thread).  Multi-GPU is one context per GPU — one process each, or one
+ * process driving them all —, sharded by sampling index (hr_render's `stride`).
  * Host buffers passed in are copied — the caller keeps ownership.  No torch / STL types in signatures.
  */
 #ifndef HANAMARU_HIP_H
