@@ -34,7 +34,10 @@ Extra objects on the JSON line:
                  `loaded_bytes` (what the lanes really request with this build's 16-byte node records), the traversal section's
                  share, the traversal-only workload (hr_render_debug, Depth mode), `traffic` (PMC) and `physical`.
   multi_gpu    — per rank: wall time until its samplings were done, the all-reduce as it saw it, its kernels' summed durations;
-                 the accumulator's size; max / min over ranks.
+                 the accumulator's size; max / min over ranks.  `rccl`: what the communicators report about themselves after the timed
+                 region (ranks, devices, RCCL version, which code path: rccl-rank | rccl-group | same-device-fallback); `checksum`: the
+                 f64 sums of the ranks' own accumulators against the all-reduced total.  A run whose exchange is not verified by both
+                 exits with code 3.
   cpu_baseline — the CPU oracle (f64 restatement of the reference path, oracle/) timed on this box's host cores
                  on a bounded sample; reported, not optimised.
 """
@@ -137,6 +140,7 @@ def main():
     import hanamaru_amd as ha
     from hanamaru_amd.sharding import step_range, strong_plan, strong_step_range
 
+    exit_code = 0
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     launcher = env_world > 1
     rank = int(os.environ.get("RANK", "0")) if launcher else 0
@@ -309,6 +313,24 @@ def main():
     acc_mean = float(acc.mean().item()) if one_device else float(r0.read_accumulator().mean())   # after the all-reduce: the total
     if os.environ.get("HR_BENCH_CHECKSUM") == "1" and rank == 0:
         sys.stderr.write("accumulator mean after all-reduce: %.9g\n" % acc_mean)
+    # ---- outside the timed region: the evidence that the exchange happened.  Every context reports what its communicator says about
+    # itself (hr_comm_info: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion, asked of RCCL now) and the f64 sum of
+    # its OWN accumulator (untouched by the all-reduce, which writes the total to a buffer of its own) and of the total it received.
+    # The parts must add up to the total: multi_gpu.checksum; a mismatch, or a communicator smaller than --gpus on a box that has the
+    # devices, makes the run fail (exit code 3) instead of printing a rate for an exchange that did not take place.
+    exchange = []
+    for r, (g, d) in zip(rs, mine):
+        ci = r.comm_info()
+        own = None if one_device else r.accumulator_sum(False)
+        tot = None
+        if not one_device:
+            tot = r.accumulator_sum(True) if (lib_rccl or len(rs) > 1) else own
+        exchange.append({"rank": g, "device": d, "comm": ci, "own_sum": own, "total_sum": tot})
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, exchange)
+        exchange = [x for part in gathered for x in part]
+    exchange.sort(key=lambda x: x["rank"])
 
     # ---- outside the timed region, rank 0: the post chain (renderer.rs:64-90 as two HIP kernels) on the all-reduced accumulator
     post = None
@@ -376,9 +398,44 @@ def main():
                           "allreduce_ms": {"max": max(ar_ms), "min": min(ar_ms)},
                           "allreduce_share_of_timed_region": round(min(ar_ms) * 1e-3 / elapsed, 5),
                           "per_rank": sorted(per_rank, key=lambda x: x["rank"]),
+                          "rccl": None, "checksum": None,
                           "note": ("one process drives all contexts: render_ms of rank k is observed after ranks 0..k-1 were awaited (a lower bound for the "
                                    "later ranks' own time is their kernels' summed durations)" if (not launcher and world > 1) else "one process per rank")},
         }
+        # what the communicators said about themselves, and the checksum of the exchange
+        comms = [x["comm"] for x in exchange]
+        paths_seen = sorted(set(c["path"] for c in comms))
+        rccl = {"path": paths_seen[0] if len(paths_seen) == 1 else paths_seen,
+                "nranks": max(1, min(c["nranks"] for c in comms)) if world > 1 else 1,
+                "ranks_seen": sorted(c["rank"] for c in comms) if world > 1 else [0],
+                "devices_seen": sorted(set(c["device"] for c in comms)),
+                "version": max(c["rccl_version"] for c in comms),
+                "allreduces_per_rank": sorted(set(c["allreduces"] for c in comms)),
+                "source": "hr_comm_info() of every context after the timed region: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion as the communicator answers them"
+                          if world > 1 and not one_device else ("single rank: no communicator, no collective" if world == 1 else "HR_BENCH_ONE_DEVICE debugging aid: torch.distributed gloo on a host copy, no RCCL")}
+        out["multi_gpu"]["rccl"] = rccl
+        failures = []
+        if not one_device:
+            parts = [sum(x["own_sum"][k] for x in exchange) for k in range(3)]
+            totals = [x["total_sum"] for x in exchange]
+            total = totals[0]
+            rel = max(abs(parts[k] - total[k]) / max(abs(total[k]), 1e-30) for k in range(3))
+            same = all(t == total for t in totals)
+            out["multi_gpu"]["checksum"] = {"sum_of_parts": [float("%.12g" % v) for v in parts], "total": [float("%.12g" % v) for v in total], "rel_err": float("%.3g" % rel),
+                                            "totals_identical_on_all_ranks": same,
+                                            "definition": "per-channel f64 device sums (hr_accumulator_sum): every rank's OWN accumulator, added over the ranks, against the all-reduced total "
+                                                          "rank 0 holds; rel_err = max over channels of |parts - total| / |total| (fp32 all-reduce rounding: ~1e-8); a run with rel_err > 1e-6 exits with code 3"}
+            if rel > 1e-6 or not (total[0] > 0.0):
+                failures.append("checksum: the ranks' accumulators do not add up to the all-reduced total (rel_err %.3g)" % rel)
+            if not same:
+                failures.append("checksum: the ranks hold different totals")
+        if world > 1 and not one_device:
+            if rccl["nranks"] != world or rccl["ranks_seen"] != list(range(world)):
+                failures.append("communicator reports %s ranks %s, --gpus %d" % (rccl["nranks"], rccl["ranks_seen"], world))
+            have_devices = launcher or ndev >= world
+            if have_devices and (paths_seen not in (["rccl-rank"], ["rccl-group"]) or len(rccl["devices_seen"]) != world):
+                failures.append("the box has the devices, but the exchange did not run over RCCL on %d distinct devices (path %s, devices %s)" % (world, paths_seen, rccl["devices_seen"]))
+        out["multi_gpu"]["exchange_verified"] = not failures
         launches = max(1, st["trace_launches"])
         avg_ms = st["trace_kernel_ms"] / launches
         # the library may cap the samplings per launch (hand-off buffer size): use what was actually launched
@@ -389,7 +446,9 @@ def main():
         # `bound`: what the PMC passes say limits the kernel (the CUs' L1 tag lookups / texture-addresser issue and lane divergence — the
         # tree is L2-resident, physical HBM traffic is ~6 % of peak); `bound_contract` / `peak`: BASELINE's metric prices the traversal
         # against the HBM peak, and that normalisation is what `achieved` / `frac` are (SURVEY.md 8(d)'s byte booking).
-        roof = {"bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel", "pair_bound": "seed_seg_kernel",
+        roof = {"schema": "r04+: achieved / frac = SURVEY 8(d) byte booking (until r03 these two fields were what is now loaded_bytes.achieved / .frac)",
+                "bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel",
+                "pair_bound": "seed_seg_kernel" if st["seed_kernel_ms"] / max(1, st["seed_launches"]) >= avg_ms else "trace_kernel",   # the slower kernel of the concurrent pair
                 "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "frac_survey_8d": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
@@ -476,6 +535,9 @@ def main():
                 roof["traffic_stale"] = stale   # true: the PMC passes were taken on other kernel sources than the ones running now
                 roof["traffic_write"] = int(tk.get("write_bytes_per_path", 0) * paths_per_launch)
             phys = {k: tk[k] for k in ("l2_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "l1_line_accesses_per_path", "l1_to_l2_requests_per_path") if k in tk}
+            roof["replayed_from_profiles"] = {"fields": ["traffic", "traffic_write", "physical", "issue"], "file": pmc["source"],
+                                              "note": "PMC figures are NOT measured in this run: separate rocprofv3 --pmc passes of this same command (tools/prof_pmc.sh), read back from the "
+                                                      "newest profiles/rNN_pmc_traffic.json; traffic_stale says whether the kernel sources have changed since"}
             if phys:
                 phys["note"] = "what bounds the kernel physically (PMC, kernel alone on the chip): the L1's tag lookups — one cache line per clock per CU — and SIMD lane divergence, not bytes"
                 roof["physical"] = phys
@@ -527,11 +589,16 @@ def main():
                                              "BVHs; one thread: 240x135 x 1 sampling" %
                                              (args.scene, cw, ch, mult, cw * ch * 4 * mult, cores, hw_threads, ("%.0f CPUs" % quota) if quota else "none")}
         print(json.dumps(out), flush=True)
+        if failures:
+            sys.stderr.write("bench.py: the multi-GPU exchange is not verified:\n  " + "\n  ".join(failures) + "\n")
+            exit_code = 3
     for r in rs:
         r.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -244,6 +244,7 @@ struct RenderParams {
     uint32_t ovf_cap;                 // seed kernels: entries of each consumer wave's fix-up list (sized per launch by hr_api.hip)
     uint32_t rr_start;                // trace kernel: Russian roulette from this iteration on (0 = off, the default: the reference has none)
     uint32_t gov_slot;                // parity of the launch: which slot of gov-> its two kernels stamp
+    uint32_t nee_cull_off;            // trace kernel: 1 = trace every NEE shadow ray, also those nee_setup knows to add nothing (debug option nee_cull 0: the A/B and the bit-equality test)
     GovDev *gov;                      // nullptr: no governor (debug kernels, host emulation) — trace_boost / pad[1] as given
 };
 
@@ -279,7 +280,7 @@ static const int SEG_B1 = 11, SEG_B2 = 21, SEG_NBLK = 11;
 HD uint32_t rec_slot(uint32_t lane_base, uint32_t slot) { return lane_base + (slot >> 2) * 256u + (slot & 3u); }
 
 struct Counters {
-    unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, pad;
+    unsigned long long paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, rng_overflow, shadow_culled;   // shadow_culled: NEE shadow rays known to add nothing before they are traced (pt_core.h nee_setup)
     // wave-level phase statistics of the trace kernel (counters build): invocations and lanes served
     unsigned long long shade_calls, shade_lanes, box_passes, box_lanes, leaf_calls, leaf_lanes, outer_iters, pad2;
     // wave-cycles (s_memtime deltas, summed over the waves) spent in: A shade, B refill, C box phase, C leaf phase

@@ -1,4 +1,4 @@
-// hr_api.hip — the device context and the C ABI of include/hanamaru_hip.h (gfx950).  One translation unit with its kernels:
+// hr_api.hip — the device context and the C ABI of include/hanamaru_hip.h (+ the test / measurement entry points of hanamaru_hip_debug.h) (gfx950).  One translation unit with its kernels:
 //   seed_kernels.h   seed_seg_kernel (default: the ISAAC-64 init sweep as three runs computed side by side from states the producer
 //                    waves work out ahead in registers, consumer waves run the LDS-bound round), seed_pc_kernel (the same roles with
 //                    a ring of generator words), seed_isaac64_kernel (fused form), seed_debug_kernel
@@ -23,6 +23,7 @@
 #include "flatten.h"
 #include "gpu_bvh.h"
 #include "hanamaru_hip.h"
+#include "hanamaru_hip_debug.h"
 #include "hr_comm.h"
 #include "isaac_core.h"
 #include "post_core.h"
@@ -74,6 +75,8 @@ struct hr_ctx {
     // multi-GPU: RCCL communicator of this rank, and the all-reduced accumulator (valid until the next render / clear / write)
     hrcomm::Comm comm = nullptr;
     int comm_world = 0, comm_rank = 0;
+    int comm_path = HR_COMM_NONE;              // how the group was formed (hr_comm_info)
+    uint64_t allreduces = 0;                   // collectives this context has enqueued since its communicator was made
     std::vector<hr_ctx *> same_device_peers;   // hr_comm_init_local over contexts that share ONE device: summed by a kernel, not by RCCL
     float *accum_total = nullptr;
     bool total_valid = false;
@@ -110,6 +113,7 @@ struct hr_ctx {
     int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
     int seed_prof = 0;                       // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
+    bool nee_cull = true;                    // debug option nee_cull: 0 = trace every NEE shadow ray (bit-identical image, more rays)
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
@@ -373,7 +377,7 @@ int hr_destroy(hr_ctx *c) {
     if (c->d_rgb8) (void)hipFree(c->d_rgb8);
     if (c->accum_total) (void)hipFree(c->accum_total);
     if (c->comm && hrcomm::api().CommDestroy) (void)hrcomm::api().CommDestroy(c->comm);
-    for (hr_ctx *p : c->same_device_peers) if (p != c) { p->same_device_peers.clear(); p->comm_world = 0; p->total_valid = false; }
+    for (hr_ctx *p : c->same_device_peers) if (p != c) { p->same_device_peers.clear(); p->comm_world = 0; p->total_valid = false; p->comm_path = HR_COMM_NONE; p->allreduces = 0; }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->seed_stream) (void)hipStreamDestroy(c->seed_stream);
     delete c;
@@ -814,6 +818,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
     rp.ovf_cap = c->ovf_cap;
     rp.rr_start = c->rr_start;
+    rp.nee_cull_off = c->nee_cull ? 0u : 1u;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
         rp.sampling_begin = s_begin + done * stride;
@@ -1010,9 +1015,10 @@ __global__ void add_accumulator_kernel(float *__restrict__ total, const float *_
 }
 static int comm_release(hr_ctx *c) {
     if (c->comm) { NCCL_TRY(hrcomm::api().CommDestroy(c->comm)); c->comm = nullptr; }
-    for (hr_ctx *p : c->same_device_peers) if (p != c) { p->same_device_peers.clear(); p->comm_world = 0; p->total_valid = false; }
+    for (hr_ctx *p : c->same_device_peers) if (p != c) { p->same_device_peers.clear(); p->comm_world = 0; p->total_valid = false; p->comm_path = HR_COMM_NONE; p->allreduces = 0; }
     c->same_device_peers.clear();
     c->comm_world = 0; c->comm_rank = 0; c->total_valid = false;
+    c->comm_path = HR_COMM_NONE; c->allreduces = 0;
     return HR_OK;
 }
 int hr_comm_init_rank(hr_ctx *c, const void *id, int world_size, int rank) {
@@ -1024,7 +1030,7 @@ int hr_comm_init_rank(hr_ctx *c, const void *id, int world_size, int rank) {
     hrcomm::UniqueId uid;
     memcpy(&uid, id, sizeof uid);
     NCCL_TRY(hrcomm::api().CommInitRank(&c->comm, world_size, uid, rank));
-    c->comm_world = world_size; c->comm_rank = rank;
+    c->comm_world = world_size; c->comm_rank = rank; c->comm_path = HR_COMM_RCCL_RANK;
     return HR_OK;
 }
 int hr_comm_init_local(hr_ctx **ctxs, int n) {
@@ -1036,7 +1042,7 @@ int hr_comm_init_local(hr_ctx **ctxs, int n) {
         for (int i = 1; i < n; i++) same = same && ctxs[i]->device == ctxs[0]->device;
         if (same) {
             for (int i = 0; i < n; i++) { int rc = comm_release(ctxs[i]); if (rc) return rc; }
-            for (int i = 0; i < n; i++) { ctxs[i]->same_device_peers.assign(ctxs, ctxs + n); ctxs[i]->comm_world = n; ctxs[i]->comm_rank = i; }
+            for (int i = 0; i < n; i++) { ctxs[i]->same_device_peers.assign(ctxs, ctxs + n); ctxs[i]->comm_world = n; ctxs[i]->comm_rank = i; ctxs[i]->comm_path = HR_COMM_SAME_DEVICE_SUM; }
             return HR_OK;
         }
     }
@@ -1050,7 +1056,7 @@ int hr_comm_init_local(hr_ctx **ctxs, int n) {
         for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return fail(HR_ERR_INVALID, "hr_comm_init_local: device %d appears twice (RCCL needs one rank per device)", devs[i]);
     }
     NCCL_TRY(hrcomm::api().CommInitAll(comms.data(), n, devs.data()));
-    for (int i = 0; i < n; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_world = n; ctxs[i]->comm_rank = i; }
+    for (int i = 0; i < n; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_world = n; ctxs[i]->comm_rank = i; ctxs[i]->comm_path = HR_COMM_RCCL_GROUP; }
     return HR_OK;
 }
 int hr_comm_destroy(hr_ctx *c) {
@@ -1084,9 +1090,11 @@ static int allreduce_enqueue(hr_ctx *c) {
         // peer's next hr_render / hr_clear / hr_write_accumulator cannot race with them
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->total_valid = true;
+        c->allreduces++;
         return HR_OK;
     }
     NCCL_TRY(hrcomm::api().AllReduce(c->accum, c->accum_total, n, hrcomm::kFloat, hrcomm::kSum, c->comm, c->stream));
+    c->allreduces++;
     return HR_OK;   // total_valid is set by the callers once the collective is known to be enqueued (group end)
 }
 int hr_allreduce_accumulator(hr_ctx *c) {
@@ -1114,6 +1122,57 @@ int hr_allreduce_accumulators(hr_ctx **ctxs, int n) {
 }
 void *hr_total_device_ptr(hr_ctx *c) { return c && c->total_valid ? c->accum_total : nullptr; }
 
+// What the communicator says about itself — asked of RCCL, not remembered from the init call: the evidence a bench line needs that
+// its all-reduce ran over N ranks (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion).
+int hr_comm_info(hr_ctx *c, hr_comm_info_t *out) {
+    if (!c || !out) return fail(HR_ERR_INVALID, "hr_comm_info: null argument");
+    memset(out, 0, sizeof *out);
+    out->path = c->comm_path; out->device = c->device; out->allreduces = c->allreduces;
+    if (c->comm) {
+        int v = 0;
+        NCCL_TRY(hrcomm::api().CommCount(c->comm, &v)); out->nranks = v;
+        NCCL_TRY(hrcomm::api().CommUserRank(c->comm, &v)); out->rank = v;
+        NCCL_TRY(hrcomm::api().CommCuDevice(c->comm, &v)); out->device = v;
+        NCCL_TRY(hrcomm::api().GetVersion(&v)); out->rccl_version = v;
+    } else if (!c->same_device_peers.empty()) {
+        out->nranks = (int32_t)c->same_device_peers.size(); out->rank = c->comm_rank;
+    }
+    return HR_OK;
+}
+
+// Sum of an accumulator in f64, per channel, on the device: sum_of(rank's own accumulators) == sum(all-reduced total) is the checksum of
+// the exchange (bench.py multi_gpu.checksum).  One pass, 1,024 workgroups, f64 atomics on three words.
+__global__ __launch_bounds__(256) void accumulator_sum_kernel(const float *__restrict__ a, size_t pixels, double *__restrict__ out) {
+    double s[3] = {0.0, 0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (size_t)gridDim.x * blockDim.x) {
+        s[0] += (double)a[i * 3]; s[1] += (double)a[i * 3 + 1]; s[2] += (double)a[i * 3 + 2];
+    }
+    for (int k = 0; k < 3; k++) {
+        double x = s[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(out + k, x);
+    }
+}
+int hr_accumulator_sum(hr_ctx *c, int which, double out_rgb[3]) {
+    if (!c || !out_rgb || which < 0 || which > 1) return fail(HR_ERR_INVALID, "hr_accumulator_sum: bad argument (which: 0 = this context's own accumulator, 1 = the all-reduced total)");
+    if (!c->accum || !c->W) return fail(HR_ERR_NO_TARGET, "hr_accumulator_sum: no accumulator");
+    if (which == 1 && !c->total_valid) return fail(HR_ERR_INVALID, "hr_accumulator_sum: no all-reduced total (hr_allreduce_accumulator first)");
+    int rc = hr_synchronize(c);
+    if (rc) return rc;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 3 * sizeof(double)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(double), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(accumulator_sum_kernel, dim3(1024), dim3(256), 0, c->stream, which ? c->accum_total : c->accum, (size_t)c->W * c->H, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, d, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_accumulator_sum: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
 int hr_get_stats(hr_ctx *c, hr_stats *out) {
     if (!c || !out) return fail(HR_ERR_INVALID, "hr_get_stats: null argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -1125,7 +1184,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     memset(out, 0, sizeof *out);
     out->paths = c->counters ? h.paths : c->paths_rendered;
     out->rays = h.rays; out->node_tests = h.node_tests; out->tri_tests = h.tri_tests;
-    out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow;
+    out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow; out->shadow_culled = h.shadow_culled;
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
     out->bvh_build_ms = c->bvh_build_ms;
@@ -1264,6 +1323,7 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
+    if (k == "nee_cull") { c->nee_cull = value != 0.0; return HR_OK; }
     return fail(HR_ERR_INVALID, "unknown debug option '%s'", key);
 }
 
@@ -1335,6 +1395,7 @@ int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
     rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
     rp.adv_den = c->adv_den; rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll; rp.kchunk = c->kchunk;
     rp.pad[0] = c->seed_prio;
+    rp.nee_cull_off = c->nee_cull ? 0u : 1u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, tiles))) return rc;
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u))) return rc;

@@ -23,6 +23,11 @@ struct Api {
     int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    // what the communicator says about itself (hr_comm_info: the evidence a bench line carries that the collective ran over N ranks)
+    int (*CommCount)(Comm, int *) = nullptr;
+    int (*CommUserRank)(Comm, int *) = nullptr;
+    int (*CommCuDevice)(Comm, int *) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
     std::string error;
 };
 
@@ -54,6 +59,10 @@ inline bool load() {
     a.GroupEnd = (int (*)())sym("ncclGroupEnd");
     a.CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
     a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    a.CommCount = (int (*)(Comm, int *))sym("ncclCommCount");
+    a.CommUserRank = (int (*)(Comm, int *))sym("ncclCommUserRank");
+    a.CommCuDevice = (int (*)(Comm, int *))sym("ncclCommCuDevice");
+    a.GetVersion = (int (*)(int *))sym("ncclGetVersion");
     if (!ok) { dlclose(a.lib); a.lib = nullptr; }
     return ok;
 }

@@ -102,7 +102,7 @@ struct TraceState {
 HD void trace_begin(TraceState &ts, float tmax, uint32_t start = 0u) { ts.cur = start; ts.t = tmax; ts.prim = -1; ts.type = 0; ts.u = ts.v = 0.0f; ts.leaf = 0; ts.leaf2 = 0; }
 HD bool trace_done(const TraceState &ts) { return ts.cur == NODE_END && ts.leaf == 0; }
 
-struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests; };
+struct LaneCounters { uint32_t rays, node_tests, tri_tests, sphere_tests, cuboid_tests, shadow_culled; };
 
 // bvh.rs:266-290 (two-sided, accepts t == best, rejects det == 0) on the derived record TriT (device_scene.h): the plane first, then the
 // barycentrics as two dot products with the hit position relative to v0.  Straight-line: the lanes of a wave test different triangles,
@@ -599,6 +599,7 @@ struct Path {
     float cur_refl;       // reflectance of the sampled bounce (PointMaterial::sample's scalar)
     V3f view, n; float param, roughness;
     float shadow_len;     // |sample point - shadow origin|
+    float own_r;          // radius of the sphere the shaded point lies on, 0 = not a sphere (nee_setup's third shortcut)
     float r0, r1;
 };
 static const uint32_t PATH_IDLE = 0xffffffffu;
@@ -648,24 +649,57 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
     trace_begin(p.ts, T_INF, p.ray.start);
 }
 
-// scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter path_emitter(p)
-HD void nee_setup(const Scene &sc, Path &p) {
+// scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter path_emitter(p).
+// Returns false when the ray need not be traced at all, because its contribution is known to be exactly zero (round 5; `cull` = 0
+// switches the three shortcuts off: debug option nee_cull 0, the A/B and the bit-equality test; bit 0 = (1) and (3), bit 1 = (2) — the
+// logging instantiation keeps (2) off, because the log records the visibility verdict of renderer.rs:280 also where the BSDF is zero):
+//   (1) the sample point lies on the FAR side of the emitter.  sample_on_surface draws uniformly over the whole sphere (scene.rs:92-101), so
+//       for more than half of the samples the shadow ray runs through the emitter itself before it reaches the sample: the closest hit of
+//       renderer.rs:279 is then the emitter's near side (or something nearer still), `approximately` (vector.rs:89-91) fails, nothing is
+//       added.  With sn the unit normal at the sample and d the ray direction, x = (r + OFFSET) (sn . d) is the distance from the sample
+//       back to the ray's point of closest approach to the centre; the ray is inside the sphere of radius r over at least the last x of
+//       its way whenever x^2 > 2 r OFFSET + OFFSET^2 (it enters the sphere at all).  The walk would stop at the first hit more than 0.0201 in
+//       front of the sample (shadow_early_out); x > 0.0201 + slack therefore decides the same thing without walking.  Slack: the fp32 ray
+//       misses the sample point by ~2e-7 of its length — 2e-3 + 1e-6 L on x and a factor 2 on the entry condition are far more than that.
+//       Marginal samples (a chord of about 0.02: within 1.3 degrees of the silhouette of an r = 1 emitter) are traced as before.
+//   (2) GGX, emitter below the shaded point's horizon: material.rs:64-67 returns 0 (`l_dot_n.is_sign_negative()`), the contribution is
+//       emission * 0 — nothing is added whatever the shadow ray finds (bsdf_eval tests the same sign bit on the same two vectors).
+//   (3) the shaded point lies on a SPHERE and the emitter is below its horizon: the shadow ray starts OFFSET above the sphere and runs
+//       into it.  Same geometry as (1) from the other end: xo = (ro + OFFSET) (-n . d) is the distance from the origin to the closest
+//       approach, the ray enters the sphere (xo^2 > 2 ro OFFSET + OFFSET^2, with the same factor 2) at a distance of at most xo, and that
+//       hit is more than 0.0201 in front of the sample when L - xo > 0.0201 + slack.  own_r = 0: the shaded point is not on a sphere.
+// A culled ray is one the reference traces and then discards; the accumulator is the same to the bit (test_nee_culls_do_not_change_a_bit).
+HD bool nee_setup(const Scene &sc, Path &p, uint32_t cull) {
     const Emitter em = sc.emitters[path_emitter(p)];
     float unit_z = 1.0f - 2.0f * p.r1;
     float a = HR_SQRT(fmaxf(1.0f - unit_z * unit_z, 0.0f));
     float sn_, cs_;
     HR_SINCOS_2PI(p.r0, sn_, cs_);
     V3f sn = v3(a * cs_, a * sn_, unit_z);
-    V3f sp = v3(em.c) + (em.r + OFFSET_F) * sn;
+    const float ro = em.r + OFFSET_F;
+    V3f sp = v3(em.c) + ro * sn;
     V3f sv = sp - p.next_o;
     float sl2 = dot(sv, sv), isl = HR_RSQ(sl2);
-    p.shadow_len = sl2 * isl;
-    ray_set(p.ray, p.next_o, sv * isl);
+    const float len = sl2 * isl;
+    const V3f d = sv * isl;
+    if (cull) {
+        const float slack = 0.0221f + 1e-6f * len;
+        const float x = ro * dot(sn, d);
+        const bool far_side = x > slack && x * x > 2.0f * (2.0f * em.r * OFFSET_F + OFFSET_F * OFFSET_F) && len > 2.0f * x;   // (len > 2 x: the origin lies in front of the entry point, which is at most 2 x before the sample)
+        const float nd = dot(p.n, d);
+        const bool ggx_below = (cull & 2u) && path_surface(p) == 3 && signbit(nd);
+        const float rs = p.own_r + OFFSET_F, xo = -rs * nd;
+        const bool own_sphere = p.own_r > 0.0f && xo * xo > 2.0f * (2.0f * p.own_r * OFFSET_F + OFFSET_F * OFFSET_F) && xo > 0.0f && len - xo > slack;
+        if (far_side || ggx_below || own_sphere) return false;
+    }
+    p.shadow_len = len;
+    ray_set(p.ray, p.next_o, d);
     ray_quantise(sc, p.ray);
     // a closest hit beyond the sample point can never pass the proximity test (vector.rs:89-91: |dp|^2 < 4e-4),
     // so the search is limited to the sample distance + 0.03 (the reference does an unbounded closest-hit query)
     trace_begin(p.ts, p.shadow_len + 0.03f, p.ray.start);
     p.st |= 16u;
+    return true;
 }
 
 // A shadow ray only contributes when its closest hit lies within 0.02 of the sample point (renderer.rs:280-282 with
@@ -742,12 +776,10 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         if (!sampled) return true;  // renderer.rs:190-193
         p.accum = p.accum + p.refl * m.emission;          // renderer.rs:196
         p.refl = p.refl * m.albedo;                       // renderer.rs:183,295 (NEE scale) and the first factor of :197
-        if (nee_available(m.surface) && sc.num_emitters > 0) {
-            p.n = s.n; p.param = m.param; p.roughness = m.roughness;
-            p.st = (p.st & 15u) | ((uint32_t)m.surface << 5);   // emitter 0; the phase bit is set by nee_setup
-            nee_setup(sc, p);
-            return false;
-        }
+        if (!(nee_available(m.surface) && sc.num_emitters > 0)) goto bounce;
+        p.n = s.n; p.param = m.param; p.roughness = m.roughness;
+        p.own_r = p.ts.type == 1 ? sc.spheres[p.ts.prim].w : 0.0f;
+        p.st = (p.st & 15u) | ((uint32_t)m.surface << 5);   // emitter 0; the phase bit is set by nee_setup
     } else {
         // renderer.rs:280-292.  Hit point and sample point lie on the same ray: |hit - sample| = |t - shadow_len|
         float dt = p.ts.t - p.shadow_len;
@@ -769,10 +801,17 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
             p.accum = p.accum + p.refl * (e * w);
             if (LOG) plog_or(*lg, path_iter(p), 16u << (path_emitter(p) & 3u));
         }
-        p.st += 256u;     // next emitter
-        if (path_emitter(p) < sc.num_emitters) { nee_setup(sc, p); return false; }
-        p.st &= 15u;      // back to the main ray
+        p.st = (p.st & ~16u) + 256u;     // next emitter
     }
+    // the next emitter whose shadow ray has to be traced (renderer.rs:274: `for emission in emissions`, in order); the ones nee_setup
+    // culls are rays the reference traces and discards — they count as rays of the path in the log, not in the kernel's counters
+    for (; path_emitter(p) < sc.num_emitters; p.st += 256u) {
+        if (nee_setup(sc, p, rp.nee_cull_off ? 0u : (LOG ? 1u : 3u))) return false;
+        if (CNT) cn->shadow_culled++;
+        if (LOG) lg->rays++;
+    }
+    p.st &= 15u;      // back to the main ray
+bounce:
     // renderer.rs:197-199 (a miss returned above)
     p.refl = p.refl * p.cur_refl;
     if (is_zero(p.refl) || path_iter(p) >= 9u) return true;

@@ -97,15 +97,15 @@ __device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParam
 template <bool CNT>
 __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uint32_t npaths, const LaneCounters &lc, const WaveStats &ws) {
     if (!CNT) return;
-    unsigned long long v[6] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests};
-    for (int i = 0; i < 6; i++) {
+    unsigned long long v[7] = {npaths, lc.rays, lc.node_tests, lc.tri_tests, lc.sphere_tests, lc.cuboid_tests, lc.shadow_culled};
+    for (int i = 0; i < 7; i++) {
         unsigned long long x = v[i];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         v[i] = x;
     }
     if (lane == 0) {
         atomicAdd(&cnt->paths, v[0]); atomicAdd(&cnt->rays, v[1]); atomicAdd(&cnt->node_tests, v[2]);
-        atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]);
+        atomicAdd(&cnt->tri_tests, v[3]); atomicAdd(&cnt->sphere_tests, v[4]); atomicAdd(&cnt->cuboid_tests, v[5]); atomicAdd(&cnt->shadow_culled, v[6]);
         atomicAdd(&cnt->shade_calls, (unsigned long long)ws.ph[0]); atomicAdd(&cnt->shade_lanes, (unsigned long long)ws.ph[1]);
         atomicAdd(&cnt->box_passes, (unsigned long long)ws.ph[2]); atomicAdd(&cnt->box_lanes, (unsigned long long)ws.ph[3]);
         atomicAdd(&cnt->leaf_calls, (unsigned long long)ws.ph[4]); atomicAdd(&cnt->leaf_lanes, (unsigned long long)ws.ph[5]);
@@ -121,7 +121,7 @@ template <bool CNT, int MINW, bool QN, bool RR = false, bool LOG = false>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter, uint32_t *plog = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
-    LaneCounters lc = {0, 0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0, 0};
     uint32_t npaths = 0;
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t kchunk = rp.kchunk ? rp.kchunk : TRACE_KCHUNK;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void trace_debug_kernel(Scene sc, RenderParams 
     if (sl > 0.0f) { trace_begin(p.ts, sl + 0.03f, p.ray.start); p.st |= 16u; }   // nee_setup's search limit, shadow phase
     else trace_begin(p.ts, T_INF, p.ray.start);
     if (!active) { p.ts.cur = NODE_END; p.ts.leaf = 0; }
-    LaneCounters lc = {0, 0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0, 0};
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t n_active = (uint32_t)__popcll(wave_ballot(active));
     uint32_t tick = 0;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void debug_render_kernel(Scene sc
     uint32_t px, py, sub;
     tile_lane_pixel(rp, tile, lane, px, py, sub);
     const bool active = px < rp.width && py < rp.height;
-    LaneCounters lc = {0, 0, 0, 0, 0};
+    LaneCounters lc = {0, 0, 0, 0, 0, 0};
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     Path p;
     p.q = active ? lane : PATH_IDLE;

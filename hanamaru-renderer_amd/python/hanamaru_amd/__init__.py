@@ -70,6 +70,14 @@ class SceneDesc(C.Structure):
                 ("skybox", Skybox), ("camera", Camera)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("path", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("device", C.c_int32),
+                ("rccl_version", C.c_int32), ("_pad", C.c_int32), ("allreduces", C.c_uint64)]
+
+
+COMM_PATHS = {0: "none", 1: "rccl-rank", 2: "rccl-group", 3: "same-device-fallback"}
+
+
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("cuboid_tests", C.c_uint64),
@@ -81,7 +89,7 @@ class Stats(C.Structure):
                 ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
                 ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8),
                 ("debug_kernel_ms", C.c_double), ("debug_launches", C.c_uint64),
-                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64)]
+                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64), ("shadow_culled", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}
@@ -163,6 +171,8 @@ def hip_lib():
         L.hr_allreduce_accumulators.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.hr_total_device_ptr.argtypes = [C.c_void_p]
         L.hr_total_device_ptr.restype = C.c_void_p
+        L.hr_comm_info.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
+        L.hr_accumulator_sum.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         _hip = L
     return _hip
 
@@ -370,6 +380,19 @@ class Renderer:
 
     def total_device_ptr(self):
         return self.L.hr_total_device_ptr(self._h)
+
+    def comm_info(self):
+        """hr_comm_info: what the communicator reports about itself (ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion)."""
+        ci = CommInfo()
+        self._check(self.L.hr_comm_info(self._h, C.byref(ci)))
+        return {"path": COMM_PATHS.get(ci.path, "?"), "nranks": int(ci.nranks), "rank": int(ci.rank), "device": int(ci.device),
+                "rccl_version": int(ci.rccl_version), "allreduces": int(ci.allreduces)}
+
+    def accumulator_sum(self, total=False):
+        """hr_accumulator_sum: per-channel f64 sums (device reduction) of this context's own accumulator, or of the all-reduced total."""
+        out = (C.c_double * 3)()
+        self._check(self.L.hr_accumulator_sum(self._h, 1 if total else 0, out))
+        return [float(out[0]), float(out[1]), float(out[2])]
 
     def debug_draws(self, sampling, first_path, num_paths, window):
         out = np.empty((num_paths, window), dtype=np.uint64)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 5
+#define HR_ABI_VERSION 6
 
 typedef enum hr_status {
     HR_OK = 0,
@@ -128,6 +128,9 @@ typedef struct hr_stats {
     /* the priority governor (option trace_boost): the level kernels start at now (0 = the seed kernel's producer waves first .. 4 = the
      * trace kernel's box and leaf phases first), launches it has judged since the last scene / resolution / option change, level changes */
     uint64_t governor_level, governor_decisions, governor_moves;
+    /* counters build: NEE shadow rays the reference traces and discards, which the kernel knows to add nothing before it traces them
+     * (sample on the emitter's far side; GGX with the emitter below the horizon; the shaded sphere itself in the way) — not in `rays` */
+    uint64_t shadow_culled;
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;
@@ -205,6 +208,25 @@ int hr_allreduce_accumulator(hr_ctx *ctx);
 int hr_allreduce_accumulators(hr_ctx **ctxs, int n);
 void *hr_total_device_ptr(hr_ctx *ctx);   /* device pointer of the all-reduced accumulator, NULL when not valid */
 
+/* What the context's communicator says about ITSELF (asked of RCCL at the time of the call: ncclCommCount, ncclCommUserRank,
+ * ncclCommCuDevice, ncclGetVersion) — so that a host can print evidence that its all-reduce really ran over N ranks:
+ *   path  HR_COMM_NONE            no communicator
+ *         HR_COMM_RCCL_RANK       hr_comm_init_rank: this process is one rank of an RCCL communicator
+ *         HR_COMM_RCCL_GROUP      hr_comm_init_local over distinct devices: one process, one RCCL communicator per device
+ *         HR_COMM_SAME_DEVICE_SUM hr_comm_init_local over contexts that share one device: NOT RCCL, a sum kernel on that device
+ *   nranks / rank / device: RCCL's answers (same-device sum: the group's size, this context's index, the shared device)
+ *   rccl_version: ncclGetVersion's code (0 without RCCL);  allreduces: collectives this context has enqueued on that communicator */
+enum { HR_COMM_NONE = 0, HR_COMM_RCCL_RANK = 1, HR_COMM_RCCL_GROUP = 2, HR_COMM_SAME_DEVICE_SUM = 3 };
+typedef struct hr_comm_info_t {
+    int32_t path, nranks, rank, device;
+    int32_t rccl_version, _pad;
+    uint64_t allreduces;
+} hr_comm_info_t;
+int hr_comm_info(hr_ctx *ctx, hr_comm_info_t *out);
+/* Per-channel sum of an accumulator, in f64 on the device: which = 0 this context's own accumulator, 1 = the all-reduced total.
+ * The checksum of the exchange: the ranks' own sums add up to the total's sum (to fp32 rounding of the all-reduce: ~1e-7 relative). */
+int hr_accumulator_sum(hr_ctx *ctx, int which, double out_rgb[3]);
+
 int hr_get_stats(hr_ctx *ctx, hr_stats *out);
 /* Options that leave the image as the reference computes it (the summation order of the accumulator aside):
  *   "counters"      0 / 1: instrumented build of the trace kernel (fills the counter fields of hr_stats)
@@ -229,51 +251,9 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *                   indices, not from its ISAAC-64 stream, whose draws the reference estimator has all spoken for); its noise
  *                   changes, it traces ~10 % fewer rays. */
 int hr_set_option(hr_ctx *ctx, const char *key, double value);
-/* Measurement / experiment knobs, kept out of hr_set_option so that a host cannot change the kernels' schedule — or produce a
- * garbage image — by a key string meant for a product option: "adv_den" / "leaf_den" (trace-kernel phase thresholds), "min_waves"
- * (4..6, occupancy variant of the trace kernel; only with quant_nodes = 1), "kchunk", "node_unroll" (1 | 2), "trace_wgs",
- * "seed_mode" (2 = three-run seed kernel, default; 3 = its phase-shifted four-run form and 4 = its five-wave four-run form, both
- * slower, kept as measured experiments; 1 = producer / consumer kernel with a
- * ring of generator words; 0 = fused),
- * "seed_split" (seed_mode 1), "seed_prio" / "init_prio" (s_setprio of the seed kernel's consumer / producer waves), "seed_prof"
- * (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles; seed_mode 3: 1 | 2 | 3 = consumer 0, consumer 1, producer 0), "ploc_top" (bvh_builder 2: clusters the bottom-up merges
- * leave for the top-down build over them; 1 = merge to the root; takes effect at the next hr_upload_scene), "debug_skip" (bit mask that drops parts of the pipeline
- * for timing experiments: THE IMAGE IS GARBAGE). */
-int hr_set_debug_option(hr_ctx *ctx, const char *key, double value);
-
-/* ---- unit-level entry points used by the parity tests (same kernels' device functions) ---- */
-
-/* Raw ISAAC-64 outputs of the per-path generators exactly as the seed kernel stores them:
- * for path p (= pixel-major, sub-sample minor: ((y*W + x)*4 + sy*2 + sx)) out[p*window + k] =
- * k-th next_u64() of StdRng::from_seed([8700304, sampling, s, t]) (renderer.rs:165-168). */
-int hr_debug_draws(hr_ctx *ctx, uint32_t sampling, uint32_t first_path, uint32_t num_paths,
-                   uint32_t window, uint64_t *host_out);
-
-/* The DRAWS_PER_PATH (=20) fp32 draws the seed kernel hands to the trace kernel for every path of one
- * sampling: out[((y*W + x)*4 + sub)*20 + d]; d=0,1 = accepted lens sample (2u-1, 2v-1) after the rejection
- * loop of camera.rs:66-81, d=2.. = the (f64,f64) pairs of renderer.rs:175 in order. */
-int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
-
-/* Per-path accounting of ONE sampling through the production pipeline (seed kernel + the render kernel's LOG instantiation: the same
- * traversal and the same path state machine as hr_render; the accumulator is not touched).  out: W*H*4 records of eight 32-bit words,
- * record ((y*W + x)*4 + sy*2 + sx) = { radiance r, g, b (float bits) of calc_pixel (renderer.rs:163-203), scene.intersect calls of the path
- * (main + shadow rays), event log bytes 0-3, 4-7, 8 (one byte per iteration of renderer.rs:174, see pt_core.h PathLog: miss / surface type
- * hit / sample returned None, reflected or transmitted, which emitters' shadow rays were visible), hash of the element indices hit }.
- * The oracle keeps the same log (orc_path_log): tests/test_gpu_parity.py compares path by path. */
-int hr_debug_path_log(hr_ctx *ctx, uint32_t sampling, uint32_t *host_out);
-
-/* Closest-hit query for n rays (scene.rs:385-401 minus the material fetch).
- * rays: n * 6 floats (origin, direction).  out per ray: 8 floats
- * { hit(0/1), distance, pos.x, pos.y, pos.z, n.x, n.y, n.z }, plus element index in out_element. */
-int hr_debug_intersect(hr_ctx *ctx, uint32_t n, const float *rays, float *out, int32_t *out_element);
-
-/* The same query through the PRODUCTION traversal of hr_render (scalar walk above: one node + its leaf per step on the 32-byte
- * records): 64 rays per wave through the render kernel's box / leaf phases on the record format it walks for this scene, with
- * parked leaves and closest-hit culling.  shadow_len == NULL or shadow_len[i] <= 0: closest hit (bvh.rs:213-290 + scene.rs:385-401).
- * shadow_len[i] > 0: ray i is a shadow ray towards a light sample at that distance (renderer.rs:276-282) — the search is limited to
- * the sample distance + 0.03 and stops at the first hit more than 0.02 in front of the sample, exactly as in the render kernel;
- * the visibility verdict of renderer.rs:280 is then  hit && (distance - shadow_len)^2 < 4e-4. */
-int hr_debug_trace(hr_ctx *ctx, uint32_t n, const float *rays, const float *shadow_len, float *out, int32_t *out_element);
+/* The measurement knobs (hr_set_debug_option) and the unit-level entry points of the parity tests (hr_debug_*) live in
+ * hanamaru_hip_debug.h: same library, but a product host — the Rust shell of INTEGRATION.md, the hanamaru-hip CLI — includes and binds
+ * this header only (tests/test_abi.py checks that the CLI binary imports no hr_debug_* symbol). */
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,10 @@ pub const HR_MESH: i32 = 2;
 #[repr(C)] pub struct HrSceneDesc { pub elements: *const HrElement, pub num_elements: u32,
                                     pub images: *const HrImage, pub num_images: u32,
                                     pub skybox: HrSkybox, pub camera: HrCamera }
+/// hr_comm_info_t: what the communicator reports about itself (path: 0 none, 1 RCCL rank of hr_comm_init_rank, 2 RCCL group of one
+/// process, 3 same-device sum — not RCCL)
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct HrCommInfo { pub path: i32, pub nranks: i32, pub rank: i32, pub device: i32,
+                                                                    pub rccl_version: i32, pub _pad: i32, pub allreduces: u64 }
 pub enum HrCtx {}
 
 extern "C" {
@@ -56,11 +60,14 @@ extern "C" {
     pub fn hr_allreduce_accumulator(ctx: *mut HrCtx) -> c_int;
     pub fn hr_allreduce_accumulators(ctxs: *mut *mut HrCtx, n: c_int) -> c_int;
     pub fn hr_comm_destroy(ctx: *mut HrCtx) -> c_int;
+    pub fn hr_comm_info(ctx: *mut HrCtx, out: *mut HrCommInfo) -> c_int;
+    /// which: 0 = this context's own accumulator, 1 = the all-reduced total; per-channel f64 sums (the checksum of the exchange)
+    pub fn hr_accumulator_sum(ctx: *mut HrCtx, which: c_int, out_rgb: *mut f64) -> c_int;
 }
 
 // ---- GENERATED by tools/gen_rust_layout.py from include/hanamaru_hip.h: do not edit ----
 /// the ABI these mirrors were checked against (hr_abi_version() of the library must return it)
-pub const HR_ABI_VERSION: i32 = 5;
+pub const HR_ABI_VERSION: i32 = 6;
 const _: () = assert!(std::mem::size_of::<HrTexture>() == 32 && std::mem::align_of::<HrTexture>() == 8);   // hr_texture
 const _: () = assert!(std::mem::size_of::<HrMaterial>() == 112 && std::mem::align_of::<HrMaterial>() == 8);   // hr_material
 const _: () = assert!(std::mem::size_of::<HrImage>() == 16 && std::mem::align_of::<HrImage>() == 8);   // hr_image
@@ -68,6 +75,7 @@ const _: () = assert!(std::mem::size_of::<HrElement>() == 232 && std::mem::align
 const _: () = assert!(std::mem::size_of::<HrCamera>() == 168 && std::mem::align_of::<HrCamera>() == 8);   // hr_camera
 const _: () = assert!(std::mem::size_of::<HrSkybox>() == 48 && std::mem::align_of::<HrSkybox>() == 8);   // hr_skybox
 const _: () = assert!(std::mem::size_of::<HrSceneDesc>() == 248 && std::mem::align_of::<HrSceneDesc>() == 8);   // hr_scene_desc
+const _: () = assert!(std::mem::size_of::<HrCommInfo>() == 32 && std::mem::align_of::<HrCommInfo>() == 8);   // hr_comm_info_t
 const _: () = assert!(std::mem::size_of::<Vector3>() == 24);   // hr_vec3
 #[cfg(test)]
 mod layout {
@@ -113,6 +121,12 @@ mod layout {
         assert_eq!(off!(HrSceneDesc, num_images), 24);
         assert_eq!(off!(HrSceneDesc, skybox), 32);
         assert_eq!(off!(HrSceneDesc, camera), 80);
+        assert_eq!(off!(HrCommInfo, path), 0);
+        assert_eq!(off!(HrCommInfo, nranks), 4);
+        assert_eq!(off!(HrCommInfo, rank), 8);
+        assert_eq!(off!(HrCommInfo, device), 12);
+        assert_eq!(off!(HrCommInfo, rccl_version), 16);
+        assert_eq!(off!(HrCommInfo, allreduces), 24);
     }
 }
 // ---- END GENERATED ----

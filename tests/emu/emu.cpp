@@ -326,15 +326,20 @@ int emu_raw_draws_seg(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t
     return 0;
 }
 
-// counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests
+// nee_setup's shortcuts (pt_core.h): 1 = on (the kernel's default), 0 = every NEE shadow ray is traced
+static int g_nee_cull = 1;
+void emu_set_nee_cull(int on) { g_nee_cull = on; }
+
+// counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, shadow_culled
 int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc,
                uint64_t *counters) {
     Scene sc = e->view;
     sc.qnodes = nullptr;   // the emulated render walks the 32-byte records (node indices): every ray's walk starts at 0
     RenderParams rp{};
     rp.width = W; rp.height = H;
+    rp.nee_cull_off = g_nee_cull ? 0u : 1u;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-    std::vector<std::vector<uint64_t>> cn(nthreads, std::vector<uint64_t>(6, 0));
+    std::vector<std::vector<uint64_t>> cn(nthreads, std::vector<uint64_t>(7, 0));
     for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
         std::atomic<uint32_t> next{0};
         auto work = [&](int tid) {
@@ -350,14 +355,14 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
                         emu_place_path(rpp, W, H, x, y, sub, p, rec);
                         path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
                         path_start(sc, rpp, p, x, y, sub, rec.f);
-                        LaneCounters lc = {0, 0, 0, 0, 0};
+                        LaneCounters lc = {0, 0, 0, 0, 0, 0};
                         for (;;) {
                             while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
                             if (path_advance<true>(sc, rpp, p, rec.f, &lc)) break;
                         }
                         sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
                         cn[tid][0]++; cn[tid][1] += lc.rays; cn[tid][2] += lc.node_tests; cn[tid][3] += lc.tri_tests;
-                        cn[tid][4] += lc.sphere_tests; cn[tid][5] += lc.cuboid_tests;
+                        cn[tid][4] += lc.sphere_tests; cn[tid][5] += lc.cuboid_tests; cn[tid][6] += lc.shadow_culled;
                     }
                     float *o = &acc[((size_t)y * W + x) * 3];
                     o[0] += sum[0]; o[1] += sum[1]; o[2] += sum[2];
@@ -369,7 +374,7 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
         for (auto &t : th) t.join();
     }
     if (counters)
-        for (int k = 0; k < 6; k++) { counters[k] = 0; for (auto &c : cn) counters[k] += c[k]; }
+        for (int k = 0; k < 7; k++) { counters[k] = 0; for (auto &c : cn) counters[k] += c[k]; }
     return 0;
 }
 
@@ -380,6 +385,7 @@ int emu_path_log(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, 
     sc.qnodes = nullptr;
     RenderParams rp{};
     rp.width = W; rp.height = H;
+    rp.nee_cull_off = g_nee_cull ? 0u : 1u;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     std::atomic<uint32_t> next{0};
     auto work = [&]() {
@@ -394,7 +400,7 @@ int emu_path_log(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, 
                     emu_place_path(rpp, W, H, x, y, sub, p, rec);
                     path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
                     path_start(sc, rpp, p, x, y, sub, rec.f);
-                    LaneCounters lc = {0, 0, 0, 0, 0};
+                    LaneCounters lc = {0, 0, 0, 0, 0, 0};
                     PathLog lg;
                     plog_reset(lg);
 #if defined(HR_PATH_VERBOSE)
@@ -448,7 +454,7 @@ int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out,
         ray_quantise(sc, r);
         TraceState ts;
         trace_begin(ts, T_INF, g_walk_mode == 2 ? r.start : 0u);   // 16-byte records: byte offset of the octant's copy; 32-byte records: node index
-        LaneCounters lc = {0, 0, 0, 0, 0};
+        LaneCounters lc = {0, 0, 0, 0, 0, 0};
         if (g_walk_mode == 0) {
             while (ts.cur != NODE_END) trace_step<true>(sc, r, ts, &lc);
         } else {

@@ -57,9 +57,9 @@ class EmuScene:
     def render(self, w, h, s_begin, s_end, stride=1, threads=0, acc=None):
         if acc is None:
             acc = np.zeros((h, w, 3), dtype=np.float32)
-        cn = (C.c_uint64 * 6)()
+        cn = (C.c_uint64 * 7)()
         lib().emu_render(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data, cn)
-        return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests"], list(cn)))
+        return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests", "shadow_culled"], list(cn)))
 
     def path_log(self, w, h, sampling, threads=0):
         """(radiance [h, w, 4, 3] float32, rays, events [h, w, 4, 10] uint8 (nine event bytes + the count of sphere hits), element hash) — the layout of Renderer.debug_path_log"""
@@ -92,6 +92,12 @@ def set_walk_mode(mode):
     """0 = node + leaf per visit, 1 = the trace kernel's postponed-leaf schedule, 2 = that schedule on the 16-byte quantised
     nodes (EmuScene.intersect)."""
     lib().emu_set_walk_mode(mode)
+
+
+def set_nee_cull(on):
+    """nee_setup's shortcuts (pt_core.h): shadow rays known to add nothing are not traced (default on)."""
+    lib().emu_set_nee_cull.argtypes = [C.c_int]
+    lib().emu_set_nee_cull(1 if on else 0)
 
 
 def last_node_tests():

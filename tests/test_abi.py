@@ -16,11 +16,30 @@ def _declared(header, prefix):
 
 def test_hip_library_exports_header(ha):
     names = _declared("hanamaru_hip.h", "hr")
-    assert len(names) >= 18
+    assert len(names) >= 29 and "hr_comm_info" in names and "hr_accumulator_sum" in names
+    debug = _declared("hanamaru_hip_debug.h", "hr")
+    assert set(debug) == {"hr_set_debug_option", "hr_debug_draws", "hr_debug_path_draws", "hr_debug_path_log", "hr_debug_intersect", "hr_debug_trace"}
+    assert not [n for n in names if n.startswith("hr_debug_") or n == "hr_set_debug_option"], "the product header declares a debug entry point"
     lib = C.CDLL(ha.HIP_LIB)
-    for n in names:
+    for n in names + debug:
         assert hasattr(lib, n), "libhanamaru_hip.so lacks %s" % n
-    assert ha.hip_lib().hr_abi_version() == 5
+    assert ha.hip_lib().hr_abi_version() == 6
+
+
+def test_product_hosts_bind_the_product_header_only(ha):
+    """hr_debug_* / hr_set_debug_option are declared in hanamaru_hip_debug.h, not in the product header: the hanamaru-hip CLI (the C++ stand-in
+    for the Rust shell) must not import one of them, and neither the Rust mirror nor INTEGRATION.md may name one as something to bind."""
+    import subprocess
+    cli = os.path.join(ROOT, "hanamaru-renderer_amd", "hanamaru-hip")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built (needs libhanamaru_hip.so: __graft_entry__.build())")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", cli], stdout=subprocess.PIPE, text=True, check=True).stdout
+    used = sorted(set(re.findall(r"\b(hr_[a-z0-9_]+)", syms)))
+    assert used and "hr_render" in used
+    assert not [n for n in used if n.startswith("hr_debug_") or n == "hr_set_debug_option"], used
+    assert "hanamaru_hip_debug.h" not in open(os.path.join(ROOT, "hanamaru-renderer_amd", "host", "cli_main.cpp")).read()
+    ffi = open(os.path.join(ROOT, "rust", "hip_ffi.rs")).read()
+    assert not re.search(r"pub fn (hr_debug_|hr_set_debug_option)", ffi)
 
 
 def test_host_library_exports_header(ha):
@@ -36,7 +55,7 @@ def test_struct_layouts_match_header(ha):
     assert C.sizeof(ha.Vec3) == 24 and C.sizeof(ha.Texture) == 32 and C.sizeof(ha.Material) == 16 + 3 * 32
     assert C.sizeof(ha.Image) == 16 and C.sizeof(ha.Camera) == 6 * 24 + 24 and C.sizeof(ha.Skybox) == 48
     assert C.sizeof(ha.Element) == 8 + 112 + 32 + 48 + 32
-    assert C.sizeof(ha.Stats) == 41 * 8
+    assert C.sizeof(ha.Stats) == 42 * 8 and C.sizeof(ha.CommInfo) == 32
 
 
 def test_no_device_is_a_clean_error(ha):

@@ -78,7 +78,8 @@ def test_radiance_accumulator(emu_scenes, name, w, h, s):
     # path structure: same number of rays within 0.1 % (an fp32 branch flip changes a path's length)
     ref_rays = rc["rays_primary"] + rc["rays_bounce"] + rc["rays_shadow"]
     assert cn["paths"] == rc["paths"] == w * h * 4 * s
-    assert abs(cn["rays"] - ref_rays) <= 1e-3 * ref_rays
+    # (the shadow rays nee_setup knows to add nothing are scene.intersect calls of the reference that the per-lane code does not make)
+    assert abs(cn["rays"] + cn["shadow_culled"] - ref_rays) <= 1e-3 * ref_rays
     # on the mesh scenes the device tree + culling must do less work than the reference-order walk it replaces
     if name.startswith("rtcamp6"):
         assert cn["node_tests"] * 1.5 < rc["mesh_node_tests"] + rc["top_node_tests"] and cn["tri_tests"] * 3 < rc["tri_tests"]
@@ -434,7 +435,7 @@ def test_per_path_event_log(emu_scenes, name, w, h):
     g = e.path_log(w, h, 1)
     r = o.path_log(w, h, 1)
     acc, cn = e.render(w, h, 1, 2)
-    assert cn["rays"] == int(g[1].sum())                                        # the log's ray count is the counters' ray count
+    assert cn["rays"] + cn["shadow_culled"] == int(g[1].sum())                                        # the log's ray count is the counters' ray count
     np.testing.assert_allclose(g[0].astype(np.float64).sum(axis=2), acc, rtol=1e-5, atol=1e-6)
     ref, ocn = o.render(w, h, 1, 2, counters=True)
     assert ocn["rays_primary"] + ocn["rays_bounce"] + ocn["rays_shadow"] == int(r[1].sum())
@@ -450,6 +451,27 @@ def test_per_path_event_log(emu_scenes, name, w, h):
     else:
         assert sb["no_sphere_bounce"]["over_1e-3_floor1_ppm"] == 0.0 and sb["over_1e-3_floor1_ppm"] <= 1500.0, sb
         assert all(int(k) >= 2 for k in sb["over_1e-3_by_sphere_bounces_ppm"]), sb  # the tail needs at least two sphere bounces
+
+
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_v2", "tbf3", "rtcamp5", "spheres", "cornell_mini", "material_examples"])
+def test_nee_culls_do_not_change_a_bit(emu, emu_scenes, name):
+    """The shadow rays nee_setup does not trace (sample on the emitter's far side, GGX below the horizon, the shaded sphere in the way) are
+    rays the reference traces and discards (renderer.rs:279-280): with the shortcuts off the per-lane code renders the same accumulator,
+    bit for bit, from more rays."""
+    _, _, e = emu_scenes(name)
+    try:
+        emu.set_nee_cull(True)
+        a, ca = e.render(96, 54, 1, 3)
+        la = e.path_log(96, 54, 1)
+        emu.set_nee_cull(False)
+        b, cb = e.render(96, 54, 1, 3)
+        lb = e.path_log(96, 54, 1)
+    finally:
+        emu.set_nee_cull(True)
+    assert np.array_equal(a, b)
+    assert cb["shadow_culled"] == 0 and ca["shadow_culled"] > 0 and ca["rays"] + ca["shadow_culled"] == cb["rays"]
+    for x, y in zip(la, lb):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

@@ -492,7 +492,8 @@ def test_config3_full_size_crops(gpu, scenes):
     gpu.set_option("counters", 0)
     assert st["paths"] == 1920 * 1080 * 4 * 8 and st["rng_overflow"] == 0
     assert (acc.sum(axis=2) > 0).mean() > 0.9   # black floor texels (albedo 0) and dark sky stay exactly 0
-    assert 2.5 < st["rays"] / st["paths"] < 3.6          # 3.05 rays per path
+    assert 2.5 < (st["rays"] + st["shadow_culled"]) / st["paths"] < 3.6          # 3.05 rays per path (scene.intersect calls of the reference: traced + culled)
+    assert 2.0 < st["rays"] / st["paths"] < 2.9          # what the kernel traces of them
 
 
 def test_post_chain_matches_oracle(gpu, scenes, orc):
@@ -880,6 +881,40 @@ def test_priority_governor_does_not_change_results(gpu, scenes):
         assert np.array_equal(outs[0], o), np.abs(outs[0] - o).max()
 
 
+def test_nee_culls_do_not_change_a_bit(gpu, scenes):
+    """nee_setup (pt_core.h) does not trace a shadow ray whose contribution is known to be exactly zero before it starts: the sample lies on
+    the far side of the emitter (sample_on_surface draws over the whole sphere, scene.rs:92-101 — more than half of the samples), the surface
+    is GGX and the emitter below its horizon (material.rs:64-67 returns 0), or the shaded sphere itself is in the way.  The reference traces
+    those rays and discards them (renderer.rs:279-280); with debug option nee_cull 0 so does the kernel — same accumulator, bit for bit, on
+    every scene type; and the path log still counts the reference's scene.intersect calls."""
+    try:
+        for name, w, h, s in [("rtcamp6_v3_1", 400, 225, 4), ("rtcamp6_v2", 320, 180, 2), ("tbf3", 320, 180, 2), ("rtcamp5", 320, 180, 2), ("rtcamp6_v1", 256, 144, 2),
+                              ("spheres", 320, 180, 2), ("cornell_mini", 200, 128, 4), ("material_examples", 256, 144, 2)]:
+            sc, _ = scenes(name)
+            gpu.upload_scene(sc)
+            gpu.set_resolution(w, h)
+            out = {}
+            for cull in (1, 0):
+                gpu.set_debug_option("nee_cull", cull)
+                gpu.set_option("counters", 1)
+                gpu.clear()
+                gpu.render(1, 1 + s)
+                st = gpu.stats()
+                gpu.set_option("counters", 0)
+                out[cull] = (gpu.read_accumulator().copy(), st, gpu.debug_path_log(1))
+            (a, sa, la), (b, sb, lb) = out[1], out[0]
+            assert a.sum() > 0 and np.array_equal(a, b), (name, np.abs(a - b).max())
+            assert sb["shadow_culled"] == 0 and sa["shadow_culled"] > 0
+            assert sa["rays"] + sa["shadow_culled"] == sb["rays"], (name, sa["rays"], sa["shadow_culled"], sb["rays"])
+            for x, y in zip(la, lb):      # radiance, ray counts (culled rays included), events, hashes of every path
+                assert np.array_equal(x, y), name
+            print("nee culls %s: %.3f of %.3f rays per path not traced (%.1f %% of the node tests)" %
+                  (name, sa["shadow_culled"] / sa["paths"], sb["rays"] / sb["paths"], 100.0 * (1.0 - sa["node_tests"] / sb["node_tests"])))
+    finally:
+        gpu.set_debug_option("nee_cull", 1)
+        gpu.set_option("counters", 0)
+
+
 def test_kernel_variants_render_the_same_bits(gpu, scenes):
     """The instrumented build (counters), the occupancy variants (min_waves 4 / 6), the walk on the 32-byte fp32 records (quant_nodes 0)
     and a device-built tree are other INSTRUCTION STREAMS for the same arithmetic: closest hits do not depend on the tree or the
@@ -997,6 +1032,16 @@ def test_bench_gpus_n_without_a_launcher(tmp_path):
     # the timed region's split, per rank
     m = j2["multi_gpu"]
     assert m["accumulator_bytes"] == 160 * 90 * 3 * 4 and len(m["per_rank"]) == 2 and [x["rank"] for x in m["per_rank"]] == [0, 1]
+    # the line proves its own exchange: what the communicators said about themselves, and parts == total
+    assert j1["multi_gpu"]["rccl"]["nranks"] == 1 and j1["multi_gpu"]["rccl"]["path"] == "none" and j1["multi_gpu"]["exchange_verified"]
+    assert j1["multi_gpu"]["checksum"]["rel_err"] == 0.0 and j1["multi_gpu"]["checksum"]["total"][0] > 0
+    rc, ck = m["rccl"], m["checksum"]
+    assert rc["nranks"] == 2 and rc["ranks_seen"] == [0, 1] and rc["allreduces_per_rank"] == [2] and m["exchange_verified"]       # warm-up + the timed one
+    if torch.cuda.device_count() >= 2:
+        assert rc["path"] == "rccl-group" and rc["devices_seen"] == [0, 1] and rc["version"] > 20000
+    else:
+        assert rc["path"] == "same-device-fallback" and rc["devices_seen"] == [0]
+    assert ck["rel_err"] < 1e-6 and ck["totals_identical_on_all_ranks"] and abs(sum(ck["total"]) / (160 * 90 * 3) - m2) <= 1e-5 * m2
     assert all(x["paths"] == 160 * 90 * 4 * 4 and x["render_ms"] > 0 and x["allreduce_ms"] > 0 and x["seed_kernel_ms"] > 0 for x in m["per_rank"])
     assert m["render_ms"]["max"] >= m["render_ms"]["min"] > 0 and 0 < m["allreduce_share_of_timed_region"] < 1
     # three contexts, odd step count
@@ -1031,6 +1076,69 @@ def test_bench_multirank_path_on_one_gpu(tmp_path):
     j2, m2 = _bench_line(_run_bench(["--gpus", "2", "--steps", "2", "--no-counters"], env={"HR_BENCH_ONE_DEVICE": "1"}, launcher_ranks=2))
     assert abs(m1 - m2) <= 1e-6 * m1
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0 and "roofline" in j2
+    assert j2["multi_gpu"]["checksum"] is None and "gloo" in j2["multi_gpu"]["rccl"]["source"]      # the aid is labelled as what it is
+
+
+def _two_gpus():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif("not _two_gpus()", reason="needs two GPUs (skipped on the 1-GPU box, live on any bigger one)")
+def test_rccl_group_over_two_distinct_devices(scenes, ha):
+    """hr_comm_init_local over two contexts on two DIFFERENT devices: ncclCommInitAll + one RCCL group all-reduce over xGMI (the path `python
+    bench.py --gpus N` and the CLI take on a multi-GPU node).  Sharded by sampling index, the total both contexts receive must be the
+    accumulator of one context that rendered every sampling (fp32 summation order aside), the communicators must say 2 ranks on devices 0 and
+    1, and the parts' f64 sums must add up to the total's."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    rs = [ha.Renderer(d) for d in (0, 1)]
+    try:
+        for r in rs:
+            r.upload_scene(sc)
+            r.set_resolution(320, 180)
+        ha.comm_init_local(rs)
+        infos = [r.comm_info() for r in rs]
+        assert [i["path"] for i in infos] == ["rccl-group"] * 2 and [i["nranks"] for i in infos] == [2, 2]
+        assert sorted(i["rank"] for i in infos) == [0, 1] and sorted(i["device"] for i in infos) == [0, 1] and infos[0]["rccl_version"] > 20000
+        for k, r in enumerate(rs):
+            r.render(1 + k, 9, 2)
+        ha.allreduce_accumulators(rs)
+        tots = [r.read_accumulator() for r in rs]
+        assert np.array_equal(tots[0], tots[1])
+        parts = np.sum([r.accumulator_sum(False) for r in rs], axis=0)
+        total = np.array(rs[0].accumulator_sum(True))
+        assert (np.abs(parts - total) <= 1e-6 * np.abs(total)).all() and total.min() > 0
+        one = ha.Renderer(0)
+        one.upload_scene(sc)
+        one.set_resolution(320, 180)
+        one.render(1, 9)
+        ref = one.read_accumulator().astype(np.float64)
+        one.close()
+        assert np.abs(tots[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        assert [r.comm_info()["allreduces"] for r in rs] == [1, 1]
+        # a device listed twice next to another one is refused before RCCL sees it
+        extra = ha.Renderer(0)
+        try:
+            with pytest.raises(ha.HipError):
+                ha.comm_init_local([rs[0], rs[1], extra])
+        finally:
+            extra.close()
+    finally:
+        for r in rs:
+            r.close()
+
+
+@pytest.mark.skipif("not _two_gpus()", reason="needs two GPUs (skipped on the 1-GPU box, live on any bigger one)")
+def test_bench_launcher_path_with_real_rccl_on_two_gpus(tmp_path):
+    """bench.py exactly as the driver launches N = 2: torch.distributed.run, one process per GPU, hr_comm_init_rank from a broadcast
+    ncclUniqueId, ncclAllReduce inside the library.  The line must prove its exchange (2 ranks, 2 devices, path rccl-rank, parts == total)
+    and the total must be a single-rank run's over the same sampling indices."""
+    j1, m1 = _bench_line(_run_bench(["--steps", "4", "--no-counters"]))
+    j2, m2 = _bench_line(_run_bench(["--gpus", "2", "--steps", "2", "--no-counters"], launcher_ranks=2))
+    assert abs(m1 - m2) <= 1e-6 * m1
+    rc, ck = j2["multi_gpu"]["rccl"], j2["multi_gpu"]["checksum"]
+    assert rc["path"] == "rccl-rank" and rc["nranks"] == 2 and rc["ranks_seen"] == [0, 1] and rc["devices_seen"] == [0, 1] and rc["version"] > 20000
+    assert ck["rel_err"] < 1e-6 and ck["totals_identical_on_all_ranks"] and j2["multi_gpu"]["exchange_verified"]
 
 
 def test_config5_4k_crops(gpu, scenes):
@@ -1549,10 +1657,18 @@ def test_rccl_allreduce_of_the_accumulator(gpu, scenes, ha):
     own = gpu.read_accumulator()
     uid = ha.comm_unique_id()
     assert len(uid) == ha.COMM_ID_BYTES and any(uid)
+    assert gpu.comm_info()["path"] == "none" and gpu.comm_info()["nranks"] == 0
     gpu.comm_init_rank(uid, 1, 0)
     try:
+        ci = gpu.comm_info()                   # asked of RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion
+        assert ci["path"] == "rccl-rank" and ci["nranks"] == 1 and ci["rank"] == 0 and ci["device"] == 0 and ci["rccl_version"] > 20000 and ci["allreduces"] == 0
         assert not gpu.total_device_ptr()
+        with pytest.raises(ha.HipError):
+            gpu.accumulator_sum(True)          # no total yet
         gpu.allreduce_accumulator()
+        assert gpu.comm_info()["allreduces"] == 1
+        s_own, s_tot = np.array(gpu.accumulator_sum(False)), np.array(gpu.accumulator_sum(True))
+        assert np.array_equal(s_own, s_tot) and np.allclose(s_own, own.astype(np.float64).sum(axis=(0, 1)), rtol=1e-12)
         assert gpu.total_device_ptr() and gpu.total_device_ptr() != gpu.L.hr_accumulator_device_ptr(gpu._h)
         tot = gpu.read_accumulator()
         assert np.array_equal(tot, own) and own.sum() > 0
@@ -1585,6 +1701,8 @@ def test_rccl_group_path_of_one_process_driving_its_gpus(scenes, ha):
         r.render(1, 4)
         own = r.read_accumulator()
         ha.comm_init_local([r])
+        ci = r.comm_info()
+        assert ci["path"] == "rccl-group" and ci["nranks"] == 1 and ci["rank"] == 0 and ci["rccl_version"] > 20000
         assert not r.total_device_ptr()
         ha.allreduce_accumulators([r])
         assert r.total_device_ptr() and r.total_device_ptr() != r.L.hr_accumulator_device_ptr(r._h)
@@ -1618,9 +1736,13 @@ def test_same_device_group_sum(scenes, ha):
             r.upload_scene(sc)
             r.set_resolution(80, 45)
         ha.comm_init_local(rs)
+        assert [r.comm_info()["path"] for r in rs] == ["same-device-fallback"] * 3 and [r.comm_info()["rank"] for r in rs] == [0, 1, 2]
+        assert rs[0].comm_info()["nranks"] == 3 and rs[0].comm_info()["rccl_version"] == 0
         for k, r in enumerate(rs):
             r.render(1 + k, 10, 3)
         ha.allreduce_accumulators(rs)
+        parts = np.sum([r.accumulator_sum(False) for r in rs], axis=0)
+        assert (np.abs(parts - np.array(rs[1].accumulator_sum(True))) <= 1e-6 * parts).all()
         tots = [r.read_accumulator().astype(np.float64) for r in rs]
         assert np.array_equal(tots[0], tots[1]) and np.array_equal(tots[0], tots[2])
         one = ha.Renderer(0)

@@ -49,7 +49,7 @@ def main():
             "channels_within_tolerance": float((rel <= 1e-2).mean()), "channels_within_1e-3": float((rel <= 1e-3).mean()),
             "mean_radiance_gpu": float(acc.mean() / (4 * s)), "mean_radiance_oracle": float(ref.mean() / (4 * s)),
             "mean_rel_diff": float(abs(acc.mean() - ref.mean()) / ref.mean()),
-            "rays_gpu": int(st["rays"]), "rays_oracle": int(ref_rays), "rays_rel_diff": float(abs(st["rays"] - ref_rays) / ref_rays),
+            "rays_gpu": int(st["rays"] + st["shadow_culled"]), "rays_gpu_traced": int(st["rays"]), "rays_oracle": int(ref_rays), "rays_rel_diff": float(abs(st["rays"] + st["shadow_culled"] - ref_rays) / ref_rays),
             "png_channels_exact": float((d8 == 0).mean()), "png_channels_within_1": float((d8 <= 1).mean()), "png_max_diff": int(d8.max()),
             "node_tests_per_ray_gpu": st["node_tests"] / max(1, st["rays"]),
             "node_tests_per_ray_reference_order": (cn["mesh_node_tests"] + cn["top_node_tests"]) / ref_rays,
