@@ -454,6 +454,7 @@ def main():
                 "seed_kernel_avg_ms": round(st["seed_kernel_ms"] / max(1, st["seed_launches"]), 4),
                 "bvh_builder": builder, "bvh_build_ms": round(st["bvh_build_ms"], 4),
                 "priority_governor": {"level": int(st["governor_level"]), "launches_judged": int(st["governor_decisions"]), "moves": int(st["governor_moves"]),
+                                      "trace_workgroups": int(st["governor_budget"]) or "all", "trace_workgroup_moves": int(st["governor_budget_moves"]),
                                       "note": "which kernel's waves come first (0 = the seed kernel's producer waves .. 4 = the trace kernel's box and leaf phases), decided on the device from the kernels' own time stamps, launch by launch"}}
 
         def loaded_bytes(c):   # what the lanes request for the tests they perform (device_scene.h record sizes)

@@ -224,6 +224,13 @@ struct GovDev {
     int32_t fixed;                           // >= 0: option trace_boost pins the level
     float known[5];                          // smoothed max(seed, trace) ticks per level, 0 = not tried yet
     uint32_t decisions, moves;               // launches the governor judged / times it changed the level
+    // The wave budget (round 5): how many of the trace kernel's persistent workgroups stay (blockIdx.x < budget; 0 = all).  Where the
+    // trace kernel is the faster kernel of the pair by a margin, every wave it does not need is a wave that does not take issue slots
+    // from the seed kernel beside it: the headline runs 3 workgroups per CU instead of 4 and the seed kernel 4 % faster.
+    uint32_t budget;                         // what trace kernels that start now obey
+    uint32_t bud[2];                         // the budget the trace kernel of each slot read
+    uint32_t budget_lo, budget_hi, budget_step;   // smallest budget, largest budget below "all", step (workgroups; set by the host from the CU count)
+    uint32_t budget_moves;
 };
 // the trace kernel's priority mask of a level (bits 0-3: which of every four box phases run at priority 1, bit 4: the leaf phase too)
 HD uint32_t gov_trace_mask(int32_t level) { return level >= 4 ? 0x1fu : level == 3 ? 0xfu : 0u; }
@@ -244,7 +251,8 @@ struct RenderParams {
     uint32_t ovf_cap;                 // seed kernels: entries of each consumer wave's fix-up list (sized per launch by hr_api.hip)
     uint32_t rr_start;                // trace kernel: Russian roulette from this iteration on (0 = off, the default: the reference has none)
     uint32_t gov_slot;                // parity of the launch: which slot of gov-> its two kernels stamp
-    uint32_t nee_cull_off;            // trace kernel: 1 = trace every NEE shadow ray, also those nee_setup knows to add nothing (debug option nee_cull 0: the A/B and the bit-equality test)
+    uint32_t nee_cull_off;            // trace kernel: which of nee_setup's three shortcuts are switched OFF (bit 0 far side, 1 GGX below the horizon, 2 own sphere); 7 = trace every NEE shadow ray (debug option nee_cull: the A/B and the bit-equality test)
+    uint32_t wg_budget;               // trace kernel: workgroups with blockIdx.x >= wg_budget leave at once (0 = all stay) — debug option trace_budget
     GovDev *gov;                      // nullptr: no governor (debug kernels, host emulation) — trace_boost / pad[1] as given
 };
 

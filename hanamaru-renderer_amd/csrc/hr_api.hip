@@ -100,6 +100,7 @@ struct hr_ctx {
     uint32_t adv_den = 2, leaf_den = 2;      // trace-kernel phase thresholds
     int min_waves = 5;                       // occupancy variant of the trace kernel
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
+    uint32_t trace_grid = 0, trace_budget = 0;   // debug: absolute grid size (0 = trace_wgs per CU) / workgroups that stay (0 = all)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
     int trace_boost = -1;                    // which kernel's waves come first: -1 = governed on the device from the kernels' own time stamps (default), 0 .. 4 = fixed level
@@ -113,7 +114,7 @@ struct hr_ctx {
     int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
     int seed_prof = 0;                       // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
-    bool nee_cull = true;                    // debug option nee_cull: 0 = trace every NEE shadow ray (bit-identical image, more rays)
+    uint32_t nee_cull = 7;                   // debug option nee_cull: mask of nee_setup's shortcuts in force (1 far side | 2 GGX below the horizon | 4 own sphere); 0 = trace every NEE shadow ray (bit-identical image, more rays)
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
@@ -190,17 +191,38 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
         // 38 ms against 26 — and is the slower kernel beyond doubt: such launches count too.  Until round 4 they did not, and the governor sat
         // at level 0, the wrong end, on exactly the scenes where the trace kernel needs the slots: +2.5 % there.)
         const bool beside = ov_trace > 0.7f || trace_t > 1.25f * seed_t;
+        // The wave budget comes first.  While the trace kernel is the faster kernel of the pair at level 0, workgroups it can do without are
+        // taken away (one step per judged launch, down to budget_lo), and given back step by step as soon as it comes within 3 % of the
+        // seed kernel; the priority levels only come into play with every workgroup in place.  Measured on the headline (1080p,
+        // 256 CUs; trace / seed ms per launch): all 1,536 workgroups 19.4 / 25.3, 896 20.6 / 24.7, 768 22.0 / 24.4, 704 23.3 / 24.3,
+        // 640 24.5 / 24.3 — the seed kernel gains what the trace kernel's waves no longer take, +3.5 % on the pair at 704 - 768.
+        const uint32_t B = g->bud[slot];
         if (ov_seed > 0.7f && beside && L == (int)g->lvl[1][slot] && L >= 0 && L < GOV_LEVELS) {
-            g->known[L] = g->known[L] > 0 ? 0.5f * (g->known[L] + m) : m;
             g->decisions++;
-            if (L == g->level) {   // (a launch that started before the last change of level: noted, nothing decided from it)
-                int next = L;
-                if (trace_t > 1.015f * seed_t && L < GOV_LEVELS - 1 && g->known[L + 1] == 0) next = L + 1;
-                else if (seed_t > 1.015f * trace_t && L > 0 && g->known[L - 1] == 0) next = L - 1;
-                else
-                    for (int k = 0; k < GOV_LEVELS; k++)
-                        if (g->known[k] > 0 && g->known[k] < 0.995f * g->known[next]) next = k;
-                if (next != L) { g->moves++; __hip_atomic_store(&g->level, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            bool budget_moved = false;
+            if (L == 0 && g->level == 0 && B == g->budget && g->budget_step) {
+                const float ratio = trace_t / seed_t;
+                uint32_t nb = B;
+                if (ratio > 0.97f && B) nb = B + g->budget_step > g->budget_hi ? 0u : B + g->budget_step;
+                else if (ratio < 0.88f) nb = !B ? g->budget_hi : (B >= g->budget_lo + g->budget_step ? B - g->budget_step : B);
+                if (nb != B) {
+                    budget_moved = true;
+                    g->budget_moves++;
+                    __hip_atomic_store(&g->budget, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < GOV_LEVELS; k++) g->known[k] = 0;   // another balance: what the levels were worth is to be learnt again
+                }
+            }
+            if (!budget_moved && B == 0 && g->budget == 0) {
+                g->known[L] = g->known[L] > 0 ? 0.5f * (g->known[L] + m) : m;
+                if (L == g->level) {   // (a launch that started before the last change of level: noted, nothing decided from it)
+                    int next = L;
+                    if (trace_t > 1.015f * seed_t && L < GOV_LEVELS - 1 && g->known[L + 1] == 0) next = L + 1;
+                    else if (seed_t > 1.015f * trace_t && L > 0 && g->known[L - 1] == 0) next = L - 1;
+                    else
+                        for (int k = 0; k < GOV_LEVELS; k++)
+                            if (g->known[k] > 0 && g->known[k] < 0.995f * g->known[next]) next = k;
+                    if (next != L) { g->moves++; __hip_atomic_store(&g->level, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
             }
         }
     }
@@ -219,6 +241,8 @@ static int govern_reset(hr_ctx *c) {
         for (int sl = 0; sl < 2; sl++) h.t0[k][sl] = ~0ull;
     h.fixed = c->trace_boost;
     h.level = c->trace_boost >= 0 ? c->trace_boost : 0;
+    // the wave budget is governed with the level (a fixed level pins it at "all"): 2.5 .. 3.5 workgroups per CU in steps of a quarter
+    if (c->trace_boost < 0) { h.budget_step = (uint32_t)c->num_cus / 4u; h.budget_lo = (uint32_t)c->num_cus * 5u / 2u; h.budget_hi = (uint32_t)c->num_cus * 7u / 2u; }
     HIP_TRY(hipMemcpy(c->gov, &h, sizeof h, hipMemcpyHostToDevice));
     return HR_OK;
 }
@@ -818,7 +842,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
     rp.ovf_cap = c->ovf_cap;
     rp.rr_start = c->rr_start;
-    rp.nee_cull_off = c->nee_cull ? 0u : 1u;
+    rp.nee_cull_off = ~c->nee_cull & 7u;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
         rp.sampling_begin = s_begin + done * stride;
@@ -844,7 +868,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         // waves than tiles
         const uint32_t kch = c->kchunk ? c->kchunk : TRACE_KCHUNK;
         const uint64_t units = (uint64_t)tiles * ((nk + kch - 1) / kch);   // work units of the trace kernel
-        uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(c->trace_grid ? c->trace_grid : (uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
+        rp.wg_budget = c->trace_budget;
         HIP_TRY(hipMemsetAsync(c->d_tile_counter + slot, 0, sizeof(uint32_t), c->stream));
         {
             dim3 g(grid), b(64 * TRACE_WAVES);
@@ -1141,17 +1166,22 @@ int hr_comm_info(hr_ctx *c, hr_comm_info_t *out) {
 }
 
 // Sum of an accumulator in f64, per channel, on the device: sum_of(rank's own accumulators) == sum(all-reduced total) is the checksum of
-// the exchange (bench.py multi_gpu.checksum).  One pass, 1,024 workgroups, f64 atomics on three words.
+// the exchange (bench.py multi_gpu.checksum).  Deterministic: a fixed grid, every workgroup leaves its partial sums (waves in order), the
+// host adds the 1,024 partial sums in order — two contexts that hold the same total report the same sum to the last bit.
+static const unsigned ACC_SUM_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void accumulator_sum_kernel(const float *__restrict__ a, size_t pixels, double *__restrict__ out) {
     double s[3] = {0.0, 0.0, 0.0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (size_t)gridDim.x * blockDim.x) {
         s[0] += (double)a[i * 3]; s[1] += (double)a[i * 3 + 1]; s[2] += (double)a[i * 3 + 2];
     }
+    __shared__ double part[4][3];
     for (int k = 0; k < 3; k++) {
         double x = s[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        if ((threadIdx.x & 63u) == 0u) atomicAdd(out + k, x);
+        if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6][k] = x;
     }
+    __syncthreads();
+    if (threadIdx.x < 3) out[blockIdx.x * 3 + threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
 int hr_accumulator_sum(hr_ctx *c, int which, double out_rgb[3]) {
     if (!c || !out_rgb || which < 0 || which > 1) return fail(HR_ERR_INVALID, "hr_accumulator_sum: bad argument (which: 0 = this context's own accumulator, 1 = the all-reduced total)");
@@ -1160,16 +1190,16 @@ int hr_accumulator_sum(hr_ctx *c, int which, double out_rgb[3]) {
     int rc = hr_synchronize(c);
     if (rc) return rc;
     double *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 3 * sizeof(double)));
-    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(double), c->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(accumulator_sum_kernel, dim3(1024), dim3(256), 0, c->stream, which ? c->accum_total : c->accum, (size_t)c->W * c->H, d);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, d, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    std::vector<double> h(ACC_SUM_BLOCKS * 3);
+    HIP_TRY(hipMalloc((void **)&d, h.size() * sizeof(double)));
+    hipLaunchKernelGGL(accumulator_sum_kernel, dim3(ACC_SUM_BLOCKS), dim3(256), 0, c->stream, which ? c->accum_total : c->accum, (size_t)c->W * c->H, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_accumulator_sum: %s", hipGetErrorString(e));
+    out_rgb[0] = out_rgb[1] = out_rgb[2] = 0.0;
+    for (unsigned b = 0; b < ACC_SUM_BLOCKS; b++) for (int k = 0; k < 3; k++) out_rgb[k] += h[b * 3 + k];
     return HR_OK;
 }
 
@@ -1194,6 +1224,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
         HIP_TRY(hipMemcpyAsync(&g, c->gov, sizeof g, hipMemcpyDeviceToHost, c->stream));   // on the context's own stream: a null-stream copy could serialise against other contexts' launches
         HIP_TRY(hipStreamSynchronize(c->stream));
         out->governor_level = (uint64_t)(g.level < 0 ? 0 : g.level); out->governor_decisions = g.decisions; out->governor_moves = g.moves;
+        out->governor_budget = g.budget; out->governor_budget_moves = g.budget_moves;
     }
     out->shade_calls = h.shade_calls; out->shade_lanes = h.shade_lanes; out->box_passes = h.box_passes; out->box_lanes = h.box_lanes;
     out->leaf_calls = h.leaf_calls; out->leaf_lanes = h.leaf_lanes; out->outer_iters = h.outer_iters;
@@ -1286,6 +1317,8 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         c->node_unroll = (uint32_t)value;
         return HR_OK;
     }
+    if (k == "trace_grid") { c->trace_grid = (uint32_t)value; return HR_OK; }
+    if (k == "trace_budget") { c->trace_budget = (uint32_t)value; return HR_OK; }
     if (k == "trace_wgs") {
         if (value < 1 || value > 8) return fail(HR_ERR_INVALID, "trace_wgs must be in [1,8]");
         c->trace_wgs = (uint32_t)value;
@@ -1323,7 +1356,7 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
-    if (k == "nee_cull") { c->nee_cull = value != 0.0; return HR_OK; }
+    if (k == "nee_cull") { c->nee_cull = (uint32_t)value & 7u; return HR_OK; }
     return fail(HR_ERR_INVALID, "unknown debug option '%s'", key);
 }
 
@@ -1395,7 +1428,7 @@ int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
     rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
     rp.adv_den = c->adv_den; rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll; rp.kchunk = c->kchunk;
     rp.pad[0] = c->seed_prio;
-    rp.nee_cull_off = c->nee_cull ? 0u : 1u;
+    rp.nee_cull_off = ~c->nee_cull & 7u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, tiles))) return rc;
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u))) return rc;

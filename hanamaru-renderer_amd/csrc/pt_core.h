@@ -599,7 +599,6 @@ struct Path {
     float cur_refl;       // reflectance of the sampled bounce (PointMaterial::sample's scalar)
     V3f view, n; float param, roughness;
     float shadow_len;     // |sample point - shadow origin|
-    float own_r;          // radius of the sphere the shaded point lies on, 0 = not a sphere (nee_setup's third shortcut)
     float r0, r1;
 };
 static const uint32_t PATH_IDLE = 0xffffffffu;
@@ -651,7 +650,7 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
 
 // scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter path_emitter(p).
 // Returns false when the ray need not be traced at all, because its contribution is known to be exactly zero (round 5; `cull` = 0
-// switches the three shortcuts off: debug option nee_cull 0, the A/B and the bit-equality test; bit 0 = (1) and (3), bit 1 = (2) — the
+// switches the three shortcuts off: debug option nee_cull 0, the A/B and the bit-equality test; bit 0 = (1), bit 1 = (2), bit 2 = (3) — the
 // logging instantiation keeps (2) off, because the log records the visibility verdict of renderer.rs:280 also where the BSDF is zero):
 //   (1) the sample point lies on the FAR side of the emitter.  sample_on_surface draws uniformly over the whole sphere (scene.rs:92-101), so
 //       for more than half of the samples the shadow ray runs through the emitter itself before it reaches the sample: the closest hit of
@@ -685,12 +684,10 @@ HD bool nee_setup(const Scene &sc, Path &p, uint32_t cull) {
     if (cull) {
         const float slack = 0.0221f + 1e-6f * len;
         const float x = ro * dot(sn, d);
-        const bool far_side = x > slack && x * x > 2.0f * (2.0f * em.r * OFFSET_F + OFFSET_F * OFFSET_F) && len > 2.0f * x;   // (len > 2 x: the origin lies in front of the entry point, which is at most 2 x before the sample)
+        const bool far_side = (cull & 1u) && x > slack && x * x > 2.0f * (2.0f * em.r * OFFSET_F + OFFSET_F * OFFSET_F) && len > 2.0f * x;   // (len > 2 x: the origin lies in front of the entry point, which is at most 2 x before the sample)
         const float nd = dot(p.n, d);
         const bool ggx_below = (cull & 2u) && path_surface(p) == 3 && signbit(nd);
-        const float rs = p.own_r + OFFSET_F, xo = -rs * nd;
-        const bool own_sphere = p.own_r > 0.0f && xo * xo > 2.0f * (2.0f * p.own_r * OFFSET_F + OFFSET_F * OFFSET_F) && xo > 0.0f && len - xo > slack;
-        if (far_side || ggx_below || own_sphere) return false;
+        if (far_side || ggx_below) return false;
     }
     p.shadow_len = len;
     ray_set(p.ray, p.next_o, d);
@@ -778,7 +775,6 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         p.refl = p.refl * m.albedo;                       // renderer.rs:183,295 (NEE scale) and the first factor of :197
         if (!(nee_available(m.surface) && sc.num_emitters > 0)) goto bounce;
         p.n = s.n; p.param = m.param; p.roughness = m.roughness;
-        p.own_r = p.ts.type == 1 ? sc.spheres[p.ts.prim].w : 0.0f;
         p.st = (p.st & 15u) | ((uint32_t)m.surface << 5);   // emitter 0; the phase bit is set by nee_setup
     } else {
         // renderer.rs:280-292.  Hit point and sample point lie on the same ray: |hit - sample| = |t - shadow_len|
@@ -806,7 +802,7 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
     // the next emitter whose shadow ray has to be traced (renderer.rs:274: `for emission in emissions`, in order); the ones nee_setup
     // culls are rays the reference traces and discards — they count as rays of the path in the log, not in the kernel's counters
     for (; path_emitter(p) < sc.num_emitters; p.st += 256u) {
-        if (nee_setup(sc, p, rp.nee_cull_off ? 0u : (LOG ? 1u : 3u))) return false;
+        if (nee_setup(sc, p, (LOG ? 5u : 7u) & ~rp.nee_cull_off)) return false;
         if (CNT) cn->shadow_culled++;
         if (LOG) lg->rays++;
     }

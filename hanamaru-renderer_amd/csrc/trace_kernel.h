@@ -119,6 +119,13 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uin
 // The same kernel, the same path_advance: what is logged is what hr_render computes.
 template <bool CNT, int MINW, bool QN, bool RR = false, bool LOG = false>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter, uint32_t *plog = nullptr) {
+    // the wave budget (device_scene.h GovDev::budget; debug option trace_budget pins it): surplus workgroups leave before they touch anything
+    {
+        uint32_t budget = rp.wg_budget;
+        if (!budget && rp.gov) budget = __hip_atomic_load(&rp.gov->budget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rp.gov && blockIdx.x == 0 && threadIdx.x == 0) rp.gov->bud[rp.gov_slot] = budget;
+        if (budget && blockIdx.x >= budget) return;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     LaneCounters lc = {0, 0, 0, 0, 0, 0};

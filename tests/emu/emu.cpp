@@ -326,8 +326,8 @@ int emu_raw_draws_seg(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t
     return 0;
 }
 
-// nee_setup's shortcuts (pt_core.h): 1 = on (the kernel's default), 0 = every NEE shadow ray is traced
-static int g_nee_cull = 1;
+// nee_setup's shortcuts (pt_core.h): mask of the ones in force (7 = all: the kernel's default), 0 = every NEE shadow ray is traced
+static int g_nee_cull = 7;
 void emu_set_nee_cull(int on) { g_nee_cull = on; }
 
 // counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, shadow_culled
@@ -337,7 +337,7 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
     sc.qnodes = nullptr;   // the emulated render walks the 32-byte records (node indices): every ray's walk starts at 0
     RenderParams rp{};
     rp.width = W; rp.height = H;
-    rp.nee_cull_off = g_nee_cull ? 0u : 1u;
+    rp.nee_cull_off = ~(uint32_t)g_nee_cull & 7u;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     std::vector<std::vector<uint64_t>> cn(nthreads, std::vector<uint64_t>(7, 0));
     for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
@@ -385,7 +385,7 @@ int emu_path_log(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, 
     sc.qnodes = nullptr;
     RenderParams rp{};
     rp.width = W; rp.height = H;
-    rp.nee_cull_off = g_nee_cull ? 0u : 1u;
+    rp.nee_cull_off = ~(uint32_t)g_nee_cull & 7u;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     std::atomic<uint32_t> next{0};
     auto work = [&]() {

@@ -97,7 +97,7 @@ def set_walk_mode(mode):
 def set_nee_cull(on):
     """nee_setup's shortcuts (pt_core.h): shadow rays known to add nothing are not traced (default on)."""
     lib().emu_set_nee_cull.argtypes = [C.c_int]
-    lib().emu_set_nee_cull(1 if on else 0)
+    lib().emu_set_nee_cull(7 if on is True else int(on))
 
 
 def last_node_tests():

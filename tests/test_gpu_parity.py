@@ -1019,7 +1019,7 @@ def test_bench_gpus_n_without_a_launcher(tmp_path):
     assert "spp-sharded x2" in par and ("RCCL group all-reduce" in par if torch.cuda.device_count() >= 2 else "FALLBACK" in par), par
     # the bench line's roofline: frac IS SURVEY 8(d)'s figure, the loaded bytes can not exceed that booking, and the traversal-only workload is there
     r = j1["roofline"]
-    assert r["bound"] == "l1_ta_issue" and r["bound_contract"] == "hbm" and r["pair_bound"] == "seed_seg_kernel" and r["peak"] == 8000.0
+    assert r["bound"] == "l1_ta_issue" and r["bound_contract"] == "hbm" and r["pair_bound"] in ("seed_seg_kernel", "trace_kernel") and r["peak"] == 8000.0   # (pair_bound: the slower kernel of THIS run — at 160x90 either)
     assert 0 < r["frac"] == r["frac_survey_8d"] and 0 < r["loaded_bytes"]["frac"] <= r["frac"] and "frac_alone" not in r
     assert abs(r["achieved"] * 1e9 * r["avg_launch_ms"] * 1e-3 - r["algorithmic_bytes_per_launch"]) <= 2e-3 * r["algorithmic_bytes_per_launch"]
     assert 0 < r["l2"]["frac"] < 1 and 0 < r["l2"]["frac_alone"] < 1 and r["hbm_normalised_alone"] > 0   # (at 160x90 "alone" is not reliably the faster one)
