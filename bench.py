@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samplings per kernel launch (0 = the library's automatic choice: 4 at 1080p)")
     ap.add_argument("--scene", default="rtcamp6_v3_1")
     ap.add_argument("--max-leaf", type=int, default=0)
-    ap.add_argument("--bvh-builder", type=int, default=0, help="0 = host SAH (default), 1 = device LBVH, 2 = device PLOC")
+    ap.add_argument("--bvh-builder", type=int, default=-1, help="-1 = by scene size (library default: host SAH below 200,000 primitives), 0 = host SAH, 1 = device LBVH, 2 = device PLOC")
     ap.add_argument("--split-ratio", type=float, default=None, help="early split clipping: -1 automatic (library default), 0 off, > 0 ratio")
     ap.add_argument("--trace-boost", type=int, default=-2, help="-1 = governed (library default), 0 .. 5 = fixed level")
     ap.add_argument("--max-tail-gib", type=float, default=0.0)
@@ -189,7 +189,7 @@ def main():
         r = ha.Renderer(d)
         if args.max_leaf:
             r.set_option("max_leaf", args.max_leaf)
-        if args.bvh_builder:
+        if args.bvh_builder >= 0:
             r.set_option("bvh_builder", args.bvh_builder)
         if args.quant_nodes >= 0:
             r.set_option("quant_nodes", args.quant_nodes)
@@ -442,7 +442,7 @@ def main():
         paths_per_launch = st["paths"] / launches if st["paths"] else W * H * 4 * min(args.batch or 4, SPS)
         quant = args.quant_nodes != 0
         node_b = 16 if quant else 32
-        builder = {0: "host-sah", 1: "device-lbvh", 2: "device-ploc"}.get(args.bvh_builder, "?")
+        builder = {0: "host-sah", 1: "device-lbvh", 2: "device-ploc"}.get(int(st["bvh_builder_used"]), "?")
         # `bound`: what the PMC passes say limits the kernel (the CUs' L1 tag lookups / texture-addresser issue and lane divergence — the
         # tree is L2-resident, physical HBM traffic is ~6 % of peak); `bound_contract` / `peak`: BASELINE's metric prices the traversal
         # against the HBM peak, and that normalisation is what `achieved` / `frac` are (SURVEY.md 8(d)'s byte booking).

@@ -108,7 +108,8 @@ struct hr_ctx {
     bool quant_nodes = true;                 // trace kernel walks the 16-byte quantised nodes (host-built trees; next upload)
     int max_leaf = 4;                        // BVH leaf size (next upload)
     double split_ratio = -1.0;               // early split clipping: -1 = automatic (kept when it cuts the SAH cost by more than 7 %), 0 = off, > 0 = ratio
-    int bvh_builder = 0;                     // 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH, 2 = device PLOC (gpu_bvh.h); next upload
+    int bvh_builder = -1;                    // -1 = by scene size (default: host SAH below AUTO_BUILDER_PRIMS primitives, device PLOC from there on), 0 = host binned SAH (bvh_build.cpp), 1 = device LBVH, 2 = device PLOC (gpu_bvh.h); next upload
+    int builder_in_use = 0;                  // what the last hr_upload_scene built with (0 | 1 | 2)
     double bvh_build_ms = 0;                 // device builder: key + sort + hierarchy + fit + emit + gather kernels
     uint64_t max_tail_bytes = 20ull << 30;   // cap of each hand-off buffer
     int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
@@ -133,10 +134,10 @@ struct hr_ctx {
 #include <map>
 #include <mutex>
 static std::mutex g_bound_mu;
-static std::map<const void *, const hr_ctx *> g_bound;
+static std::map<const void *, std::pair<const hr_ctx *, size_t>> g_bound;   // buffer -> (context, bytes)
 static void unbind_accumulator(hr_ctx *c) {
     std::lock_guard<std::mutex> lk(g_bound_mu);
-    for (auto it = g_bound.begin(); it != g_bound.end();) it = it->second == c ? g_bound.erase(it) : std::next(it);
+    for (auto it = g_bound.begin(); it != g_bound.end();) it = it->second.first == c ? g_bound.erase(it) : std::next(it);
 }
 static void free_scene(hr_ctx *c) {
     for (void *p : c->scene_allocs) (void)hipFree(p);
@@ -197,7 +198,10 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
         // 256 CUs; trace / seed ms per launch): all 1,536 workgroups 19.4 / 25.3, 896 20.6 / 24.7, 768 22.0 / 24.4, 704 23.3 / 24.3,
         // 640 24.5 / 24.3 — the seed kernel gains what the trace kernel's waves no longer take, +3.5 % on the pair at 704 - 768.
         const uint32_t B = g->bud[slot];
-        if (ov_seed > 0.7f && beside && L == (int)g->lvl[1][slot] && L >= 0 && L < GOV_LEVELS) {
+        // (a trace kernel far shorter than the seed kernel — the sphere scenes: 6 ms against 24 — never covers 70 % of a seed kernel, but that it
+        // has workgroups to spare is beyond doubt: it is judged for the budget when it ran beside the next launch's seed kernel itself)
+        const bool spare = trace_t < 0.7f * seed_t && ov_trace > 0.7f;
+        if ((ov_seed > 0.7f || spare) && beside && L == (int)g->lvl[1][slot] && L >= 0 && L < GOV_LEVELS) {
             g->decisions++;
             bool budget_moved = false;
             if (L == 0 && g->level == 0 && B == g->budget && g->budget_step) {
@@ -253,16 +257,18 @@ static void invalidate_totals(hr_ctx *c) {
 }
 static int drain_events(hr_ctx *c) {
     auto sum = [](std::vector<EventPair> &ev, double &acc) -> hipError_t {
+        // a pair whose query fails is dropped with the rest (left in the list it would fail every later drain, i.e. every later API call)
+        hipError_t first = hipSuccess;
         for (auto &e : ev) {
             float ms = 0;
             hipError_t r = hipEventElapsedTime(&ms, e.a, e.b);
-            if (r != hipSuccess) return r;
-            acc += ms;
+            if (r == hipSuccess) acc += ms;
+            else if (first == hipSuccess) first = r;
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
         }
         ev.clear();
-        return hipSuccess;
+        return first;
     };
     HIP_TRY(sum(c->seed_events, c->seed_ms));
     HIP_TRY(sum(c->trace_events, c->trace_ms));
@@ -466,7 +472,9 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
         if (se == hipSuccess) se = hipStreamSynchronize(c->stream);
         if (se != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "device split clipping: %s", hipGetErrorString(se)); }
         const uint64_t refs = (uint64_t)last[0] + last[1];
-        if (refs > nt && refs < MAX_PRIMS_PER_TYPE) {
+        // (bounded together with the spheres and cuboids: the builder's n = refs + spheres + cuboids indexes its sort keys and INFO_COUNT with
+        // 24 bits; beyond that the split references are dropped and the triangles go in as they are)
+        if (refs > nt && refs + p.num_spheres + p.num_cuboids < MAX_PRIMS_PER_TYPE) {
             LBVH_ALLOC(ref_tri, uint32_t, refs, false)
             LBVH_ALLOC(ref_box, float, 6 * refs, false)
             split_emit_kernel<<<(nt + 127) / 128, 128, 0, c->stream>>>(tris_in, nt, sp, split_offsets, ref_tri, ref_box);
@@ -475,6 +483,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     }
     const int n = (int)(p.num_tris + p.num_spheres + p.num_cuboids);
     p.index_bits = key_index_bits_for((uint64_t)n);
+    if (n <= 0 || (uint64_t)n >= (1ull << p.index_bits)) { cleanup(); return fail(HR_ERR_UNSUPPORTED, "device BVH build: %d primitives do not fit the %d index bits of the sort keys", n, p.index_bits); }
     const int N = 2 * n - 1;
     LBVH_ALLOC(keys_in, mkey_t, n, false)
     LBVH_ALLOC(keys, mkey_t, n, false)
@@ -503,7 +512,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     if (e != hipSuccess) { cleanup(); return fail(HR_ERR_DEVICE, "hipcub sort (size query): %s", hipGetErrorString(e)); }
     LBVH_ALLOC(sort_tmp, unsigned char, sort_bytes, false)
     // multi-workgroup PLOC: packed role counters, their scan, the two-slot iteration state
-    const bool ploc_multi = c->bvh_builder == 2 && n > 1;
+    const bool ploc_multi = c->builder_in_use == 2 && n > 1;
     size_t scan_bytes = 0;
     if (ploc_multi) {
         e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (u64t *)nullptr, (u64t *)nullptr, n, c->stream);
@@ -529,7 +538,7 @@ static int build_bvh_on_device(hr_ctx *c, const HostScene &hs, const Tri *tris_i
     }
     if (e == hipSuccess) {
         leaf_kernel<<<(n + T - 1) / T, T, 0, st>>>(p, keys, n, w);
-        if (n > 1 && c->bvh_builder == 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
+        if (n > 1 && c->builder_in_use == 1) hierarchy_kernel<<<(n - 1 + T - 1) / T, T, 0, st>>>(keys, n, w);
         if (ploc_multi) {
             ploc_init_kernel<<<(n + T - 1) / T, T, 0, st>>>(n, cl_a, ploc_state);
             uint32_t *cur = cl_a, *nxt = cl_b;
@@ -611,7 +620,18 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
 
     HostScene hs;
     std::string ferr;
-    const bool gpu_build = c->bvh_builder != 0;
+    // Which builder: the host's binned-SAH build with split clipping gives the best tree (1 - 3 % fewer node tests than the device PLOC
+    // build) but is one thread — 12 k triangles take 20 ms, 10^6 six seconds, 4 x 10^6 twenty-five — while the device builds 4 x 10^6 in
+    // 38 ms.  By default the scene's size decides: below AUTO_BUILDER_PRIMS primitives (host build < 1 s) the host tree, above it PLOC.
+    static const uint64_t AUTO_BUILDER_PRIMS = 200000;
+    int builder = c->bvh_builder;
+    if (builder < 0) {
+        uint64_t prims = 0;
+        for (uint32_t e = 0; e < sd->num_elements; e++) prims += sd->elements[e].kind == HR_MESH ? sd->elements[e].num_faces : 1;
+        builder = prims >= AUTO_BUILDER_PRIMS ? 2 : 0;
+    }
+    c->builder_in_use = builder;
+    const bool gpu_build = builder != 0;
     rc = flatten_scene(sd, hs, ferr, c->max_leaf, gpu_build ? 0.0 : c->split_ratio, !gpu_build);
     if (rc) return fail(rc, "hr_upload_scene: %s", ferr.c_str());   // a description that is refused leaves the scene in place
     free_scene(c);
@@ -691,13 +711,21 @@ int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
-    if (device_rgb) {
+    {
+        // look-up, release of this context's old binding and the new entry under ONE lock: two threads binding one buffer to two contexts
+        // cannot both pass.  The registry holds byte ranges: a buffer that overlaps another context's is refused like an equal one.
+        // (The caller binds NULL before it frees a bound buffer: an entry left behind would refuse whoever is handed the address next.)
         std::lock_guard<std::mutex> lk(g_bound_mu);
-        auto it = g_bound.find(device_rgb);
-        if (it != g_bound.end() && it->second != c) return fail(HR_ERR_INVALID, "hr_bind_accumulator: this buffer is already bound to another context (one context per accumulator: the launch's radiance is added with plain loads and stores)");
+        const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
+        if (device_rgb)
+            for (const auto &kv : g_bound) {
+                const char *a = (const char *)kv.first, *b = (const char *)device_rgb;
+                if (kv.second.first != c && a < b + bytes && b < a + kv.second.second)
+                    return fail(HR_ERR_INVALID, "hr_bind_accumulator: this buffer is already bound to another context (one context per accumulator: the launch's radiance is added with plain loads and stores)");
+            }
+        for (auto it = g_bound.begin(); it != g_bound.end();) it = it->second.first == c ? g_bound.erase(it) : std::next(it);
+        if (device_rgb) g_bound[device_rgb] = std::make_pair((const hr_ctx *)c, bytes);
     }
-    unbind_accumulator(c);
-    if (device_rgb) { std::lock_guard<std::mutex> lk(g_bound_mu); g_bound[device_rgb] = c; }
     c->accum = device_rgb ? device_rgb : c->accum_own;
     invalidate_totals(c);
     return HR_OK;
@@ -1217,7 +1245,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->sphere_tests = h.sphere_tests; out->cuboid_tests = h.cuboid_tests; out->rng_overflow = h.rng_overflow; out->shadow_culled = h.shadow_culled;
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
-    out->bvh_build_ms = c->bvh_build_ms;
+    out->bvh_build_ms = c->bvh_build_ms; out->bvh_builder_used = (uint64_t)c->builder_in_use;
     out->debug_kernel_ms = c->debug_ms; out->debug_launches = c->debug_launches;
     {
         GovDev g;
@@ -1265,7 +1293,7 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "bvh_builder") {  // takes effect at the next hr_upload_scene
-        if (value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "bvh_builder must be 0 (host SAH), 1 (device LBVH) or 2 (device PLOC)");
+        if (value != -1 && value != 0 && value != 1 && value != 2) return fail(HR_ERR_INVALID, "bvh_builder must be -1 (by scene size), 0 (host SAH), 1 (device LBVH) or 2 (device PLOC)");
         c->bvh_builder = (int)value;
         return HR_OK;
     }
@@ -1494,8 +1522,7 @@ int hr_debug_trace(hr_ctx *c, uint32_t n, const float *rays, const float *shadow
         rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll;
         // the record format hr_render walks on this scene; timed with HIP events (hr_stats.debug_kernel_ms), counted with option "counters"
         EventPair ev{nullptr, nullptr};
-        (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);
-        (void)hipEventRecord(ev.a, c->stream);
+        bool timed = hipEventCreate(&ev.a) == hipSuccess && hipEventCreate(&ev.b) == hipSuccess && hipEventRecord(ev.a, c->stream) == hipSuccess;
         const dim3 g((n + 63) / 64), b(64);
         if (c->counters) {
             if (c->dsc.qnodes) hipLaunchKernelGGL((trace_debug_kernel<true, true>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el, c->d_counters);
@@ -1503,16 +1530,16 @@ int hr_debug_trace(hr_ctx *c, uint32_t n, const float *rays, const float *shadow
         } else if (c->dsc.qnodes) hipLaunchKernelGGL((trace_debug_kernel<true>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
         else hipLaunchKernelGGL((trace_debug_kernel<false>), g, b, 0, c->stream, c->dsc, rp, n, d_rays, d_sl, d_out, d_el);
         e = hipGetLastError();
-        (void)hipEventRecord(ev.b, c->stream);
-        c->debug_events.push_back(ev);
-        c->debug_launches++;
+        timed = timed && e == hipSuccess && hipEventRecord(ev.b, c->stream) == hipSuccess;
+        if (timed) { c->debug_events.push_back(ev); c->debug_launches++; }   // only a pair that was really recorded is ever queried
+        else { if (ev.a) (void)hipEventDestroy(ev.a); if (ev.b) (void)hipEventDestroy(ev.b); }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 8 * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_element, d_el, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(d_el); (void)hipFree(d_sl);
     if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_trace: %s", hipGetErrorString(e));
-    return HR_OK;
+    return drain_events(c);
 }
 
 }  // extern "C"

@@ -721,6 +721,13 @@ HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
 //         sphere of the same material, or the neighbouring triangle with another normal, is another branch)
 //   rays: scene.intersect calls of the path (main + shadow rays)
 //   ev9 bits 8-15: how many of the path's main rays hit a SPHERE (the one primitive that multiplies a position error by 1 / radius)
+// Round 5 — every discrete decision of a main ray is in the log: besides the elements and triangles, `hash` takes the FACE of a cuboid hit
+// (scene.rs:160-182's cascade: another face is another normal) and the cube-map FACE of the sky lookup that ends a path (scene.rs:295-319:
+// every face is a texture of its own, clamped at its border — a flip at a seam is a jump); and ev9 bits 16-31 carry a 16-bit sum over the
+// TEXEL QUADS (integer corner x1, y1 of texture.rs:29-49) of every image the main rays sampled — surface textures and the sky.  Bilinear
+// interpolation is continuous across quad borders, so another quad is NOT another branch: paths are "same" by events + hash, and the quad sum
+// says how many of them interpolated between other texels (tests/path_parity.py `other_texel_quad`).  All of it is computed by LOG-only helpers
+// beside the production code (plog_sky, plog_quad, cuboid_face_of), from the same fp32 values.
 struct PathLog { unsigned long long ev; uint32_t ev9, hash, rays; };
 HD void plog_reset(PathLog &l) { l.ev = 0ull; l.ev9 = 0u; l.hash = 0x811c9dc5u; l.rays = 0u; }
 HD void plog_or(PathLog &l, uint32_t iter, uint32_t bits) {
@@ -728,6 +735,36 @@ HD void plog_or(PathLog &l, uint32_t iter, uint32_t bits) {
     else l.ev9 |= bits;
 }
 HD void plog_hit(PathLog &l, int32_t elem) { l.hash = (l.hash ^ (uint32_t)(elem + 1)) * 0x01000193u; }
+HD uint32_t quad_hash16(uint32_t ix, uint32_t iy) { return ((ix * 0x9E3779B1u) ^ (iy * 0x85EBCA77u)) >> 16; }
+HD void plog_quad_add(PathLog &l, uint32_t ix, uint32_t iy) { l.ev9 = (l.ev9 & 0xffffu) | ((((l.ev9 >> 16) + quad_hash16(ix, iy)) & 0xffffu) << 16); }
+// the corner (x1, y1) sample_bilinear() starts from (texture.rs:30-33), from the same fp32 products
+HD void plog_quad(const Scene &sc, PathLog &l, int32_t image, float u, float v) {
+    if (image < 0) return;
+    const ImageRef im = sc.images[image];
+    plog_quad_add(l, f32_as_u32_sat(floorf(u * (float)im.width)), f32_as_u32_sat(floorf(v * (float)im.height)));
+}
+// face and corner of sky_sample()'s lookup: the same comparisons and quotients (scene.rs:295-319)
+HD void plog_sky(const Scene &sc, PathLog &l, V3f d) {
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float u, v;
+    if (ax > ay && ax > az) {
+        float i = HR_RCP(d.x);
+        if (!signbit(d.x)) { face = 0; u = -d.z * i; v = d.y * i; } else { face = 1; u = -d.z * i; v = -d.y * i; }
+    } else if (ay > ax && ay > az) {
+        float i = HR_RCP(d.y);
+        if (!signbit(d.y)) { face = 2; u = d.x * i; v = -d.z * i; } else { face = 3; u = -d.x * i; v = -d.z * i; }
+    } else {
+        float i = HR_RCP(d.z);
+        if (!signbit(d.z)) { face = 4; u = d.x * i; v = d.y * i; } else { face = 5; u = d.x * i; v = -d.y * i; }
+    }
+    u = 0.5f * (u + 1.0f); v = 0.5f * (v + 1.0f);
+    plog_hit(l, 0x2000 + face);
+    uint32_t w = sc.sky_w, h = sc.sky_h;
+    if (!sc.sky_quads) { const ImageRef im = sc.images[sc.sky_image[face]]; w = im.width; h = im.height; }
+    plog_quad_add(l, f32_as_u32_sat(floorf(u * (float)w)), f32_as_u32_sat(floorf(v * (float)h)));
+}
+// which face of scene.rs:160-182's cascade a cuboid hit took, from the normal hit_surface() chose
+HD int32_t cuboid_face_of(V3f n) { return n.y > 0.0f ? 0 : n.y < 0.0f ? 1 : n.x < 0.0f ? 2 : n.x > 0.0f ? 3 : n.z < 0.0f ? 4 : n.z > 0.0f ? 5 : 6; }
 
 // returns true when the path is finished (accum final)
 // RR / rr_start: Russian roulette from that iteration on (off = the reference's estimator: renderer.rs:174-200 has none).  A template
@@ -753,7 +790,7 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         const f2v r01 = *reinterpret_cast<const f2v *>(recs + rec_slot(path_draw_base(p), ((p.q >> 12) & 15u) + 2u * path_iter(p)));   // renderer.rs:175
         p.r0 = r01[0]; p.r1 = r01[1];
         if (!hit) {  // scene.rs:398 + renderer.rs:196,199
-            if (LOG) plog_or(*lg, path_iter(p), 1u);
+            if (LOG) { plog_or(*lg, path_iter(p), 1u); plog_sky(sc, *lg, p.ray.d); }
             p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
             return true;
         }
@@ -769,6 +806,11 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         p.view = -p.ray.d;
         bool transmitted;
         const bool sampled = bsdf_sample(m, p.r0, p.r1, s.pos, p.view, s.n, p.next_o, p.next_d, p.cur_refl, transmitted);
+        if (LOG) {
+            if (p.ts.type == 2) plog_hit(*lg, 0x1000 + cuboid_face_of(s.n));
+            const Material mt = sc.materials[s.elem];
+            plog_quad(sc, *lg, mt.albedo_img, s.u, s.v); plog_quad(sc, *lg, mt.emission_img, s.u, s.v); plog_quad(sc, *lg, mt.roughness_img, s.u, s.v);
+        }
         if (LOG) { plog_hit(*lg, s.elem); if (p.ts.type == 1) lg->ev9 += 256u; if (p.ts.type == 0) plog_hit(*lg, (int32_t)(sc.tri_face[p.ts.prim] + 0x9e3779b9u)); plog_or(*lg, path_iter(p), sampled ? (2u + (uint32_t)m.surface) | (transmitted ? 8u : 0u) : 7u); }
         if (!sampled) return true;  // renderer.rs:190-193
         p.accum = p.accum + p.refl * m.emission;          // renderer.rs:196

@@ -1,7 +1,7 @@
 // hanamaru-hip — host driver with the reference binary's flag surface and outputs (main.rs:1226-1295,
 // renderer.rs:205-251): `hanamaru-hip -w W -h H -s S -t SEC -i SEC`.  Stand-in for the Rust host (no Rust
 // toolchain here): scene authoring + PNG writing stay on the host, the render loop calls the C ABI.
-// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N, --gpus N / --gpu-ids LIST,
+// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N, --inflight K, --gpus N / --gpu-ids LIST,
 // --checkpoint FILE (write the fp32 accumulator + sampling count when the render stops) and --resume FILE
 // (continue from such a file: samplings are independent and seeded by index, so a resumed render adds exactly
 // the samplings that are missing — SURVEY.md §8f rank 3; the reference has no resumable state).
@@ -48,7 +48,8 @@ static void usage(const char *prog) {
            "        --scene NAME    rtcamp6_v3_1 (default) | rtcamp6_v3 | rtcamp6_v2 | rtcamp6_v1 | rtcamp5 | tbf3 | material_examples | simple |\n"
            "                        spheres | rtcamp6_dodeca | cornell_mini\n"
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
-           "        --batch N       samplings per progress report (default 32; the library launches 4 at a time)\n"
+           "        --batch N       samplings per progress report (default 1: one \"rendering:\" line per sampling, as the reference)\n"
+           "        --inflight K    reports' worth of work enqueued ahead on the GPU (default 8; 1 = wait for every report before the next starts)\n"
            "        --gpus N        render on devices 0..N-1 of this node from this one process: device r takes every N-th sampling,\n"
            "                        the accumulators are summed with one RCCL all-reduce when an image is written (default 1)\n"
            "        --gpu-ids LIST  the same with an explicit comma-separated device list\n"
@@ -62,7 +63,8 @@ int main(int argc, char **argv) {
     double time_limit = 123.0, interval = 15.0;              // main.rs:1255-1256
     std::string scene_name = "rtcamp6_v3_1", assets, ckpt_out, ckpt_in, gpu_ids;
     int gpus = 1;
-    int batch = 32;  // samplings between two report_progress calls; one host sync (pipeline drain) per report
+    int batch = 1;      // samplings per report_progress call ("rendering:" line); 1 = the reference's cadence
+    int inflight = 8;   // chunks enqueued ahead of the one being reported
     bool debug = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -80,6 +82,7 @@ int main(int argc, char **argv) {
         else if (a == "--scene") scene_name = val("scene");
         else if (a == "--assets") assets = val("assets");
         else if (a == "--batch") batch = atoi(val("batch"));
+        else if (a == "--inflight") inflight = atoi(val("inflight"));
         else if (a == "--gpus") gpus = atoi(val("gpus"));
         else if (a == "--gpu-ids") gpu_ids = val("gpu-ids");
         else if (a == "--checkpoint") ckpt_out = val("checkpoint");
@@ -87,6 +90,7 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "Unrecognized option: '%s'.\n", a.c_str()); return 1; }
     }
     if (batch < 1) { fprintf(stderr, "--batch must be at least 1.\n"); return 1; }
+    if (inflight < 1) { fprintf(stderr, "--inflight must be at least 1.\n"); return 1; }
     if (width == 0 || height == 0) { fprintf(stderr, "width and height must be positive.\n"); return 1; }
     if (gpus < 1) { fprintf(stderr, "--gpus must be at least 1.\n"); return 1; }
     if (assets.empty()) {
@@ -195,29 +199,46 @@ int main(int argc, char **argv) {
         sampled = 1;
         sampling = 0;
     }
-    // Renderer::render's loop with report_progress (renderer.rs:32-43, 205-251) at chunk granularity: a chunk = `--batch` samplings
-    // (--batch 1: the reference's cadence, one "rendering:" line per sampling).  One chunk stays in flight while the host reports on the
-    // previous one (hr_mark / hr_wait), so the GPU never drains between progress lines.  What follows from that, and is the ONE deviation
-    // from renderer.rs:205-251: the time-limit prediction (renderer.rs:222-231: stop when used + 1.1 x last > limit) is made BEFORE a chunk
-    // is issued, i.e. it looks two chunks ahead (used + 2.2 x last) — the render stops one chunk earlier rather than one chunk late.
-    // A progress image (renderer.rs:243-251) holds exactly the samplings of the "rendering:" line before it, as in the reference: when one
-    // is due the chunk in flight is awaited and reported first, the image is written, and the pipeline starts again (one drain per image).
+    // Renderer::render's loop with report_progress (renderer.rs:32-43, 205-251).  A chunk = `--batch` samplings = one "rendering:" line;
+    // the default, --batch 1, is the reference's own cadence: one line per sampling.  What is reported and what is launched are two
+    // things: up to `--inflight` chunks are enqueued ahead (hr_render only enqueues; hr_mark behind every chunk, hr_wait for the oldest),
+    // so the GPU never drains between progress lines.  report_progress's three rules keep their order and their meaning:
+    //   * time limit (renderer.rs:222-231: stop when used + 1.1 x last > limit).  The reference asks this after a sampling, before it
+    //     starts the next; here the question is asked when a chunk is ISSUED, for the moment that chunk would finish: it is issued only
+    //     if used + 1.1 x last x (chunks in flight + 1) <= limit.  With one chunk in flight at a time (-i 0, or --inflight 1) that is the
+    //     reference's rule to the letter; with k in flight it looks k chunks ahead — the render stops at the same sampling the
+    //     reference's prediction would have stopped at had `last` not changed meanwhile, never later.  When the chunks in flight have
+    //     been reported and none may follow, the final image is written: "reached time limit" if the rule says so, else "reached max
+    //     sampling" (in that order, renderer.rs:222-241).
+    //   * progress image (renderer.rs:243-251): when the interval has passed at a report, the chunks in flight are awaited and reported
+    //     first, so that the image holds exactly the samplings of the "rendering:" line before it, as in the reference (one pipeline
+    //     drain per image).  An interval of 0 asks for an image after every report: the loop then keeps one chunk in flight, and
+    //     `-s 5 -i 0` prints and writes exactly what the reference does — 000.png .. 003.png after samplings 1 .. 4, final 004.png.
     struct Chunk { uint32_t begin, end; std::vector<uint64_t> ticket; };
-    auto issue = [&](uint32_t s, Chunk &c) -> int {
-        c.begin = s;
-        c.end = s + (uint32_t)batch;
+    std::vector<Chunk> q;     // issued, not yet reported; oldest first
+    uint32_t next_s = first;
+    auto issue = [&]() -> int {
+        Chunk c;
+        c.begin = next_s;
+        c.end = next_s + (uint32_t)batch;
         if (c.end > sampling + 1) c.end = sampling + 1;
         c.ticket.assign(ndev, 0);
-        for (uint32_t r = 0; r < ndev; r++)
-            if (hr_render(ctxs[r], c.begin + r, c.end, ndev) != 0 || hr_mark(ctxs[r], &c.ticket[r]) != 0) { fprintf(stderr, "hr_render: %s\n", hr_last_error()); return 1; }
+        for (uint32_t r = 0; r < ndev; r++) {
+            // device r of N renders the samplings with (s - 1) mod N == r, whatever the chunk's first sampling is — a chunk
+            // shorter than N leaves some devices without work, their marker is then reached at once
+            const uint32_t b = c.begin + (r + ndev - (c.begin - 1u) % ndev) % ndev;
+            if (hr_render(ctxs[r], b, c.end, ndev) != 0 || hr_mark(ctxs[r], &c.ticket[r]) != 0) { fprintf(stderr, "hr_render: %s\n", hr_last_error()); return 1; }
+        }
+        next_s = c.end;
+        q.push_back(c);
         return 0;
     };
-    Chunk cur{}, nxt{};
-    bool have_cur = false, have_next = false;
-    double chunk_sec = 0.0;   // duration of the last completed chunk (0 = not known yet)
+    double chunk_sec = 0.0;   // `from_last_sampling_sec` of the last report (0 = nothing reported yet)
     double used = 0.0;
-    // wait for a chunk and print its line (renderer.rs:206-214)
-    auto report = [&](const Chunk &c) -> int {
+    // wait for the oldest chunk in flight and print its line (renderer.rs:206-214)
+    auto report = [&]() -> int {
+        const Chunk c = q.front();
+        q.erase(q.begin());
         for (uint32_t r = 0; r < ndev; r++)
             if (hr_wait(ctxs[r], c.ticket[r]) != 0) { fprintf(stderr, "hr_wait: %s\n", hr_last_error()); return 1; }
         sampled = c.end - 1;
@@ -237,35 +258,37 @@ int main(int argc, char **argv) {
         printf("remain: %.3f sec.\n", time_limit - used);
         return save(sampled);
     };
-    if (first <= sampling) { if (issue(first, cur)) return 1; have_cur = true; }
-    else if (!debug && sampled > 0) {   // resumed from a checkpoint that already holds every requested sampling: just resolve it
+    // may another chunk be enqueued?  (samplings left, room in the pipeline, and the time-limit rule asked for the moment it would finish)
+    const size_t depth = interval <= 0.0 ? 1 : (size_t)inflight;
+    auto may_issue = [&]() -> bool {
+        if (next_s > sampling || q.size() >= depth) return false;
+        if (chunk_sec <= 0.0) return true;   // nothing measured yet: fill the pipeline
+        return (now_sec() - begin) + 1.1 * chunk_sec * (double)(q.size() + 1) <= time_limit;
+    };
+    if (first > sampling && !debug && sampled > 0) {   // resumed from a checkpoint that already holds every requested sampling: just resolve it
         printf("reached max sampling\n");
         if (save(sampled)) return 1;
     }
-    while (have_cur) {
-        // keep the next chunk in flight unless the samplings run out or the time limit is in sight
-        if (!have_next && cur.end <= sampling && (now_sec() - begin) + chunk_sec * 2.2 <= time_limit) { if (issue(cur.end, nxt)) return 1; have_next = true; }
-        if (report(cur)) return 1;
-        if (!have_next) {   // nothing in flight: the render ends here
-            if (finish(sampled >= sampling ? "reached max sampling" : "reached time limit")) return 1;
+    bool running = first <= sampling;
+    while (running) {
+        while (may_issue()) if (issue()) return 1;
+        if (q.empty()) {   // nothing in flight and nothing may follow: the render ends here (renderer.rs:222-241, the time limit asked first)
+            // (samplings left over: only the time-limit rule can have refused them)
+            if (finish(next_s <= sampling || used + 1.1 * chunk_sec > time_limit ? "reached time limit" : "reached max sampling")) return 1;
             break;
         }
-        if (now_sec() - last_image >= interval) {   // renderer.rs:243-251
-            if (report(nxt)) return 1;              // the chunk in flight: the image then holds exactly the samplings reported
-            have_next = false;
-            // nothing is in flight now: the reference's own rules apply as they stand (renderer.rs:222-241)
-            if (used + chunk_sec * 1.1 > time_limit) { if (finish("reached time limit")) return 1; break; }
+        if (report()) return 1;
+        if (last_progress - last_image >= interval) {   // renderer.rs:243-251, with the `now` of the report
+            while (!q.empty()) if (report()) return 1;   // the chunks in flight: the image then holds exactly the samplings reported
+            // nothing is in flight now: the reference's own rules apply as they stand, in their order (renderer.rs:222-241)
+            if (used + 1.1 * chunk_sec > time_limit) { if (finish("reached time limit")) return 1; break; }
             if (sampled >= sampling) { if (finish("reached max sampling")) return 1; break; }
             for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
             printf("output progress image: %03u.png\n", counter);
             if (save(sampled)) return 1;
             counter++;
             last_image = last_progress;             // `now` of the report that triggered it (renderer.rs:250)
-            if (issue(sampled + 1, cur)) return 1;
-            continue;
         }
-        cur = nxt;
-        have_next = false;
     }
     for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
     if (!ckpt_out.empty()) {

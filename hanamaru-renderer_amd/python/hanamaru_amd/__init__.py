@@ -89,7 +89,7 @@ class Stats(C.Structure):
                 ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
                 ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8),
                 ("debug_kernel_ms", C.c_double), ("debug_launches", C.c_uint64),
-                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64), ("shadow_culled", C.c_uint64), ("governor_budget", C.c_uint64), ("governor_budget_moves", C.c_uint64)]
+                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64), ("shadow_culled", C.c_uint64), ("governor_budget", C.c_uint64), ("governor_budget_moves", C.c_uint64), ("bvh_builder_used", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}
@@ -400,12 +400,12 @@ class Renderer:
         return out
 
     def debug_path_log(self, sampling):
-        """hr_debug_path_log: (radiance [H, W, 4, 3] float32, rays [H, W, 4] uint32, events [H, W, 4, 10] uint8 — nine event bytes + the count of sphere hits —, hash [H, W, 4] uint32) of every
+        """hr_debug_path_log: (radiance [H, W, 4, 3] float32, rays [H, W, 4] uint32, events [H, W, 4, 12] uint8 — nine event bytes, the count of sphere hits, the 16-bit texel-quad sum —, hash [H, W, 4] uint32) of every
         path of one sampling, from the render kernel's logging instantiation."""
         raw = np.zeros((self.height, self.width, 4, 8), dtype=np.uint32)
         self._check(self.L.hr_debug_path_log(self._h, sampling, raw.ctypes.data))
         rad = raw[..., 0:3].copy().view(np.float32)
-        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(self.height, self.width, 4, 12)[..., :10]
+        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(self.height, self.width, 4, 12)[..., :12]
         return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
 
     def debug_intersect(self, rays):

@@ -134,6 +134,7 @@ typedef struct hr_stats {
     /* the governor's wave budget: how many of the trace kernel's persistent workgroups stay (0 = all of them) — fewer where the trace
      * kernel is the faster kernel of the pair and its surplus waves only slow the seed kernel beside it —, and how often it changed */
     uint64_t governor_budget, governor_budget_moves;
+    uint64_t bvh_builder_used;  /* the builder the last hr_upload_scene used (0 host SAH, 1 device LBVH, 2 device PLOC): what option bvh_builder = -1 chose */
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;
@@ -241,7 +242,9 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
  *   next hr_upload_scene:
- *   "bvh_builder"   0 = host binned-SAH build (default), 1 = LBVH, 2 = PLOC built on the device — replaces bvh.rs:107-211
+ *   "bvh_builder"   -1 = by scene size (default): the host's binned-SAH build below 200,000 primitives (the best tree; one host thread,
+ *                   < 1 s), the device PLOC build from there on (0.97 - 0.99 of that tree's quality; 4 x 10^6 triangles in 38 ms instead of
+ *                   25 s); 0 = host build, 1 = LBVH, 2 = PLOC on the device — replaces bvh.rs:107-211 (hr_stats.bvh_builder_used)
  *   "max_leaf"      BVH leaf size, 1..15 (default 4)
  *   "split_ratio"   early split clipping of long thin triangles in the host builder: -1 = automatic (kept when it cuts the SAH
  *                   cost by more than 7 %, default), 0 = off, > 0 = always, with that box / triangle area ratio

@@ -73,14 +73,14 @@ class OracleScene:
             pass
 
     def path_log(self, w, h, sampling, threads=0):
-        """Every path of one sampling: (radiance [h, w, 4, 3] float64, rays [h, w, 4] uint32, events [h, w, 4, 10] uint8 (nine event bytes + the count of sphere hits), element hash [h, w, 4]
+        """Every path of one sampling: (radiance [h, w, 4, 3] float64, rays [h, w, 4] uint32, events [h, w, 4, 12] uint8 (nine event bytes, the count of sphere hits, the 16-bit texel-quad sum), element hash [h, w, 4]
         uint32) — the oracle's side of hr_debug_path_log (same event encoding, oracle.cpp PathLog)."""
         rad = np.zeros((h, w, 4, 3), dtype=np.float64)
         words = np.zeros((h, w, 4, 5), dtype=np.uint32)
         rc = lib().orc_path_log(self._h, w, h, sampling, threads, rad.ctypes.data, words.ctypes.data)
         if rc != 0:
             raise RuntimeError("orc_path_log failed: %d" % rc)
-        ev = np.ascontiguousarray(words[..., 1:4]).view(np.uint8).reshape(h, w, 4, 12)[..., :10]
+        ev = np.ascontiguousarray(words[..., 1:4]).view(np.uint8).reshape(h, w, 4, 12)[..., :12]
         return rad, words[..., 0].copy(), ev.copy(), words[..., 4].copy()
 
     def render(self, w, h, s_begin, s_end, stride=1, threads=0, acc=None, counters=False):

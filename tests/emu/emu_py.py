@@ -62,11 +62,11 @@ class EmuScene:
         return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests", "shadow_culled"], list(cn)))
 
     def path_log(self, w, h, sampling, threads=0):
-        """(radiance [h, w, 4, 3] float32, rays, events [h, w, 4, 10] uint8 (nine event bytes + the count of sphere hits), element hash) — the layout of Renderer.debug_path_log"""
+        """(radiance [h, w, 4, 3] float32, rays, events [h, w, 4, 12] uint8 (nine event bytes, the count of sphere hits, the 16-bit texel-quad sum), element hash) — the layout of Renderer.debug_path_log"""
         raw = np.zeros((h, w, 4, 8), dtype=np.uint32)
         lib().emu_path_log(self._h, w, h, sampling, threads, raw.ctypes.data)
         rad = raw[..., 0:3].copy().view(np.float32)
-        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(h, w, 4, 12)[..., :10]
+        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(h, w, 4, 12)[..., :12]
         return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
 
     def render_debug(self, w, h, mode):

@@ -2,8 +2,10 @@
 emulation of the same per-lane code) with the oracle's (orc_path_log), path by path.
 
 A path is SAME when its event log (one byte per iteration: miss / surface type hit / sample returned None, reflected or transmitted, NEE
-visibility mask) and the hash of the element indices it hit equal the oracle's — it took the reference's branches; everything else is
-DIVERGENT and is classified by the first iteration whose event byte differs.  Helper module: imported by tests and tools/parity_report.py."""
+visibility mask) and the hash of its discrete geometric decisions (the element and mesh triangle of every hit, the face of a cuboid hit, the
+cube-map face of the sky lookup that ends it) equal the oracle's — it took the reference's branches; everything else is DIVERGENT and is
+classified by the first iteration whose event byte differs (equal events, another hash: `other_element_same_events` — another element,
+triangle, cuboid face or sky face).  The texel quads of the image lookups are logged too (a 16-bit sum) and reported, not gated.  Helper module: imported by tests and tools/parity_report.py."""
 import numpy as np
 
 SURFACES = ["diffuse", "specular", "refraction", "ggx", "ggx_refraction"]
@@ -36,8 +38,9 @@ def account(gpu, ref, floor=1.0):
     ro, rayso, evo, ho = ref
     n = raysg.size
     rg = rg.reshape(n, 3).astype(np.float64); ro = ro.reshape(n, 3).astype(np.float64)
-    evg = evg.reshape(n, 10); evo = evo.reshape(n, 10)    # nine event bytes + the count of sphere hits (equal wherever the events and the hash are)
+    evg = evg.reshape(n, 12); evo = evo.reshape(n, 12)    # nine event bytes, the count of sphere hits (equal wherever the events and the hash are), the texel-quad sum
     sph = evo[:, 9].astype(np.int64)
+    quad_same = (evg[:, 10:12] == evo[:, 10:12]).all(axis=1)
     evg = evg[:, :9]; evo = evo[:, :9]
     hg = hg.reshape(n); ho = ho.reshape(n)
     ev_same = (evg == evo).all(axis=1)
@@ -61,6 +64,11 @@ def account(gpu, ref, floor=1.0):
     # that hits it by 1 / radius (and by 1 / cos at grazing incidence) and hands it on as a direction error — the one amplifier fp32 rays meet
     over = same & (rel_path > 1e-3)
     out["same_branch"]["over_1e-3_by_sphere_bounces_ppm"] = {str(k): round(1e6 * float((over & (sph == k)).sum()) / n, 2) for k in sorted(set(sph[over].tolist()))}
+    # same branch, but a texture value interpolated between OTHER texels (a lookup that fell on the other side of a quad border: bilinear
+    # interpolation is continuous there, so this is not a branch — how many there are and what they cost is reported, not gated)
+    oq = same & ~quad_same
+    out["same_branch"]["other_texel_quad"] = {"ppm": round(1e6 * float(oq.sum()) / n, 2), "max_rel_floor1": float(rel_path[oq].max()) if oq.any() else 0.0,
+                                              "over_1e-3_floor1_ppm": round(1e6 * float((oq & (rel_path > 1e-3)).sum()) / n, 2)}
     flat = same & (sph == 0)
     out["same_branch"]["no_sphere_bounce"] = {"paths": int(flat.sum()), "max_rel_floor1": float(rel_path[flat].max()) if flat.any() else 0.0,
                                               "over_1e-3_floor1_ppm": round(1e6 * float((flat & (rel_path > 1e-3)).sum()) / n, 2)}
