@@ -95,14 +95,14 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def latest_pmc_traffic():
-    """profiles/rNN_pmc_traffic.json of the newest round (written by tools/prof_pmc.sh), or None."""
+def latest_pmc_traffic(scene="rtcamp6_v3_1"):
+    """profiles/rNN_pmc_traffic[_<scene>].json of the newest round for this scene (written by tools/prof_pmc.sh), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
     for f in reversed(files):
         try:
             j = json.load(open(f))
-            if "kernels" in j:
+            if "kernels" in j and j.get("scene", "rtcamp6_v3_1") == scene:
                 return j
         except (OSError, ValueError):
             pass
@@ -485,6 +485,10 @@ def main():
                 "node_tests_per_ray": round(counters["node_tests"] / max(1, counters["rays"]), 2),
                 "tri_tests_per_ray": round(counters["tri_tests"] / max(1, counters["rays"]), 2),
                 "rays_per_path": round(counters["rays"] / npaths, 3),
+                # scene.intersect calls of the reference that the kernel does not make: NEE shadow rays known to contribute exactly nothing before
+                # they are traced (sample on the emitter's far side; GGX with the emitter below the horizon) — bit-identical image (pt_core.h nee_setup)
+                "nee_shadow_rays_culled_per_path": round(counters["shadow_culled"] / npaths, 3),
+                "reference_rays_per_path": round((counters["rays"] + counters["shadow_culled"]) / npaths, 3),
                 "lanes_per_shade_call": round(counters["shade_lanes"] / max(1, counters["shade_calls"]), 1),
                 "lanes_per_box_pass": round(counters["box_lanes"] / max(1, counters["box_passes"]), 1),
                 "lanes_per_leaf_call": round(counters["leaf_lanes"] / max(1, counters["leaf_calls"]), 1),
@@ -526,8 +530,8 @@ def main():
                         "the *_normalised figures divide the same bytes (and SURVEY 8(d)'s) by the HBM peak for comparison with the render kernel's line and are NOT fractions of anything physical (they exceed 1)"}
         # HBM / fabric traffic and instruction counts are PMC measurements (separate rocprofv3 --pmc passes of this same command,
         # tools/prof_pmc.sh, which also writes the JSON read here); per launch like `achieved`
-        pmc = latest_pmc_traffic()
-        if pmc and (W, H, args.scene) == (1920, 1080, "rtcamp6_v3_1"):
+        pmc = latest_pmc_traffic(args.scene)
+        if pmc and (W, H) == (1920, 1080):
             stale = pmc.get("csrc_sha") != kernel_source_sha()
             tk = pmc["kernels"].get("trace_kernel", {})
             if "fetch_bytes_per_path" in tk:

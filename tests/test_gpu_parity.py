@@ -301,13 +301,22 @@ def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
 # The headline scene and the Cornell box have no same-branch path beyond 1e-3 at all (same_max); in the scenes full of r = 0.1 spheres the
 # same-branch tail is chain amplification (every sphere bounce multiplies the ray's fp32 position error by ~2 t / r), visible in the
 # report as "over_1e-3_by_sphere_bounces_ppm": nothing at zero or one bounce in the sphere-only scene.
+# Round 5: "same branch" now includes every discrete decision of a main ray (pt_core.h PathLog: the face of a cuboid hit and the cube-map face of
+# the sky lookup are in the hash — a sky-seam flip, filed as "same branch, off by 0.585" at 7680x4320 in round 4, is a DIVERGENT path now), and
+# every scene has a bound on its worst same-branch path: same_max = 2.5 x the worst path of samplings 1 .. 8 - 12 at this size
+# (tools/same_branch_tail.py, profiles/r05_same_branch_tail.txt: rtcamp6_v2 0.097, rtcamp5 0.077, spheres 0.031, tbf3 0.015, rtcamp6_v1 0.0009).
+# What such a path is: a chain of refractions / r = 0.1 mirror spheres hands the fp32 ray's rounding on, amplified, and the path ends with a sky
+# or texture lookup a few texels from the oracle's — on the same face and surface, hence continuous: the error is bounded by the local contrast
+# of the environment map (<= ~0.1 of a radiance of 1), where a divergent path is bounded by nothing.
 PATH_LIMITS = {
-    #                 w,   h,  divergent_ppm, over_ppm, flat_over_ppm, same_max (None = not bounded)
+    #                 w,   h,  divergent_ppm, over_ppm, flat_over_ppm, same_max
     "rtcamp6_v3_1": (320, 180, 60.0, 15.0, 10.0, 1e-3),
     "cornell_mini": (160, 100, 60.0, 0.0, 0.0, 1e-3),
-    "spheres": (256, 144, 60.0, 300.0, 0.0, 0.03),
-    "rtcamp6_v2": (192, 108, 900.0, 2400.0, 300.0, None),
-    "rtcamp5": (192, 108, 600.0, 800.0, 300.0, None),
+    "spheres": (256, 144, 60.0, 300.0, 0.0, 0.08),
+    "rtcamp6_v2": (192, 108, 900.0, 2400.0, 300.0, 0.25),
+    "rtcamp5": (192, 108, 600.0, 800.0, 300.0, 0.2),
+    "tbf3": (192, 108, 200.0, 600.0, 300.0, 0.04),
+    "rtcamp6_v1": (192, 108, 150.0, 10.0, 10.0, 2.5e-3),
 }
 
 
@@ -339,8 +348,9 @@ def test_per_path_parity_accounting(gpu, scenes, name):
     assert sb["rays_equal"]                                                    # (ii)
     assert a["divergent_ppm"] <= div_ppm, a                                    # (iii)
     assert sb["over_1e-3_floor1_ppm"] <= over_ppm and sb["no_sphere_bounce"]["over_1e-3_floor1_ppm"] <= flat_ppm, sb
-    if same_max is not None:
-        assert sb["max_rel_floor1"] <= same_max, sb
+    assert sb["max_rel_floor1"] <= same_max, sb
+    oq = sb["other_texel_quad"]
+    print("per-path %s: %.1f ppm of the same-branch paths interpolated a texture between other texels than the oracle (worst of them off by %.3g)" % (name, oq["ppm"], oq["max_rel_floor1"]))
     assert abs(a["mean_radiance"]["gpu"] - a["mean_radiance"]["oracle"]) <= 2e-3 * a["mean_radiance"]["oracle"]
     # (iv) the pixel gates derived instead of measured: a channel of an S-sampling accumulator can only be off by more than 1e-3 if one of
     # the pixel's 4 S paths is (divergent or a same-branch outlier); with p = that probability per path, at least (1 - p)^(4 S) of the

@@ -1,8 +1,5 @@
 #!/bin/bash
 cp hanamaru-renderer_amd/libhanamaru_hip.so /tmp/l.so
-for k in "trace_budget=0" "trace_budget=1536" "trace_budget=896" "trace_budget=768" "trace_budget=0" "trace_budget=1536"; do
-BENCH_ARGS="--scene rtcamp6_dodeca --width 3840 --height 2160 --spp-per-step 4 --debug $k" tools/ab/abn2.sh /tmp/l.so 2>&1 | head -1 | sed "s/^/dodeca4k $k /"
-done
-for sc in rtcamp5 tbf3 rtcamp6_dodeca; do for k in "trace_budget=0" "trace_budget=1536" "trace_budget=0" "trace_budget=1536"; do
-BENCH_ARGS="--scene $sc --debug $k" tools/ab/abn2.sh /tmp/l.so 2>&1 | head -1 | sed "s/^/$sc $k /"
+for sc in rtcamp6_v2 rtcamp6_v1; do for k in "" "--split-ratio 0" "--split-ratio 0.5" "--split-ratio 1" "--split-ratio 2" "--split-ratio 4" "--max-leaf 2" "--max-leaf 3" "--max-leaf 6" "--bvh-builder 2"; do
+BENCH_ARGS="--scene $sc $k" tools/ab/abn.sh /tmp/l.so 2>&1 | head -1 | sed "s/^/$sc $k /"
 done; done

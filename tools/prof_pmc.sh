@@ -2,13 +2,15 @@
 # PMC passes for the trace / seed kernels (run on the GPU box through gpurun).  Each pass is its own rocprofv3 run with --pmc
 # only (never combined with tracing options).  Writes $OUT/summary.txt and $OUT/pmc_traffic.json; copy the latter to
 # profiles/rNN_pmc_traffic.json — bench.py reads the newest one for roofline.traffic and roofline.issue.
-#   usage: tools/prof_pmc.sh [outdir] [round-tag]      e.g. tools/prof_pmc.sh gpurun_out/pmc_r02 r02
+#   usage: tools/prof_pmc.sh [outdir] [round-tag] [scene]      e.g. tools/prof_pmc.sh gpurun_out/pmc_r02 r02     (scene: default rtcamp6_v3_1;
+#   another scene's file goes to profiles/rNN_pmc_traffic_<scene>.json and is what bench.py --scene <scene> reads)
 set -u
 OUT=${1:-gpurun_out/pmc}
 TAG=${2:-r03}
+SCENE=${3:-rtcamp6_v3_1}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python bench.py --steps 1 --warmup 0 --spp-per-step 4 --no-counters --no-cpu-baseline ${BENCH_ARGS:-}"
+CMD="python bench.py --scene $SCENE --steps 1 --warmup 0 --spp-per-step 4 --no-counters --no-cpu-baseline ${BENCH_ARGS:-}"
 PASSES=${PASSES:-7}
 i=0
 for pass in \
@@ -24,9 +26,10 @@ for pass in \
   timeout 600 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pass$i" -o p -- $CMD > "$OUT/pass$i.log" 2>&1
   echo "pass $i rc=$?" >> "$OUT/status.log"
 done
-python3 - "$OUT" "$TAG" <<'PY'
+python3 - "$OUT" "$TAG" "$SCENE" <<'PY'
 import csv, glob, json, sys, collections
-out, tag = sys.argv[1], sys.argv[2]
+out, tag, scene = sys.argv[1], sys.argv[2], sys.argv[3]
+suffix = "" if scene == "rtcamp6_v3_1" else "_" + scene
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
@@ -63,8 +66,8 @@ with open(out + "/summary.txt", "w") as o:
         kernels[name] = e
 sys.path.insert(0, ".")
 from bench import kernel_source_sha
-json.dump({"paths_per_launch": PATHS, "kernels": kernels, "csrc_sha": kernel_source_sha(),
-           "source": "profiles/%s_pmc_summary.txt (tools/prof_pmc.sh: separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction; kernels run serialised under PMC)" % tag},
+json.dump({"paths_per_launch": PATHS, "scene": scene, "kernels": kernels, "csrc_sha": kernel_source_sha(),
+           "source": "profiles/%s_pmc_summary%s.txt (tools/prof_pmc.sh: separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction; kernels run serialised under PMC)" % (tag, suffix)},
           open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())
 print(open(out + "/pmc_traffic.json").read())
