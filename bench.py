@@ -49,6 +49,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (without this RCCL fails with `hipIpcGetMemHandle: invalid
+# argument`); exported by the image already — kept here for whoever launches bench.py from a bare environment.  Before HIP initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -477,6 +480,10 @@ def main():
                               "(test counts from the instrumented build of the same kernel on the same seeds) per launch / the kernel's mean launch duration (HIP events on "
                               "its stream), over the HBM3E peak.  It is the BASELINE-mandated normalisation, comparable across rounds and record layouts; it is NOT a "
                               "physical share of HBM bandwidth (the tree is L2-resident: see `traffic`, `l2`, `physical`), and with the chip to itself it passes 1",
+                "frac_across_rounds": "r04: 0.83 (4,354 B/path, every scene.intersect call of the reference traced, every trace workgroup kept).  r05 lowers the ratio twice while raising "
+                                      "Mpaths/s: NEE shadow rays known to add nothing are not traced (fewer tests = fewer algorithmic bytes per path: nee_shadow_rays_culled_per_path), and "
+                                      "where the trace kernel is the faster kernel of the pair the governor keeps part of its workgroups out (priority_governor.trace_workgroups), so the same "
+                                      "bytes take longer on purpose — the seed kernel beside it gains more than that (profiles/r05_bench_full_wave_budget_off.json.log: all workgroups kept)",
                 "algorithmic_bytes_per_path": round(sb, 1), "algorithmic_bytes_per_launch": int(sb * paths_per_launch),
                 "loaded_bytes": {"bytes_per_path": round(lb, 1), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "note": "the bytes the lanes really request for those tests with this build's records (%d B per node visit on the %s records, 48 B per triangle, "

@@ -97,6 +97,7 @@ int main(int argc, char **argv) {
         FILE *probe = fopen("assets/models/box.obj", "rb");
         if (probe) { fclose(probe); assets = "assets"; } else assets = ".";
     }
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);   // dmabuf IPC (RCCL on this driver), unless the caller says otherwise; before the HIP runtime starts
     g_log = fopen("result.txt", "w");
     double total_begin = now_sec();
     tee("num threads: %d.", 1);  // main.rs:1261 prints rayon's pool size; here: one host thread drives one GPU

@@ -25,7 +25,7 @@ pub enum ElementRef<'a> {
     Mesh { vertexes: &'a Vec<Vector3>, faces: Vec<[u64; 3]>, material: &'a Material },
 }
 
-const BATCH: u32 = 16; // samplings between two report_progress calls (one host sync each)
+const IN_FLIGHT: usize = 8; // samplings enqueued ahead of the one being reported (hr_render only enqueues: the GPU never drains between reports)
 
 pub struct HipRenderer {
     ctx: *mut HrCtx,
@@ -77,6 +77,15 @@ impl Flat {
 }
 
 impl HipRenderer {
+    fn used(&self) -> f64 { (time::now() - self.begin).num_milliseconds() as f64 * 0.001 }
+    fn since_last_report(&self) -> f64 { (time::now() - self.last_report_progress).num_milliseconds() as f64 * 0.001 }
+    fn image_due(&self) -> bool { (time::now() - self.last_report_image).num_milliseconds() as f64 * 0.001 >= self.report_interval_sec }
+    /// the "rendering:" line of renderer.rs:211-214 alone (for the samplings that are reported on the way to a progress image)
+    fn report_line(&mut self, sampling: u32) {
+        let (used, last) = (self.used(), self.since_last_report());
+        println!("rendering: {}x{} sampled (last {:.3} sec). total: {:.3} sec ({:.2} %).", sampling, config::SUPERSAMPLING * config::SUPERSAMPLING, last, used, used / self.time_limit_sec * 100.0);
+        self.last_report_progress = time::now();
+    }
     pub fn new(sampling: u32, time_limit_sec: f64, report_interval_sec: f64) -> HipRenderer {
         // the #[repr(C)] mirrors of hip_ffi.rs were generated for this ABI (their sizes are compile-time assertions there)
         assert_eq!(unsafe { hr_abi_version() }, HR_ABI_VERSION, "libhanamaru_hip.so and hip_ffi.rs disagree about the ABI version");
@@ -138,15 +147,36 @@ impl Renderer for HipRenderer {
         // main.rs:1216 always passes a BvhScene; the trait object needs `fn as_bvh_scene(&self) -> &BvhScene` (one line in scene.rs)
         self.upload(scene.as_bvh_scene(), camera);
         check(unsafe { hr_set_resolution(self.ctx, imgbuf.width(), imgbuf.height()) });
-        let mut s = 1;
-        while s <= self.sampling {
-            let e = (s + BATCH).min(self.sampling + 1);
-            check(unsafe { hr_render(self.ctx, s, e, 1) });
-            check(unsafe { hr_synchronize(self.ctx) });
-            if self.report_progress(&Vec::new(), e - 1, imgbuf) { return e - 1; }
-            s = e;
+        // renderer.rs:32-43 with the samplings pipelined: one sampling per report as in the reference, up to IN_FLIGHT of them enqueued
+        // ahead (hr_mark behind each, hr_wait for the oldest).  The three rules of report_progress keep their order; the time-limit rule
+        // (renderer.rs:222-231) is asked when a sampling is ISSUED, for the moment it would finish — exactly the reference's rule with one
+        // sampling in flight (report_interval_sec <= 0 keeps it at one: an image is due after every report).  A progress image holds
+        // exactly the samplings reported: the ones in flight are awaited and reported first.  (hanamaru-hip's cli_main.cpp is this loop,
+        // compiled and tested.)
+        let depth = if self.report_interval_sec <= 0.0 { 1 } else { IN_FLIGHT };
+        let mut tickets: std::collections::VecDeque<(u32, u64)> = std::collections::VecDeque::new();
+        let (mut next, mut done, mut last) = (1u32, 0u32, 0.0f64);
+        loop {
+            while next <= self.sampling && tickets.len() < depth && (last <= 0.0 || self.used() + 1.1 * last * (tickets.len() + 1) as f64 <= self.time_limit_sec) {
+                let mut t = 0u64;
+                check(unsafe { hr_render(self.ctx, next, next + 1, 1) });
+                check(unsafe { hr_mark(self.ctx, &mut t) });
+                tickets.push_back((next, t));
+                next += 1;
+            }
+            let (s, t) = match tickets.pop_front() { Some(x) => x, None => break };
+            check(unsafe { hr_wait(self.ctx, t) });
+            done = s;
+            let nothing_follows = tickets.is_empty() && (next > self.sampling || self.used() + 1.1 * self.since_last_report() > self.time_limit_sec);
+            let image_due = self.image_due();
+            if image_due && !nothing_follows {          // drain first: the image then holds exactly the samplings reported
+                self.report_line(done);
+                while let Some((s2, t2)) = tickets.pop_front() { check(unsafe { hr_wait(self.ctx, t2) }); done = s2; if !tickets.is_empty() { self.report_line(done); } }
+            }
+            last = self.since_last_report();
+            if self.report_progress(&Vec::new(), done, imgbuf) { return done; }   // prints the line, applies the three rules, writes images
         }
-        self.sampling
+        done
     }
 
     // renderer.rs:205-251 with update_imgbuf (renderer.rs:64-90) replaced by hr_resolve

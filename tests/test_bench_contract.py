@@ -49,3 +49,48 @@ def test_committed_rocprof_summary_agrees_with_the_line():
     assert abs(avg_ms - j["roofline"]["avg_launch_ms"]) <= 0.03 * avg_ms, (avg_ms, j["roofline"]["avg_launch_ms"])
     seed = [ln for ln in md.splitlines() if "seed_seg_kernel" in ln][0].split("|")
     assert abs(float(seed[4]) - j["roofline"]["seed_kernel_avg_ms"]) <= 0.03 * float(seed[4])
+
+
+def _latest_scene_line(scene):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_%s.json.log" % scene)))
+    assert files, "no committed bench line for %s" % scene
+    return [json.loads(ln) for ln in open(files[-1]) if ln.startswith("{")][-1], files[-1]
+
+
+def test_committed_lines_of_the_trace_bound_scenes():
+    """The scenes whose trace kernel is the slower kernel of the pair (or level with it) — rtcamp6_v2, rtcamp6_v1, tbf3 — are tracked like the
+    headline: a bench line with its roofline (re-derivable from its own counts), PMC traffic taken on these kernel sources for THAT scene, and a
+    rocprofv3 kernel-trace summary of the same command that agrees with the line's HIP-event durations.  These are the only lines on which
+    trace-kernel work shows (every BASELINE configuration runs at the seed kernel's pace)."""
+    for scene in ("rtcamp6_v2", "rtcamp6_v1", "tbf3"):
+        j, path = _latest_scene_line(scene)
+        assert j["unit"] == "Mpaths/s" and j["n_gpus"] == 1 and j["value"] > 0 and scene + " 1920x1080" in j["config"]["workload"]
+        r = j["roofline"]
+        assert r["kernel"] == "trace_kernel" and r["pair_bound"] in ("trace_kernel", "seed_seg_kernel") and r["bound_contract"] == "hbm"
+        slower = "trace_kernel" if r["avg_launch_ms"] > r["seed_kernel_avg_ms"] else "seed_seg_kernel"
+        assert r["pair_bound"] == slower, (scene, r["avg_launch_ms"], r["seed_kernel_avg_ms"])
+        per_path = r["rays_per_path"] * (32 * r["node_tests_per_ray"] + 36 * r["tri_tests_per_ray"])
+        assert per_path <= r["algorithmic_bytes_per_path"] <= per_path + 150, (scene, per_path, r["algorithmic_bytes_per_path"])   # + 16 / 24 B per sphere / cuboid test
+        achieved = r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+        assert abs(achieved - r["achieved"]) <= 2e-3 * achieved and abs(r["achieved"] / r["peak"] - r["frac"]) <= 1e-3
+        assert abs(r["reference_rays_per_path"] - r["rays_per_path"] - r["nee_shadow_rays_culled_per_path"]) <= 2e-3 and r["nee_shadow_rays_culled_per_path"] > 0
+        assert isinstance(r["traffic"], int) and r["traffic"] > 0 and r["traffic_stale"] is False and scene in r["traffic_source"]
+        assert 30 <= r["lanes_per_box_pass"] <= 64 and j["multi_gpu"]["exchange_verified"] is True
+        md = open(path.replace("_bench_%s.json.log" % scene, "_bench_%s_kernel_stats.md" % scene)).read()
+        row = [ln for ln in md.splitlines() if "trace_kernel<false, 5, true" in ln][0].split("|")
+        assert abs(float(row[4]) - r["avg_launch_ms"]) <= 0.03 * float(row[4]), (scene, row[4], r["avg_launch_ms"])
+        seed = [ln for ln in md.splitlines() if "seed_seg_kernel" in ln][0].split("|")
+        assert abs(float(seed[4]) - r["seed_kernel_avg_ms"]) <= 0.03 * float(seed[4])
+
+
+def test_committed_headline_line_proves_its_exchange_and_its_shortcuts():
+    """Round 5 fields of the headline line: the multi-GPU evidence (one rank: no communicator; checksum of the parts against the total), the
+    NEE shadow rays that were not traced, the wave budget the governor settled on, and which figures are replayed from profiles/."""
+    j, _ = _latest_line()
+    m = j["multi_gpu"]
+    assert m["rccl"]["nranks"] == 1 and m["rccl"]["path"] == "none" and m["exchange_verified"] is True and m["checksum"]["rel_err"] <= 1e-6
+    r = j["roofline"]
+    assert 0.3 < r["nee_shadow_rays_culled_per_path"] < 0.9 and 2.9 < r["reference_rays_per_path"] < 3.2      # SURVEY Appendix D: 3.05 scene.intersect calls per path
+    g = r["priority_governor"]
+    assert g["level"] == 0 and (g["trace_workgroups"] == "all" or 512 <= g["trace_workgroups"] <= 1024)
+    assert r["replayed_from_profiles"]["fields"] == ["traffic", "traffic_write", "physical", "issue"] and "schema" in r
