@@ -252,6 +252,7 @@ struct RenderParams {
     uint32_t rr_start;                // trace kernel: Russian roulette from this iteration on (0 = off, the default: the reference has none)
     uint32_t gov_slot;                // parity of the launch: which slot of gov-> its two kernels stamp
     uint32_t nee_cull_off;            // trace kernel: which of nee_setup's three shortcuts are switched OFF (bit 0 far side, 1 GGX below the horizon, 2 own sphere); 7 = trace every NEE shadow ray (debug option nee_cull: the A/B and the bit-equality test)
+    uint32_t tail_div;                // trace kernel: the last tiles / tail_div tiles of a launch are handed out one sampling at a time (0 = none): finer work units where the launch runs dry
     uint32_t wg_budget;               // trace kernel: workgroups with blockIdx.x >= wg_budget leave at once (0 = all stay) — debug option trace_budget
     GovDev *gov;                      // nullptr: no governor (debug kernels, host emulation) — trace_boost / pad[1] as given
 };

@@ -100,6 +100,7 @@ struct hr_ctx {
     uint32_t adv_den = 2, leaf_den = 2;      // trace-kernel phase thresholds
     int min_waves = 5;                       // occupancy variant of the trace kernel
     uint32_t trace_wgs = 6;                  // trace-kernel workgroups per CU in the grid (persistent waves)
+    uint32_t tail_div = 16;                  // debug: the last 1 / tail_div of a launch's tiles go out one sampling at a time (0 = off)
     uint32_t trace_grid = 0, trace_budget = 0;   // debug: absolute grid size (0 = trace_wgs per CU) / workgroups that stay (0 = all)
     uint32_t node_unroll = 2;                // box phase: node visits per pass of the loop
     uint32_t kchunk = 0;                     // samplings per work unit of the trace kernel (0 = 4)
@@ -871,6 +872,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     rp.ovf_cap = c->ovf_cap;
     rp.rr_start = c->rr_start;
     rp.nee_cull_off = ~c->nee_cull & 7u;
+    rp.tail_div = c->tail_div;
     for (uint32_t done = 0; done < total_k; done += batch) {
         uint32_t nk = std::min(batch, total_k - done);
         rp.sampling_begin = s_begin + done * stride;
@@ -1345,6 +1347,7 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         c->node_unroll = (uint32_t)value;
         return HR_OK;
     }
+    if (k == "tail_div") { c->tail_div = (uint32_t)value; return HR_OK; }
     if (k == "trace_grid") { c->trace_grid = (uint32_t)value; return HR_OK; }
     if (k == "trace_budget") { c->trace_budget = (uint32_t)value; return HR_OK; }
     if (k == "trace_wgs") {

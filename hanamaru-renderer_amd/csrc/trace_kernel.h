@@ -132,7 +132,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
     uint32_t npaths = 0;
     WaveStats ws = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     const uint32_t kchunk = rp.kchunk ? rp.kchunk : TRACE_KCHUNK;
-    const uint32_t nchunks = (rp.num_k + kchunk - 1u) / kchunk, units = tiles * nchunks;
+    const uint32_t nchunks = (rp.num_k + kchunk - 1u) / kchunk;
+    // the launch's last tiles go out one sampling at a time: with ~20 units of 256 paths per wave the waves finish up to a unit apart, and a
+    // long-path scene feels that tail; the bulk keeps the larger units (four samplings of a tile share their texels)
+    const uint32_t tail_tiles = rp.tail_div ? tiles / rp.tail_div : 0u, bulk_units = (tiles - tail_tiles) * nchunks, units = bulk_units + tail_tiles * rp.num_k;
     uint32_t total = 0, cur_k0 = 0;          // wave-uniform: paths in the current unit (slot q = (k - cur_k0) * 64 + j), its first sampling
     const size_t tile_stride = (size_t)rp.num_k * REC_ITEM_FLOATS;   // floats of hand-off records per tile
     uint32_t cur_tile = 0, next = 0;          // wave-uniform: the tile of the unit being handed out and its queue head
@@ -195,10 +198,16 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
                 if (lane == 0) t = atomicAdd(tile_counter, 1u);
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
                 if (t >= units) exhausted = true;
-                else {
+                else if (t < bulk_units) {
                     cur_tile = t / nchunks;
                     cur_k0 = (t - cur_tile * nchunks) * kchunk;
                     total = 64u * (rp.num_k - cur_k0 < kchunk ? rp.num_k - cur_k0 : kchunk);
+                    next = 0;
+                } else {
+                    const uint32_t u = t - bulk_units, tt = u / rp.num_k;
+                    cur_tile = tiles - tail_tiles + tt;
+                    cur_k0 = u - tt * rp.num_k;
+                    total = 64u;
                     next = 0;
                 }
             }

@@ -922,7 +922,7 @@ def test_nee_culls_do_not_change_a_bit(gpu, scenes):
             gpu.upload_scene(sc)
             gpu.set_resolution(w, h)
             out = {}
-            for cull in (1, 0):
+            for cull in (7, 0):       # the mask of shortcuts in force: 7 = all (default), 0 = every shadow ray traced
                 gpu.set_debug_option("nee_cull", cull)
                 gpu.set_option("counters", 1)
                 gpu.clear()
@@ -930,7 +930,7 @@ def test_nee_culls_do_not_change_a_bit(gpu, scenes):
                 st = gpu.stats()
                 gpu.set_option("counters", 0)
                 out[cull] = (gpu.read_accumulator().copy(), st, gpu.debug_path_log(1))
-            (a, sa, la), (b, sb, lb) = out[1], out[0]
+            (a, sa, la), (b, sb, lb) = out[7], out[0]
             assert a.sum() > 0 and np.array_equal(a, b), (name, np.abs(a - b).max())
             assert sb["shadow_culled"] == 0 and sa["shadow_culled"] > 0
             assert sa["rays"] + sa["shadow_culled"] == sb["rays"], (name, sa["rays"], sa["shadow_culled"], sb["rays"])
@@ -939,7 +939,7 @@ def test_nee_culls_do_not_change_a_bit(gpu, scenes):
             print("nee culls %s: %.3f of %.3f rays per path not traced (%.1f %% of the node tests)" %
                   (name, sa["shadow_culled"] / sa["paths"], sb["rays"] / sb["paths"], 100.0 * (1.0 - sa["node_tests"] / sb["node_tests"])))
     finally:
-        gpu.set_debug_option("nee_cull", 1)
+        gpu.set_debug_option("nee_cull", 7)
         gpu.set_option("counters", 0)
 
 
@@ -1007,6 +1007,51 @@ def test_priority_governor_decides_on_the_device(gpu, scenes):
             assert st["governor_level"] == level and st["governor_decisions"] == 0 and st["governor_moves"] == 0
     finally:
         gpu.set_option("trace_boost", -1)
+
+
+def test_wave_budget_governor(gpu, scenes):
+    """The governor's second control (round 5): where the trace kernel is the faster kernel of the pair by a margin, part of its persistent
+    workgroups leave at once (GovDev::budget) — the seed kernel beside it gains what their waves no longer take.  On the headline workload the
+    budget settles between 2.5 and 3.5 workgroups per CU within a few launches; on a trace-bound scene every workgroup stays and the priority
+    levels work as before; a fixed level pins the budget at "all"; and the accumulator does not depend on any of it (fixed summation order)."""
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(1920, 1080)
+    gpu.set_option("batch", 4)
+    try:
+        gpu.set_option("trace_boost", -1)
+        gpu.clear()
+        gpu.render(1, 97)                 # 24 launches in ONE call: the host never waits, everything is decided on the device
+        st = gpu.stats()
+        governed = gpu.read_accumulator().copy()
+        cus = 256
+        print("wave budget: headline settles at %d trace workgroups (%d moves, %d launches judged), level %d" % (st["governor_budget"], st["governor_budget_moves"], st["governor_decisions"], st["governor_level"]))
+        assert st["governor_level"] == 0 and st["governor_budget_moves"] >= 2 and st["governor_decisions"] >= 12
+        assert cus * 5 // 2 <= st["governor_budget"] <= cus * 7 // 2 and st["governor_budget"] % (cus // 4) == 0
+        gpu.set_option("trace_boost", 0)  # a fixed level: no budget
+        gpu.clear()
+        gpu.render(1, 97)
+        st0 = gpu.stats()
+        assert st0["governor_budget"] == 0 and st0["governor_budget_moves"] == 0
+        assert np.array_equal(governed, gpu.read_accumulator())
+        gpu.set_option("trace_boost", -1)
+        gpu.set_debug_option("trace_budget", 512)      # pinned from the host: same bits again
+        gpu.clear()
+        gpu.render(1, 97)
+        assert np.array_equal(governed, gpu.read_accumulator())
+        gpu.set_debug_option("trace_budget", 0)
+        # a scene whose trace kernel is the slower one keeps every workgroup
+        sc2, _ = scenes("rtcamp6_v2")
+        gpu.upload_scene(sc2)
+        gpu.clear()
+        gpu.render(1, 65)
+        st2 = gpu.stats()
+        print("wave budget: rtcamp6_v2 keeps %s workgroups, level %d" % ("all" if st2["governor_budget"] == 0 else st2["governor_budget"], st2["governor_level"]))
+        assert st2["governor_budget"] == 0 and st2["governor_level"] >= 2
+    finally:
+        gpu.set_option("trace_boost", -1)
+        gpu.set_debug_option("trace_budget", 0)
+        gpu.set_option("batch", 0)
 
 
 def _run_bench(extra, env=None, launcher_ranks=0, port=29541):

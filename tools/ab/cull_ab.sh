@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ab/cull_ab.sh [scenes...] : nee_setup's shortcuts on / off on one box (bit-identical images; the rate and the kernels' times differ)
-for sc in "${@:-rtcamp6_v3_1 rtcamp6_v2 rtcamp6_v1 tbf3}"; do for cull in 1 0 1 0; do
+for sc in "${@:-rtcamp6_v3_1 rtcamp6_v2 rtcamp6_v1 tbf3}"; do for cull in 7 0 7 0; do
   python bench.py --scene $sc --steps 12 --no-cpu-baseline --debug nee_cull=$cull 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
