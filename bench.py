@@ -166,7 +166,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # the contexts this process drives: (global rank, device)
     if launcher:
-        mine = [(rank, local_rank)]
+        # (a launcher that gives every rank its own device visibility — one visible GPU per process — leaves nothing but device 0 to choose)
+        mine = [(rank, local_rank if ndev > local_rank else 0)]
         how = "gloo on a host copy: HR_BENCH_ONE_DEVICE debugging aid" if one_device else "one process per GPU, ncclAllReduce (RCCL) inside libhanamaru_hip.so"
     elif world == 1:
         mine = [(0, 0)]
@@ -436,8 +437,12 @@ def main():
             if rccl["nranks"] != world or rccl["ranks_seen"] != list(range(world)):
                 failures.append("communicator reports %s ranks %s, --gpus %d" % (rccl["nranks"], rccl["ranks_seen"], world))
             have_devices = launcher or ndev >= world
-            if have_devices and (paths_seen not in (["rccl-rank"], ["rccl-group"]) or len(rccl["devices_seen"]) != world):
-                failures.append("the box has the devices, but the exchange did not run over RCCL on %d distinct devices (path %s, devices %s)" % (world, paths_seen, rccl["devices_seen"]))
+            if have_devices and paths_seen not in (["rccl-rank"], ["rccl-group"]):
+                failures.append("the box has the devices, but the exchange did not run over RCCL (path %s)" % paths_seen)
+            # distinct devices: ncclCommCuDevice answers with the process's own ordinal, so the check only means something where this process
+            # sees all of the job's devices (a launcher that restricts every rank to one visible GPU makes them all "device 0")
+            if ndev >= world and have_devices and len(rccl["devices_seen"]) != world:
+                failures.append("the exchange did not run on %d distinct devices (devices %s)" % (world, rccl["devices_seen"]))
         out["multi_gpu"]["exchange_verified"] = not failures
         launches = max(1, st["trace_launches"])
         avg_ms = st["trace_kernel_ms"] / launches

@@ -260,7 +260,9 @@ int main(int argc, char **argv) {
         return save(sampled);
     };
     // may another chunk be enqueued?  (samplings left, room in the pipeline, and the time-limit rule asked for the moment it would finish)
-    const size_t depth = interval <= 0.0 ? 1 : (size_t)inflight;
+    // (with N devices a chunk of one sampling is work for ONE of them: N times as many chunks are kept in flight, and an interval of 0 keeps
+    // one per device — the images then come after every N-th report; the reference has no multi-GPU form to be faithful to)
+    const size_t depth = (interval <= 0.0 ? 1 : (size_t)inflight) * (size_t)ndev;
     auto may_issue = [&]() -> bool {
         if (next_s > sampling || q.size() >= depth) return false;
         if (chunk_sec <= 0.0) return true;   // nothing measured yet: fill the pipeline
