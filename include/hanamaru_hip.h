@@ -237,8 +237,10 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *   "batch"         samplings per launch, 1..64; 0 = automatic (about 33 M paths per launch: 4 at 1080p, up to 64 for small images)
  *   "trace_boost"   -1 = the two kernels are balanced from their own time stamps, on the device, launch by launch (default): five
  *                   levels from "the seed kernel's producer waves above the trace kernel" (0) over "alternating" (1) and "equal" (2)
- *                   to "the trace kernel's box phase (3) and leaf phase (4) above the producer waves"; 0 .. 4 = fixed level
- *                   (hr_stats.governor_level says where it stands)
+ *                   to "the trace kernel's box phase (3) and leaf phase (4) above the producer waves" — and, where the trace kernel is
+ *                   the faster kernel of the pair by a margin, how many of its persistent workgroups stay (its surplus waves only slow
+ *                   the seed kernel beside it); 0 .. 4 = fixed level, every workgroup kept
+ *                   (hr_stats.governor_level / governor_budget say where it stands)
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
  *   next hr_upload_scene:
