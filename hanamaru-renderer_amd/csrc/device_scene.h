@@ -234,6 +234,15 @@ struct GovDev {
 };
 // the trace kernel's priority mask of a level (bits 0-3: which of every four box phases run at priority 1, bit 4: the leaf phase too)
 HD uint32_t gov_trace_mask(int32_t level) { return level >= 4 ? 0x1fu : level == 3 ? 0xfu : 0u; }
+// The wave budget's control law (governor_kernel; also compiled for the host: tests/test_host_layer.py drives it against the measured plant).
+// B = the budget a judged launch ran with (0 = every workgroup), ratio = its trace kernel's time / its seed kernel's time at level 0.  One step
+// down while the trace kernel has more than 12 % to spare, one step up when it comes within 3 % of the seed kernel, "all" above budget_hi.
+HD uint32_t gov_budget_next(uint32_t B, float ratio, uint32_t lo, uint32_t hi, uint32_t step) {
+    if (!step) return B;
+    if (ratio > 0.97f && B) return B + step > hi ? 0u : B + step;
+    if (ratio < 0.88f) return !B ? hi : (B >= lo + step ? B - step : B);
+    return B;
+}
 // the seed kernel's producer priorities of a level: bits 0-1 even groups, bits 2-3 odd groups
 HD uint32_t gov_producer_prio(int32_t level, uint32_t init_prio) { return level <= 0 ? (init_prio | init_prio << 2) : level == 1 ? init_prio : 0u; }
 

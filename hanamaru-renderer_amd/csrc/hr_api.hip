@@ -206,10 +206,7 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
             g->decisions++;
             bool budget_moved = false;
             if (L == 0 && g->level == 0 && B == g->budget && g->budget_step) {
-                const float ratio = trace_t / seed_t;
-                uint32_t nb = B;
-                if (ratio > 0.97f && B) nb = B + g->budget_step > g->budget_hi ? 0u : B + g->budget_step;
-                else if (ratio < 0.88f) nb = !B ? g->budget_hi : (B >= g->budget_lo + g->budget_step ? B - g->budget_step : B);
+                const uint32_t nb = gov_budget_next(B, trace_t / seed_t, g->budget_lo, g->budget_hi, g->budget_step);
                 if (nb != B) {
                     budget_moved = true;
                     g->budget_moves++;

@@ -442,6 +442,8 @@ int emu_render_debug(const emu_scene *e, uint32_t W, uint32_t H, int mode, float
 static int g_walk_mode = 0;
 static uint64_t g_node_tests = 0;
 void emu_set_walk_mode(int mode) { g_walk_mode = mode; }
+// the governor's wave-budget control law as the device compiles it (device_scene.h)
+uint32_t emu_gov_budget_next(uint32_t B, float ratio, uint32_t lo, uint32_t hi, uint32_t step) { return gov_budget_next(B, ratio, lo, hi, step); }
 uint64_t emu_last_node_tests(void) { return g_node_tests; }
 
 int emu_intersect(const emu_scene *e, uint32_t n, const float *rays, float *out, int32_t *out_elem) {

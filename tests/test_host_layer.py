@@ -182,3 +182,32 @@ def test_tbf3_scene_structure(ha, orc):
     assert d.num_elements == 36 and kinds.count(2) == 23 and kinds.count(0) == 12 and kinds.count(1) == 1   # logo + 22 diamonds, 4 + 8 spheres
     assert orc.OracleScene(sc.desc_ptr).num_emissions() == 4
     assert tuple(round(v, 6) for v in d.skybox.intensity.tuple()) == (2.0, 2.0, 3.0)
+
+
+def test_wave_budget_control_law_on_the_measured_plant(emu):
+    """The governor's second control (device_scene.h gov_budget_next, the function governor_kernel calls) driven on the CPU against the plant that was
+    measured on the headline workload (profiles/r05_ab_trace_grid_sweep.txt: trace / seed ms per launch by the number of trace workgroups kept): it
+    walks down from "all" to 768 workgroups in three steps and stays; started too low it climbs back; a trace-bound pair keeps every workgroup; and
+    when the plant changes under it (a heavier scene) it gives the workgroups back step by step."""
+    import ctypes as C
+    L = emu.lib()
+    L.emu_gov_budget_next.argtypes = [C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.emu_gov_budget_next.restype = C.c_uint32
+    lo, hi, step = 640, 896, 64
+    plant = {0: (19.4, 25.3), 896: (20.6, 24.71), 832: (21.3, 24.54), 768: (22.0, 24.38), 704: (23.3, 24.33), 640: (24.5, 24.27)}
+
+    def run(b, table, n=12):
+        seen = [b]
+        for _ in range(n):
+            t, s = table[b]
+            b = int(L.emu_gov_budget_next(b, t / s, lo, hi, step))
+            seen.append(b)
+        return seen
+    down = run(0, plant)
+    assert down[:4] == [0, 896, 832, 768] and set(down[3:]) == {768}
+    assert run(640, plant)[:3] == [640, 704, 704]                      # 640 is trace-bound (ratio 1.01): one step up, 704 holds (0.958)
+    heavy = {b: (t * 1.35, s) for b, (t, s) in plant.items()}          # a scene whose trace kernel needs a third more
+    assert set(run(0, heavy)) == {0}                                   # never leaves "all"
+    back = run(768, heavy)
+    assert back[:4] == [768, 832, 896, 0] and set(back[3:]) == {0}     # the plant changed under a settled budget: given back step by step
+    assert int(L.emu_gov_budget_next(704, 0.5, lo, hi, 0)) == 704      # a fixed level (step 0) pins the budget
