@@ -57,6 +57,7 @@ sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0  # same guide: aggregate L2 bandwidth
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; measured steady 2.39 GHz under this workload (profiles/r02_power_clocks.txt)
+L1_LANES_PER_CLOCK = 1.41  # tools/taprobe.hip: 64 lanes' 16-byte loads from distinct lines take a CU 45.5 cycles (profiles/r05_taprobe.txt)
 # ceiling of the seed kernel: 80 generator states per CU, each resident for one window of 11 init blocks
 # (~510 cycles each) plus 256 round steps whose serial chain is one dependent LDS gather (72 cycles) + four dependent issue
 # slots of a lone wave (~101 cycles per step) = 31.5 k cycles = 13.1 us at 2.4 GHz
@@ -559,16 +560,17 @@ def main():
             if phys:
                 phys["note"] = "what bounds the kernel physically (PMC, kernel alone on the chip): the L1's tag lookups — one cache line per clock per CU — and SIMD lane divergence, not bytes"
                 if "l1_line_accesses_per_path" in phys and avg_ms > 0:
-                    # The kernel's physical roofline.  tools/taprobe.hip (profiles/r05_taprobe.txt): a vector load costs the CU's L1 one cycle per ACTIVE
-                    # LANE whatever its width (8 or 16 bytes) and whatever the lanes' locality, unless 4 NEIGHBOURING lanes read one aligned 64-byte
-                    # block (floor: 16.5 cycles per instruction) — a traversal's lanes never do.  So the L1 serves 256 CUs x shader clock lane
-                    # accesses per second, and TCP_TOTAL_CACHE_ACCESSES counts what the kernel asks of it.
-                    peak = 256 * SHADER_CLOCK_HZ
+                    # The kernel's physical roofline.  tools/taprobe.hip (profiles/r05_taprobe.txt): a vector load costs the CU's L1 about 0.71 cycles per
+                    # ACTIVE LANE whatever its width (8 or 16 bytes) and whatever the lanes' locality (45.5 CU cycles per 64-lane load with the 16-byte
+                    # slots spread over their lines, as a tree's records are; floor 16.4 cycles per instruction), unless 4 NEIGHBOURING lanes read one
+                    # aligned 64-byte block — a traversal's lanes rarely do.  So the L1 serves 256 CUs x shader clock x 1.41 lane accesses per second (the
+                    # probe's own pointer chase: 864 - 890 G/s), and TCP_TOTAL_CACHE_ACCESSES counts what the kernel asks of it.
+                    peak = 256 * SHADER_CLOCK_HZ * L1_LANES_PER_CLOCK
                     acc = phys["l1_line_accesses_per_path"] * paths_per_launch
                     phys["l1_lookup"] = {"lane_accesses_per_launch": int(acc), "peak_per_s": peak, "unit": "L1 lane accesses/s",
                                          "achieved_per_s": round(acc / (avg_ms * 1e-3), 0), "frac": round(acc / (avg_ms * 1e-3) / peak, 4),
                                          "frac_alone": round(acc / (alone_ms * 1e-3) / peak, 4) if alone_ms else None,
-                                         "note": "one tag lookup per clock per CU (measured law: profiles/r05_taprobe.txt); frac = beside the seed kernel (which asks almost nothing of the L1 "
+                                         "note": "1.41 lane accesses per clock per CU (measured law: profiles/r05_taprobe.txt); frac = beside the seed kernel (which asks almost nothing of the L1 "
                                                  "but shares the SIMDs' issue slots), frac_alone = the same kernel with the chip to itself"}
                 roof["physical"] = phys
             # issue: wave-level instructions per path of BOTH kernels vs what the chip can issue (one instruction per wave per

@@ -76,6 +76,14 @@ def test_committed_lines_of_the_trace_bound_scenes():
         assert abs(r["reference_rays_per_path"] - r["rays_per_path"] - r["nee_shadow_rays_culled_per_path"]) <= 2e-3 and r["nee_shadow_rays_culled_per_path"] > 0
         assert isinstance(r["traffic"], int) and r["traffic"] > 0 and r["traffic_stale"] is False and scene in r["traffic_source"]
         assert 30 <= r["lanes_per_box_pass"] <= 64 and j["multi_gpu"]["exchange_verified"] is True
+        # the physical roofline: L1 lane accesses (PMC) against 1.41 per clock per CU (tools/taprobe.hip) — a fraction, also with the chip to itself
+        lk = r["physical"]["l1_lookup"]
+        assert abs(lk["peak_per_s"] - 256 * 2.4e9 * 1.41) < 1e6 and abs(lk["lane_accesses_per_launch"] / (r["avg_launch_ms"] * 1e-3) / lk["peak_per_s"] - lk["frac"]) <= 1e-3
+        assert 0.3 < lk["frac"] < lk["frac_alone"] < 1.0, (scene, lk)
+        # one load per node test, three per triangle test, counted per lane by the instrumented kernel: what the PMC pass counted is that figure to
+        # within 15 % (neighbouring lanes that sit on the same node merge; shading and the hand-off records add a little)
+        lanes = r["rays_per_path"] * (r["node_tests_per_ray"] + 3 * r["tri_tests_per_ray"])
+        assert 0.85 * lanes <= r["physical"]["l1_line_accesses_per_path"] <= 1.15 * lanes, (scene, lanes, r["physical"]["l1_line_accesses_per_path"])
         md = open(path.replace("_bench_%s.json.log" % scene, "_bench_%s_kernel_stats.md" % scene)).read()
         row = [ln for ln in md.splitlines() if "trace_kernel<false, 5, true" in ln][0].split("|")
         assert abs(float(row[4]) - r["avg_launch_ms"]) <= 0.03 * float(row[4]), (scene, row[4], r["avg_launch_ms"])

@@ -1,19 +1,25 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r05
+# SKIP_PMC=1: the bench lines, kernel statistics and parity lines only — when bench.py changed but the kernel sources did not (the PMC passes
+# under profiles/ stay valid: bench.py checks their sha of csrc/)
 TAG=${1:-r05}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if [ -z "$SKIP_PMC" ]; then
 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl\|libdrm" | tail -5 > $OUT/pytest_gpu.log
 # the PMC passes first: every bench line below reads its `traffic` from profiles/${TAG}_pmc_traffic[_scene].json and checks the kernel sources' hash against it
 tools/prof_pmc.sh $OUT/pmc $TAG > $OUT/pmc.log 2>&1
 cp $OUT/pmc/summary.txt $OUT/${TAG}_pmc_summary.txt; cp $OUT/pmc/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
 cp $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_traffic.json profiles/
+fi
 # the scenes whose trace kernel is the slower kernel of the pair (or level with it): their own PMC passes, bench line and kernel statistics
 for sc in rtcamp6_v2 rtcamp6_v1 tbf3; do
+  if [ -z "$SKIP_PMC" ]; then
   tools/prof_pmc.sh $OUT/pmc_$sc $TAG $sc > $OUT/pmc_$sc.log 2>&1
   cp $OUT/pmc_$sc/summary.txt $OUT/${TAG}_pmc_summary_$sc.txt; cp $OUT/pmc_$sc/pmc_traffic.json $OUT/${TAG}_pmc_traffic_$sc.json
   cp $OUT/${TAG}_pmc_summary_$sc.txt $OUT/${TAG}_pmc_traffic_$sc.json profiles/
+  fi
   rocprofv3 --kernel-trace --stats -d $OUT/prof_$sc -o ${TAG}_$sc -- python bench.py --scene $sc --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_$sc.json.log 2>> $OUT/bench_full.err
   DB=$(find $OUT/prof_$sc -name "*_results.db" | head -1)
   python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_${sc}_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --scene $sc --steps 32 --no-cpu-baseline" > /dev/null

@@ -5,7 +5,8 @@
 //   lane64 : one ray per lane, one 64-byte record per visit fetched by four 16-byte loads (a 4-wide node walked by ONE lane)
 //   quad64 : one ray per QUAD, one 64-byte record per visit, each lane of the quad loads its own 16 bytes (one box per lane),
 //            successor = a quad-level reduction (two DPP steps) of the four lanes' results
-// `active` masks lanes off the way a box pass does (39 of 64 in production); quads are masked as a whole.
+// `active` masks lanes off the way a box pass does (39 of 64 in production); quads are masked as a whole.  Second part: the cost table of ONE load
+// instruction by width, distinct lines, slot spread, neighbouring-lane sharing and active lanes (profiles/r05_taprobe.txt, profiles/NOTES.md L).
 // Output: ns per wave-iteration, visits per second per CU, and box tests per second (lane16: 1 per visit, lane64 / quad64: 4 per visit).
 // hipcc --offload-arch=gfx950 -O3 tools/taprobe.hip -o tools/bin/taprobe
 #pragma clang diagnostic ignored "-Wunused-value"
@@ -75,12 +76,13 @@ __global__ __launch_bounds__(256) void chase(const Rec *__restrict__ tab, u32 ma
 // l % L share a line and read different 16-byte slots of it), `active` lanes.  All records of a line carry the same successor, so a group stays
 // together while it chases through the table.
 template <int WIDTH>
-__global__ __launch_bounds__(256) void width_chase(const Rec *__restrict__ tab, u32 line_mask, int iters, u32 L, unsigned long long active, float *out, u32 adjacent = 0) {
+__global__ __launch_bounds__(256) void width_chase(const Rec *__restrict__ tab, u32 line_mask, int iters, u32 L, unsigned long long active, float *out, u32 adjacent = 0, u32 spread = 1) {
     const u32 lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const bool act = (active >> lane) & 1ull;
     // adjacent = 0: lanes l, l + L, l + 2L ... share a line (neighbouring lanes never do); adjacent = G: G NEIGHBOURING lanes share a line
     u32 line = ((wave * 64u + (adjacent ? lane / adjacent : lane % L)) * 2654435761u >> 7) & line_mask;
-    const u32 slot = (adjacent ? lane % adjacent : lane / L) & 7u;
+    // spread = 1: the lanes' 16-byte slots are spread over the line (as a tree's records are); 0: every line is read at the same offset(s)
+    const u32 slot = (adjacent ? lane % adjacent : lane / L + (spread ? lane % L : 0u)) & 7u;
     float acc = 0.0f;
     if (act) {
         for (int i = 0; i < iters; i++) {
@@ -95,22 +97,22 @@ __global__ __launch_bounds__(256) void width_chase(const Rec *__restrict__ tab, 
     if (acc == 12345.678f || line == 0xFFFFFFFFu) out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 template <int WIDTH>
-static void run_width(const Rec *tab, u32 line_mask, u32 L, int nactive, float *out, u32 adjacent = 0) {
+static void run_width(const Rec *tab, u32 line_mask, u32 L, int nactive, float *out, u32 adjacent = 0, u32 spread = 1) {
     unsigned long long active = 0;
     for (int l = 0; l < 64; l++) if ((l * nactive) / 64 != ((l + 1) * nactive) / 64) active |= 1ull << l;
     const int iters = 4000, wps = 5, blocks = 256 * wps;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    width_chase<WIDTH><<<blocks, 256>>>(tab, line_mask, 200, L, active, out, adjacent);
+    width_chase<WIDTH><<<blocks, 256>>>(tab, line_mask, 200, L, active, out, adjacent, spread);
     hipEventRecord(e0);
-    width_chase<WIDTH><<<blocks, 256>>>(tab, line_mask, iters, L, active, out, adjacent);
+    width_chase<WIDTH><<<blocks, 256>>>(tab, line_mask, iters, L, active, out, adjacent, spread);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double instr = (double)blocks * 4 * iters;
     printf("width %2d B  lines/instr %2u (%s)  active lanes %2d : %7.3f ms  %5.1f CU-cycles per wave load instruction  %6.2f G wave loads/s\n",
-           WIDTH, adjacent ? 64u / adjacent : L, adjacent ? "neighbouring lanes share" : "strided lanes share    ", __builtin_popcountll(active), ms, ms * 1e-3 * 2.4e9 * 256.0 / instr, instr / ms * 1e-6);
+           WIDTH, adjacent ? 64u / adjacent : L, adjacent ? "neighbouring lanes share" : spread ? "strided lanes share    " : "strided, ONE offset     ", __builtin_popcountll(active), ms, ms * 1e-3 * 2.4e9 * 256.0 / instr, instr / ms * 1e-6);
     hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
@@ -176,6 +178,10 @@ int main(int argc, char **argv) {
         run_width<4>(tab, line_mask, L, 64, out);
         run_width<8>(tab, line_mask, L, 64, out);
         run_width<16>(tab, line_mask, L, 64, out);
+    }
+    for (u32 L : {16u, 64u}) {             // every lane at the SAME offset of its line (one bank of the L1's data array)
+        run_width<16>(tab, line_mask, L, 64, out, 0, 0);
+        run_width<8>(tab, line_mask, L, 64, out, 0, 0);
     }
     for (u32 G : {2u, 4u, 8u, 16u}) {      // G neighbouring lanes read consecutive 16-byte (8-byte, 4-byte) slots of one line
         run_width<16>(tab, line_mask, 64 / G, 64, out, G);
