@@ -79,7 +79,7 @@ def test_committed_lines_of_the_trace_bound_scenes():
         # the physical roofline: L1 lane accesses (PMC) against 1.41 per clock per CU (tools/taprobe.hip) — a fraction, also with the chip to itself
         lk = r["physical"]["l1_lookup"]
         assert abs(lk["peak_per_s"] - 256 * 2.4e9 * 1.41) < 1e6 and abs(lk["lane_accesses_per_launch"] / (r["avg_launch_ms"] * 1e-3) / lk["peak_per_s"] - lk["frac"]) <= 1e-3
-        assert 0.3 < lk["frac"] < lk["frac_alone"] < 1.0, (scene, lk)
+        assert 0.2 < lk["frac"] < lk["frac_alone"] < 1.0, (scene, lk)
         # one load per node test, three per triangle test, counted per lane by the instrumented kernel: what the PMC pass counted is that figure to
         # within 15 % (neighbouring lanes that sit on the same node merge; shading and the hand-off records add a little)
         lanes = r["rays_per_path"] * (r["node_tests_per_ray"] + 3 * r["tri_tests_per_ray"])
