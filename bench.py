@@ -523,6 +523,17 @@ def main():
                                      "the L2 (physical HBM traffic: `traffic`), so with the chip to itself their rate can pass the HBM "
                                      "peak: hbm_normalised_alone is NOT a fraction of anything physical — l2.frac_alone and physical.ta_busy_frac are"})
                 roof["loaded_bytes"]["normalised_alone"] = round(gbs * avg_ms / alone_ms / HBM_PEAK_GBS, 4)
+            # The kernel's PHYSICAL roofline, from this run's own counts: every test is lane-loads the L1 has to look up (one 16-byte load per node
+            # test and per sphere test, two per cuboid test, three per triangle test), and a CU's L1 serves 1.41 of them per clock whatever the
+            # wave's locality (tools/taprobe.hip, profiles/r05_taprobe.txt).  The PMC pass's TCP_TOTAL_CACHE_ACCESSES (physical.l1_lookup, replayed
+            # from profiles/) counts the same thing on the hardware side: within 10 % of this figure.
+            ll = (counters["node_tests"] + 3 * counters["tri_tests"] + counters["sphere_tests"] + 2 * counters["cuboid_tests"]) / npaths
+            l1_peak = 256 * SHADER_CLOCK_HZ * L1_LANES_PER_CLOCK
+            roof["l1_lookup"] = {"lane_loads_per_path": round(ll, 1), "peak": round(l1_peak / 1e9, 1), "unit": "G lane-loads/s",
+                                 "achieved": round(ll * paths_per_launch / (avg_ms * 1e-3) / 1e9, 1), "frac": round(ll * paths_per_launch / (avg_ms * 1e-3) / l1_peak, 4),
+                                 "frac_alone": round(ll * paths_per_launch / (alone_ms * 1e-3) / l1_peak, 4) if alone_ms else None,
+                                 "note": "traversal loads only (shading, textures and the hand-off records add a few per cent), counted by the instrumented kernel in THIS run; "
+                                         "peak = 256 CUs x 2.4 GHz x 1.41 lane-loads per clock (measured); frac beside the seed kernel, frac_alone with the chip to itself"}
             # L2 is the level that serves the tree: the same bytes against its aggregate bandwidth
             roof["l2"] = {"achieved": round(gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4),
                           "frac_alone": round(gbs * avg_ms / alone_ms / L2_PEAK_GBS, 4) if alone_ms else None,
