@@ -26,7 +26,14 @@ d = np.abs(rg - rr).sum(axis=-1)
 print("seed", seed, "builder", builder, "mean gpu %.5f oracle %.5f" % (rg.mean(), rr.mean()), "sum of |diff| %.3f" % d.sum())
 idx = np.dstack(np.unravel_index(np.argsort(-d, axis=None)[:8], d.shape))[0]
 for (y, x, s) in idx:
-    same = (g[2][y, x, s] == ref[2][y, x, s]).all() and g[3][y, x, s] == ref[3][y, x, s]
-    cls = "same branch" if same else "divergent: %s" % (path_parity.classify(g[2][y, x, s], ref[2][y, x, s]),)
+    # as tests/path_parity.py account(): nine event bytes + the hash of every discrete decision make a branch; the count of sphere hits and the
+    # texel-quad sum (bytes 9 - 11) are reported beside it
+    eg, eo = g[2][y, x, s], ref[2][y, x, s]
+    ev_same = (eg[:9] == eo[:9]).all()
+    same = ev_same and g[3][y, x, s] == ref[3][y, x, s]
+    if same:
+        cls = "same branch" + ("" if (eg[10:12] == eo[10:12]).all() else ", another texel quad somewhere along the path")
+    else:
+        cls = "divergent: %s" % ("other_element_same_events" if ev_same else "%s at iteration %d" % path_parity.classify(eg[:9], eo[:9])[::-1])
     print("pixel (%d, %d) sub %d: gpu %s oracle %s rays %d / %d  events gpu %s oracle %s  %s" % (x, y, s, np.round(rg[y, x, s], 4), np.round(rr[y, x, s], 4), g[1][y, x, s], ref[1][y, x, s],
-          list(g[2][y, x, s]), list(ref[2][y, x, s]), cls))
+          [int(v) for v in eg], [int(v) for v in eo], cls))
