@@ -707,6 +707,25 @@ int hr_bind_accumulator(hr_ctx *c, float *device_rgb) {
     if (!c) return fail(HR_ERR_INVALID, "hr_bind_accumulator: null ctx");
     if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_bind_accumulator: hr_set_resolution not called");
     HIP_TRY(hipSetDevice(c->device));
+    if (device_rgb) {
+        // what can be checked of a caller's pointer is checked: device memory, of this context's device, float-aligned, and W x H x 3 floats
+        // inside the allocation it points into (a tensor of another shape or dtype would otherwise be overrun by plain stores, silently)
+        const size_t need = (size_t)c->W * c->H * 3 * sizeof(float);
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, device_rgb) != hipSuccess || at.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            return fail(HR_ERR_INVALID, "hr_bind_accumulator: %p is not device memory", (void *)device_rgb);
+        }
+        if (at.device != c->device) return fail(HR_ERR_INVALID, "hr_bind_accumulator: the buffer lives on device %d, the context on device %d", at.device, c->device);
+        if ((uintptr_t)device_rgb % sizeof(float)) return fail(HR_ERR_INVALID, "hr_bind_accumulator: the buffer is not aligned for floats");
+        void *base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)device_rgb) == hipSuccess) {
+            if ((const char *)device_rgb + need > (const char *)base + size)
+                return fail(HR_ERR_INVALID, "hr_bind_accumulator: the buffer is too small (%zu bytes from this address to the end of its allocation, %u x %u x 3 floats = %zu needed)",
+                            (size_t)((const char *)base + size - (const char *)device_rgb), c->W, c->H, need);
+        } else (void)hipGetLastError();
+    }
     int rc = sync_all(c);
     if (rc) return rc;
     {

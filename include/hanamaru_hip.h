@@ -156,7 +156,8 @@ int hr_set_resolution(hr_ctx *ctx, uint32_t width, uint32_t height);
  * torch.distributed all-reduces over RCCL.  Pass NULL to return to the internal buffer.
  * EXCLUSIVE: one context per buffer, and the caller must not touch the buffer on another stream between hr_render and the next
  * hr_synchronize / read — a launch's radiance is added with plain loads and stores (no atomics), in a fixed order (bit-reproducible
- * renders).  Binding a buffer another context of this process holds returns HR_ERR_INVALID.  hr_set_resolution unbinds. */
+ * renders).  Binding a buffer another context of this process holds returns HR_ERR_INVALID, and so does a pointer that is not device memory of
+ * this context's device, is not float-aligned, or has fewer than W*H*3 floats between it and the end of its allocation.  hr_set_resolution unbinds. */
 int hr_bind_accumulator(hr_ctx *ctx, float *device_rgb);
 void *hr_accumulator_device_ptr(hr_ctx *ctx);
 /* Optional: run on a caller-owned hipStream_t (opaque).  NULL = the context's own stream. */

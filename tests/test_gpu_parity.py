@@ -566,6 +566,42 @@ def test_error_paths(ha):
     r.close()
 
 
+def test_bind_accumulator_checks_the_callers_pointer(ha, scenes):
+    """hr_bind_accumulator takes a caller's device pointer (e.g. a torch tensor the host all-reduces itself): what can be checked of it is
+    checked before plain stores go there — device memory, of the context's device, float-aligned, W x H x 3 floats inside its allocation.
+    A refused binding leaves the previous one in place; a good one renders what the internal accumulator renders."""
+    import torch
+    sc, _ = scenes("cornell_mini")
+    r = ha.Renderer(0)
+    try:
+        r.upload_scene(sc)
+        r.set_resolution(64, 40)
+        r.render(1, 3)
+        own = r.read_accumulator().copy()
+        host = np.zeros((40, 64, 3), dtype=np.float32)
+        small = torch.zeros((8,), dtype=torch.float32, device="cuda:0")
+        good = torch.zeros((40, 64, 3), dtype=torch.float32, device="cuda:0")
+        for what, ptr, msg in [("a host pointer", host.ctypes.data, "not device memory"), ("a wild pointer", 4096, "not device memory"),
+                               ("a misaligned pointer", good.data_ptr() + 2, "aligned")]:
+            with pytest.raises(ha.HipError) as e:
+                r.bind_accumulator(ptr)
+            assert e.value.code == -1 and msg in str(e.value), (what, str(e.value))
+        assert np.array_equal(r.read_accumulator(), own)         # still the internal accumulator
+        r.bind_accumulator(good.data_ptr())
+        r.clear()
+        r.render(1, 3)
+        r.synchronize()
+        assert np.array_equal(good.cpu().numpy(), own)
+        r.bind_accumulator(0)
+        # a tensor of the wrong shape: 32 bytes somewhere in one of torch's 2-MiB small-block segments against 1024 x 1024 x 3 floats
+        r.set_resolution(1024, 1024)
+        with pytest.raises(ha.HipError) as e:
+            r.bind_accumulator(small.data_ptr())
+        assert e.value.code == -1 and "too small" in str(e.value), str(e.value)
+    finally:
+        r.close()
+
+
 def test_no_device_memory_growth_over_context_cycles(ha):
     """create -> upload (host and device builders in turn) -> render -> replace the scene in place -> render -> destroy, twenty times: the
     device's free memory after every cycle is what it was after the first (the HIP runtime keeps its own pools; nothing of ours grows)."""
