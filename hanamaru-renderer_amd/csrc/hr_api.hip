@@ -7,6 +7,8 @@
 //                    refilled with ballot / mbcnt prefix ranks; no LDS, so it co-resides with the seed kernel of the NEXT
 //                    batch (own stream) — plus trace_debug_kernel (the same traversal, for hr_debug_trace), intersect_debug_kernel
 //                    and debug_render_kernel (renderer.rs:101-146)
+//   wf_kernels.h     the split pipeline (option trace_mode 1): wf_start_kernel, wf_traverse_kernel (the same traversal at <= 64 VGPRs),
+//                    wf_shade_kernel — the megakernel cut at scene.intersect, the path parked in HBM between the two
 //   post_kernels.h   tonemap_gamma_kernel, bilateral_quantise_kernel
 //   gpu_bvh.h        the device BVH builders' kernels (option bvh_builder = 1 LBVH, 2 PLOC)
 #include <hip/hip_runtime.h>
@@ -51,6 +53,7 @@ static int fail(int code, const char *fmt, ...) {
 
 #include "seed_kernels.h"
 #include "trace_kernel.h"
+#include "wf_kernels.h"
 #include "post_kernels.h"
 
 // ------------------------------------------------------------------------------------------ context
@@ -119,6 +122,12 @@ struct hr_ctx {
     uint32_t nee_cull = 7;                   // debug option nee_cull: mask of nee_setup's shortcuts in force (1 far side | 2 GGX below the horizon | 4 own sphere); 0 = trace every NEE shadow ray (bit-identical image, more rays)
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
+    // the split pipeline (wf_kernels.h): queues of the launch being traced, sized for the largest launch so far
+    int trace_mode = 0;                      // 0 = megakernel (trace_kernel), 1 = split: traversal kernel + shading kernel per path iteration
+    WfQueues wf{};
+    void *wf_block = nullptr;                // one allocation behind every pointer of wf
+    uint64_t wf_cap_paths = 0, wf_cap_rays = 0;
+    uint32_t wf_adv_den = 4, wf_trav_wgs = 8, wf_shade_wgs = 8;   // debug: traversal kernel leaves its walk when 1/wf_adv_den of the lanes are done; workgroups per CU
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
     std::vector<EventPair> seed_events, trace_events, post_events, debug_events;
@@ -396,6 +405,7 @@ int hr_destroy(hr_ctx *c) {
         if (c->trace_done[i]) (void)hipEventDestroy(c->trace_done[i]);
     }
     if (c->ring) (void)hipFree(c->ring);
+    if (c->wf_block) (void)hipFree(c->wf_block);
     if (c->ovf) (void)hipFree(c->ovf);
     if (c->ovf_win) (void)hipFree(c->ovf_win);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -806,6 +816,54 @@ static int ensure_ovf(hr_ctx *c, uint64_t paths_per_launch) {
     return HR_OK;
 }
 
+// Queues of the split pipeline for launches of up to `paths` paths: a step's rays are at most one main ray and one shadow ray per emitter
+// for every path (renderer.rs:274), both parities of the ray queue, one hit per ray, both parities of the live-path state.
+static int ensure_wf(hr_ctx *c, uint64_t paths) {
+    const uint64_t rays = paths * (1ull + c->dsc.num_emitters);
+    if (paths <= c->wf_cap_paths && rays <= c->wf_cap_rays) return HR_OK;
+    if (rays >= 0xffffffffull) return fail(HR_ERR_UNSUPPORTED, "split pipeline: %llu ray slots per launch exceed the 32-bit queue index (reduce option batch)", (unsigned long long)rays);
+    int rc = sync_all(c);
+    if (rc) return rc;
+    if (c->wf_block) { HIP_TRY(hipFree(c->wf_block)); c->wf_block = nullptr; }
+    c->wf_cap_paths = c->wf_cap_rays = 0;
+    const size_t ray_q = (size_t)rays * sizeof(f4), st_q = (size_t)paths * sizeof(f4), cnt = ((WF_STEPS + 2) * sizeof(WfCounts) + 255) / 256 * 256;
+    const size_t total = cnt + 4 * ray_q + (size_t)rays * sizeof(WfHitRec) + 6 * st_q;
+    hipError_t e = hipMalloc(&c->wf_block, total);
+    if (e != hipSuccess) { c->wf_block = nullptr; return fail(HR_ERR_DEVICE, "split pipeline: %.1f GiB of queues: %s", (double)total / (1ull << 30), hipGetErrorString(e)); }
+    char *b = (char *)c->wf_block;
+    c->wf.counts = (WfCounts *)b; b += cnt;
+    for (int i = 0; i < 2; i++) { c->wf.ray_a[i] = (f4 *)b; b += ray_q; c->wf.ray_b[i] = (f4 *)b; b += ray_q; }
+    c->wf.hits = (WfHitRec *)b; b += (size_t)rays * sizeof(WfHitRec);
+    for (int i = 0; i < 2; i++) { c->wf.st_a[i] = (f4 *)b; b += st_q; c->wf.st_b[i] = (f4 *)b; b += st_q; c->wf.st_c[i] = (f4 *)b; b += st_q; }
+    c->wf_cap_paths = paths; c->wf_cap_rays = rays;
+    return HR_OK;
+}
+// One launch through the split pipeline, on the main stream: camera rays, then per path iteration the traversal kernel over the step's rays
+// and the shading kernel over its live paths.  Empty steps (every path has ended) are two kernels that read one counter and leave.
+static int launch_split(hr_ctx *c, const RenderParams &rp, int slot) {
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(c->wf.counts, 0, (WF_STEPS + 2) * sizeof(WfCounts), st));
+    const uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
+    const bool qn = c->dsc.qnodes != nullptr;
+    hipLaunchKernelGGL(wf_start_kernel, dim3(std::min<uint32_t>((items + 3) / 4, (uint32_t)c->num_cus * 8u)), dim3(256), 0, st, c->dsc, rp, c->recs[slot], c->wf);
+    RenderParams rt = rp;
+    rt.adv_den = c->wf_adv_den;
+    const dim3 gt((uint32_t)c->num_cus * c->wf_trav_wgs), gs((uint32_t)c->num_cus * c->wf_shade_wgs), b(256);
+    for (uint32_t step = 1; step <= WF_STEPS; step++) {
+        if (c->counters) {
+            if (qn) hipLaunchKernelGGL((wf_traverse_kernel<true, true>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
+            else hipLaunchKernelGGL((wf_traverse_kernel<true, false>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
+            hipLaunchKernelGGL((wf_shade_kernel<true>), gs, b, 0, st, c->dsc, rp, c->recs[slot], c->wf, step, c->d_counters);
+        } else {
+            if (qn) hipLaunchKernelGGL((wf_traverse_kernel<false, true>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
+            else hipLaunchKernelGGL((wf_traverse_kernel<false, false>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
+            hipLaunchKernelGGL((wf_shade_kernel<false>), gs, b, 0, st, c->dsc, rp, c->recs[slot], c->wf, step, c->d_counters);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return HR_OK;
+}
+
 static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t st) {
     uint64_t paths = (uint64_t)rp.tiles_x * rp.tiles_y * rp.num_k * 64u;
     uint32_t grid = (uint32_t)std::min<uint64_t>((paths + SEED_COLS - 1) / SEED_COLS, (uint64_t)c->num_cus);
@@ -885,6 +943,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
+    const bool split = c->trace_mode == 1 && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
+    if (split && (rc = ensure_wf(c, (uint64_t)tiles * 64u * batch))) return rc;
     rp.ovf_cap = c->ovf_cap;
     rp.rr_start = c->rr_start;
     rp.nee_cull_off = ~c->nee_cull & 7u;
@@ -923,6 +983,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
             const bool qn = c->dsc.qnodes != nullptr;
 #define HR_LAUNCH_TRACE_RR(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->d_counters, c->d_tile_counter + slot)
             if (c->debug_skip & 16) {
+            } else if (split) {
+                if ((rc = launch_split(c, rp, slot))) return rc;
             } else if (c->rr_start) {   // the non-parity estimator has its own instantiations (one occupancy variant)
                 if (c->counters) { if (qn) HR_LAUNCH_TRACE_RR(true, 3, true); else HR_LAUNCH_TRACE_RR(true, 3, false); }
                 else if (qn) HR_LAUNCH_TRACE_RR(false, 5, true);
@@ -1402,6 +1464,16 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         c->ploc_top = (uint32_t)value;
         return HR_OK;
     }
+    if (k == "trace_mode") {
+        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "trace_mode must be 0 (megakernel) or 1 (split: traversal kernel + shading kernel)");
+        int rc = sync_all(c);
+        if (rc) return rc;
+        c->trace_mode = (int)value;
+        return govern_reset(c);
+    }
+    if (k == "wf_adv_den") { if (value < 0 || value > 64) return fail(HR_ERR_INVALID, "wf_adv_den must be in [0,64]"); c->wf_adv_den = (uint32_t)value; return HR_OK; }
+    if (k == "wf_trav_wgs") { if (value < 1 || value > 16) return fail(HR_ERR_INVALID, "wf_trav_wgs must be in [1,16]"); c->wf_trav_wgs = (uint32_t)value; return HR_OK; }
+    if (k == "wf_shade_wgs") { if (value < 1 || value > 16) return fail(HR_ERR_INVALID, "wf_shade_wgs must be in [1,16]"); c->wf_shade_wgs = (uint32_t)value; return HR_OK; }
     if (k == "debug_skip") { c->debug_skip = (int)value; return HR_OK; }
     if (k == "nee_cull") { c->nee_cull = (uint32_t)value & 7u; return HR_OK; }
     return fail(HR_ERR_INVALID, "unknown debug option '%s'", key);

@@ -38,8 +38,9 @@ struct WaveStats {
 // QN: the tree is walked on the 16-byte quantised nodes (the default for host- and device-built trees); false: on the 32-byte
 // fp32 records of the same tree (option quant_nodes = 0).  A template parameter, not a branch: each form keeps only its own
 // per-ray constants in registers.
-template <bool CNT, bool QN>
-__device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParams &rp, Path &p, const bool active, const uint32_t n_active, const uint32_t adv_den,
+// P: what a lane holds — the megakernel's Path, or the split pipeline's TravLane (wf_core.h): `ray`, `ts` and a shadow_early_out(P &).
+template <bool CNT, bool QN, class P>
+__device__ __forceinline__ void traverse_wave(const Scene &sc, const RenderParams &rp, P &p, const bool active, const uint32_t n_active, const uint32_t adv_den,
                                               const uint32_t leaf_den, LaneCounters &lc, WaveStats &ws, uint32_t &tick, const uint32_t boost_mask) {
     for (;;) {
         const bool trav = active && !trace_done(p.ts);

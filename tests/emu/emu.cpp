@@ -19,6 +19,7 @@
 #include "post_core.h"
 #include <cstdlib>
 #include "pt_core.h"
+#include "wf_core.h"
 
 using namespace hr;
 
@@ -375,6 +376,84 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
     }
     if (counters)
         for (int k = 0; k < 7; k++) { counters[k] = 0; for (auto &c : cn) counters[k] += c[k]; }
+    return 0;
+}
+
+// The split pipeline (csrc/wf_core.h, wf_kernels.h), one path at a time: the same step structure as the kernels — per iteration, walk the
+// shadow rays of the iteration before and the main ray, add the contributions in order, shade the main hit, emit — on the same per-lane
+// functions.  tests/test_emu_parity.py compares the accumulator with emu_render's (path_advance), bit for bit.
+int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc) {
+    Scene sc = e->view;
+    sc.qnodes = nullptr;
+    RenderParams rp{};
+    rp.width = W; rp.height = H;
+    const uint32_t cull = (uint32_t)g_nee_cull & 7u;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    struct RayRec { V3f o; float len; V3f d; float w; };
+    auto walk = [&](const RayRec &r) {
+        TravLane l;
+        wf_lane_begin(sc, l, r.o, r.d, r.len);
+        LaneCounters lc = {0, 0, 0, 0, 0, 0};
+        while (l.ts.cur != NODE_END) { trace_step<false>(sc, l.ray, l.ts, &lc); shadow_early_out(l); }
+        return wf_hit_pack(l.ts);
+    };
+    for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                uint32_t y = next.fetch_add(1);
+                if (y >= H) break;
+                for (uint32_t x = 0; x < W; x++) {
+                    float sum[3] = {0, 0, 0};
+                    for (uint32_t sub = 0; sub < 4; sub++) {
+                        ArrRec rec;
+                        Path p0;
+                        RenderParams rpp = rp;
+                        emu_place_path(rpp, W, H, x, y, sub, p0, rec);
+                        path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
+                        path_start(sc, rpp, p0, x, y, sub, rec.f);
+                        const float *prec = rec.f + rec.base;      // the path's record, as wf_rec_base() addresses it on the device
+                        WfPath p;
+                        p.pid = 0; p.st = wf_st(1u, true, (p0.q >> 12) & 15u, 0u); p.raybase = 0; p.cur_refl = 1.0f;
+                        p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
+                        std::vector<RayRec> rays{RayRec{p0.ray.o, WF_MAIN_RAY, p0.ray.d, 0.0f}}, nxt;
+                        LaneCounters lc = {0, 0, 0, 0, 0, 0};
+                        for (uint32_t step = 1;; step++) {
+                            std::vector<WfHitRec> hits;
+                            for (const RayRec &r : rays) hits.push_back(walk(r));
+                            const uint32_t ns = wf_shadow_rays(p);
+                            for (uint32_t k = 0; k < ns; k++) wf_contribute<false>(sc, p, hits[k], rays[k].o, rays[k].len, rays[k].d, rays[k].w, &lc);
+                            if (!wf_has_main(p)) break;
+                            p.refl = p.refl * p.cur_refl;
+                            WfBounce b;
+                            b.nee = false;
+                            if (wf_surface<false>(sc, p, prec, rays[ns].o, rays[ns].d, hits[ns], b, &lc)) break;
+                            nxt.clear();
+                            if (b.nee)
+                                for (uint32_t k = 0; k < sc.num_emitters; k++) {
+                                    V3f d; float len;
+                                    if (wf_nee_ray(sc, b, k, cull, d, len)) nxt.push_back(RayRec{b.next_o, len, d, wf_nee_weight(sc, b, k, d, len)});
+                                }
+                            const uint32_t ns_new = (uint32_t)nxt.size();
+                            const bool bounce = wf_bounces(p, b);
+                            if (!ns_new && !bounce) break;
+                            if (bounce) nxt.push_back(RayRec{b.next_o, WF_MAIN_RAY, b.next_d, 0.0f});
+                            p.st = wf_st(wf_iter(p) + (bounce ? 1u : 0u), bounce, wf_a2(p), ns_new);
+                            p.cur_refl = b.cur_refl;
+                            rays.swap(nxt);
+                            if (step > 10u) return;   // (cannot happen: nine iterations + one collecting step)
+                        }
+                        sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
+                    }
+                    float *o = &acc[((size_t)y * W + x) * 3];
+                    o[0] += sum[0]; o[1] += sum[1]; o[2] += sum[2];
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+        for (auto &t : th) t.join();
+    }
     return 0;
 }
 

@@ -25,6 +25,7 @@ def lib():
         L.emu_raw_draws_pc.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.c_void_p]
         L.emu_raw_draws_seg.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_render_wf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_path_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -60,6 +61,12 @@ class EmuScene:
         cn = (C.c_uint64 * 7)()
         lib().emu_render(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data, cn)
         return acc, dict(zip(["paths", "rays", "node_tests", "tri_tests", "sphere_tests", "cuboid_tests", "shadow_culled"], list(cn)))
+
+    def render_wf(self, w, h, s_begin, s_end, stride=1, threads=0):
+        """the split pipeline's per-lane functions (csrc/wf_core.h), path by path"""
+        acc = np.zeros((h, w, 3), dtype=np.float32)
+        lib().emu_render_wf(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data)
+        return acc
 
     def path_log(self, w, h, sampling, threads=0):
         """(radiance [h, w, 4, 3] float32, rays, events [h, w, 4, 12] uint8 (nine event bytes, the count of sphere hits, the 16-bit texel-quad sum), element hash) — the layout of Renderer.debug_path_log"""

@@ -474,6 +474,24 @@ def test_nee_culls_do_not_change_a_bit(emu, emu_scenes, name):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_v2", "tbf3", "rtcamp5", "spheres", "cornell_mini", "material_examples", "simple"])
+def test_split_pipeline_is_the_same_arithmetic(emu, emu_scenes, name):
+    """csrc/wf_core.h — the split pipeline's per-lane code (option trace_mode 1: a traversal kernel and a shading kernel per path iteration,
+    the NEE weight computed when the shadow ray is emitted, the contributions added a step later) — is path_advance cut into pieces: driven
+    path by path on the host it renders the accumulator of the megakernel's per-lane code, bit for bit.  (On the GPU:
+    test_kernel_variants_render_the_same_bits.)"""
+    _, _, e = emu_scenes(name)
+    a, _ = e.render(96, 54, 1, 3)
+    b = e.render_wf(96, 54, 1, 3)
+    assert a.sum() > 0 and np.array_equal(a, b)
+    try:
+        emu.set_nee_cull(False)
+        c = e.render_wf(96, 54, 1, 3)
+    finally:
+        emu.set_nee_cull(True)
+    assert np.array_equal(a, c)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_scenes_path_by_path(ha, orc, emu, seed):
     """Fuzz tier (tests/random_scenes.py): every element kind x surface type x textured / constant parameters, overlapping and nested —

@@ -1002,8 +1002,16 @@ def test_kernel_variants_render_the_same_bits(gpu, scenes):
             gpu.set_debug_option("min_waves", mw)
             assert np.array_equal(ref, render()), ("min_waves", mw)
         gpu.set_debug_option("min_waves", 5)
+        # the split pipeline (traversal kernel + shading kernel per path iteration, wf_kernels.h) is the megakernel cut at scene.intersect
+        gpu.set_debug_option("trace_mode", 1)
+        assert np.array_equal(ref, render()), "split pipeline"
+        gpu.set_option("counters", 1)
+        assert np.array_equal(ref, render()), "split pipeline, instrumented build"
+        gpu.set_option("counters", 0)
         gpu.set_option("quant_nodes", 0)
         gpu.upload_scene(sc)
+        assert np.array_equal(ref, render()), "split pipeline, fp32 node records"
+        gpu.set_debug_option("trace_mode", 0)
         assert np.array_equal(ref, render()), "fp32 node records"
         gpu.set_option("quant_nodes", 1)
         gpu.set_option("bvh_builder", 2)
@@ -1011,6 +1019,7 @@ def test_kernel_variants_render_the_same_bits(gpu, scenes):
         assert np.array_equal(ref, render()), "device-built tree"
     finally:
         gpu.set_option("counters", 0)
+        gpu.set_debug_option("trace_mode", 0)
         gpu.set_debug_option("min_waves", 5)
         gpu.set_option("quant_nodes", 1)
         gpu.set_option("bvh_builder", -1)
