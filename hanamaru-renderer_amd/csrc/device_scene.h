@@ -147,6 +147,8 @@ struct alignas(16) TriT {
     float bz; float v0[3];
 };
 struct alignas(16) TriS { float n[3]; int32_t element; };
+// the plane of an INPUT triangle in the reference's precision (unit normal of the f64 vertices, bvh.rs:286; v0): precise shading only (wf_core.h)
+struct alignas(16) TriX { double n[3], v0[3]; };
 HD void tri_derive(const Tri &t, TriT &tt, TriS &ts) {
     const double e1[3] = {t.e1x, t.e1y, t.e1z}, e2[3] = {t.e2x, t.e2y, t.e2z};
     const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
@@ -194,6 +196,8 @@ struct Scene {
     const f4 *spheres; const int32_t *sphere_elem;
     const f4 *sphere_lo;     // per sphere: what rounding its f64 centre and radius to `spheres[]` took away (c - (float)c, r - (float)r) — hit_surface only
     const f4 *cuboids;       // 2 per cuboid: {min, element-as-int-bits}, {max, 0}
+    const f4 *cuboid_lo;     // [2 * ELEMENT id]: what rounding a cuboid's f64 bounds to `cuboids[]` took away — precise shading only
+    const TriX *tri_exact;   // [input triangle] (tri_face[] leads there from a leaf-ordered reference) — precise shading only
     const Material *materials;
     const uint32_t *texels;
     const ImageRef *images;

@@ -89,6 +89,7 @@ Scene HostScene::view() const {
     d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
     for (int k = 0; k < 3; k++) { d.qmin[k] = qmin[k]; d.qstep[k] = qstep[k]; }
     d.spheres = spheres.data(); d.sphere_elem = sphere_elem.data(); d.sphere_lo = sphere_lo.data(); d.cuboids = cuboids.data();
+    d.cuboid_lo = cuboid_lo.data(); d.tri_exact = tri_exact.data();
     d.materials = materials.data(); d.texels = texels.data(); d.images = images.data(); d.emitters = emitters.data();
     d.num_nodes = num_nodes; d.num_tris = (uint32_t)tris.size(); d.num_spheres = (uint32_t)spheres.size();
     d.num_cuboids = (uint32_t)(cuboids.size() / 2); d.num_elements = (uint32_t)materials.size(); d.num_emitters = (uint32_t)emitters.size();
@@ -106,7 +107,7 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     struct TriD { double v0[3], v1[3], v2[3]; int32_t elem; };
     std::vector<TriD> tris;
     std::vector<f4> spheres, sphere_lo; std::vector<int32_t> sphere_elem;
-    std::vector<f4> cuboids;
+    std::vector<f4> cuboids, cuboid_lo;
     std::vector<BuildPrim> prims;        // one reference per primitive
     std::vector<BuildPrim> prims_split;  // triangles cut by early split clipping (when enabled), other primitives as they are
     // split_ratio < 0: build both trees and keep the split one only when it cuts the SAH cost by more than 7 % (the 8 octant
@@ -188,6 +189,12 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
             cv.i = (int32_t)ei;
             cuboids.push_back(f4{(float)mn[0], (float)mn[1], (float)mn[2], cv.f});
             cuboids.push_back(f4{(float)mx[0], (float)mx[1], (float)mx[2], 0.0f});
+            {   // what the fp32 bounds lost (precise shading recomputes the hit on the f64 box)
+                const f4 &a = cuboids[cuboids.size() - 2], &b = cuboids.back();
+                cuboid_lo.resize(2 * (size_t)sd->num_elements, f4{0, 0, 0, 0});   // indexed by ELEMENT: no leaf order to follow
+                cuboid_lo[2 * ei] = f4{(float)(mn[0] - (double)a.x), (float)(mn[1] - (double)a.y), (float)(mn[2] - (double)a.z), 0.0f};
+                cuboid_lo[2 * ei + 1] = f4{(float)(mx[0] - (double)b.x), (float)(mx[1] - (double)b.y), (float)(mx[2] - (double)b.z), 0.0f};
+            }
         } else if (e.kind == HR_MESH) {
             if (!e.vertexes || !e.faces) return ferr(err, HR_ERR_INVALID, "element %u: mesh without data", ei);
             for (uint64_t fi = 0; fi < e.num_faces; fi++) {
@@ -266,6 +273,17 @@ int flatten_scene(const hr_scene_desc *sd, HostScene &out, std::string &err, int
     for (size_t i = 0; i < spheres.size(); i++) { out.spheres[i] = spheres[bvh.order[1][i]]; out.sphere_elem[i] = sphere_elem[bvh.order[1][i]]; out.sphere_lo[i] = sphere_lo[bvh.order[1][i]]; }
     out.cuboids.resize(cuboids.size());
     for (size_t i = 0; i < cuboids.size() / 2; i++) { out.cuboids[2 * i] = cuboids[2 * bvh.order[2][i]]; out.cuboids[2 * i + 1] = cuboids[2 * bvh.order[2][i] + 1]; }
+    out.cuboid_lo = cuboid_lo;
+    // the planes of the input triangles in f64 (bvh.rs:267-268,286: edges of the f64 vertices, their cross product normalised)
+    out.tri_exact.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {
+        const TriD &s = tris[i];
+        const double e1[3] = {s.v1[0] - s.v0[0], s.v1[1] - s.v0[1], s.v1[2] - s.v0[2]}, e2[3] = {s.v2[0] - s.v0[0], s.v2[1] - s.v0[1], s.v2[2] - s.v0[2]};
+        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), il = l > 0.0 ? 1.0 / l : 0.0;
+        TriX &x = out.tri_exact[i];
+        for (int k = 0; k < 3; k++) { x.n[k] = n[k] * il; x.v0[k] = s.v0[k]; }
+    }
 
     out.images.assign(sd->num_images, ImageRef{});
     size_t total = 0;

@@ -26,6 +26,8 @@ struct HostScene {
     std::vector<int32_t> sphere_elem;
     std::vector<f4> sphere_lo;         // Scene::sphere_lo
     std::vector<f4> cuboids;
+    std::vector<f4> cuboid_lo;         // Scene::cuboid_lo
+    std::vector<TriX> tri_exact;       // Scene::tri_exact: per INPUT triangle (tri_face[] indexes it)
     std::vector<Material> materials;
     std::vector<ImageRef> images;
     std::vector<Emitter> emitters;

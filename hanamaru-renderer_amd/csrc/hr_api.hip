@@ -124,9 +124,10 @@ struct hr_ctx {
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
     // the split pipeline (wf_kernels.h): queues of the launch being traced, sized for the largest launch so far
     int trace_mode = 0;                      // 0 = megakernel (trace_kernel), 1 = split: traversal kernel + shading kernel per path iteration
+    bool precise = false;                    // option precise_shading: the split pipeline with the bounce geometry in f64 (wf_core.h wf_surface_f64)
+    bool wf_has_prec = false;                // the queues hold the residual quads
     WfQueues wf{};
     void *wf_block = nullptr;                // one allocation behind every pointer of wf
-    uint64_t wf_cap_paths = 0, wf_cap_rays = 0;
     uint32_t wf_adv_den = 4, wf_trav_wgs = 8, wf_shade_wgs = 8;   // debug: traversal kernel leaves its walk when 1/wf_adv_den of the lanes are done; workgroups per CU
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
@@ -652,6 +653,8 @@ int hr_upload_scene(hr_ctx *c, const hr_scene_desc *sd) {
     if ((r = upload(c, hs.sphere_elem, &d.sphere_elem))) return r;
     if ((r = upload(c, hs.sphere_lo, &d.sphere_lo))) return r;
     if ((r = upload(c, hs.cuboids, &d.cuboids))) return r;
+    if ((r = upload(c, hs.cuboid_lo, &d.cuboid_lo))) return r;
+    if ((r = upload(c, hs.tri_exact, &d.tri_exact))) return r;
     if ((r = upload(c, hs.materials, &d.materials))) return r;
     if ((r = upload(c, hs.images, &d.images))) return r;
     if ((r = upload(c, hs.emitters, &d.emitters))) return r;
@@ -819,15 +822,17 @@ static int ensure_ovf(hr_ctx *c, uint64_t paths_per_launch) {
 // Queues of the split pipeline for launches of up to `paths` paths: a step's rays are at most one main ray and one shadow ray per emitter
 // for every path (renderer.rs:274), both parities of the ray queue, one hit per ray, both parities of the live-path state.
 static int ensure_wf(hr_ctx *c, uint64_t paths) {
-    const uint64_t rays = paths * (1ull + c->dsc.num_emitters);
-    if (paths <= c->wf_cap_paths && rays <= c->wf_cap_rays) return HR_OK;
-    if (rays >= 0xffffffffull) return fail(HR_ERR_UNSUPPORTED, "split pipeline: %llu ray slots per launch exceed the 32-bit queue index (reduce option batch)", (unsigned long long)rays);
+    // per sub-queue: the items (tile x sampling) it owns x 64 paths, and per path a main ray + one shadow ray per emitter
+    const uint64_t sub_paths = ((paths / 64u + WF_SUBQ - 1u) / WF_SUBQ) * 64u, sub_rays = sub_paths * (1ull + c->dsc.num_emitters);
+    if (sub_paths <= c->wf.cap_paths && sub_rays <= c->wf.cap_rays && c->wf_block && (c->wf_has_prec || !c->precise)) return HR_OK;
+    if (sub_rays * WF_SUBQ >= 0xffffffffull) return fail(HR_ERR_UNSUPPORTED, "split pipeline: %llu ray slots per launch exceed the 32-bit queue index (reduce option batch)", (unsigned long long)(sub_rays * WF_SUBQ));
     int rc = sync_all(c);
     if (rc) return rc;
     if (c->wf_block) { HIP_TRY(hipFree(c->wf_block)); c->wf_block = nullptr; }
-    c->wf_cap_paths = c->wf_cap_rays = 0;
-    const size_t ray_q = (size_t)rays * sizeof(f4), st_q = (size_t)paths * sizeof(f4), cnt = ((WF_STEPS + 2) * sizeof(WfCounts) + 255) / 256 * 256;
-    const size_t total = cnt + 4 * ray_q + (size_t)rays * sizeof(WfHitRec) + 6 * st_q;
+    c->wf.cap_paths = c->wf.cap_rays = 0;
+    const uint64_t rays = sub_rays * WF_SUBQ, pths = sub_paths * WF_SUBQ;
+    const size_t ray_q = (size_t)rays * sizeof(f4), st_q = (size_t)pths * sizeof(f4), cnt = (WF_STEPS + 2) * WF_SUBQ * sizeof(WfCounts);
+    const size_t total = cnt + 4 * ray_q + (size_t)rays * sizeof(WfHitRec) + (c->precise ? 10 : 6) * st_q;
     hipError_t e = hipMalloc(&c->wf_block, total);
     if (e != hipSuccess) { c->wf_block = nullptr; return fail(HR_ERR_DEVICE, "split pipeline: %.1f GiB of queues: %s", (double)total / (1ull << 30), hipGetErrorString(e)); }
     char *b = (char *)c->wf_block;
@@ -835,30 +840,47 @@ static int ensure_wf(hr_ctx *c, uint64_t paths) {
     for (int i = 0; i < 2; i++) { c->wf.ray_a[i] = (f4 *)b; b += ray_q; c->wf.ray_b[i] = (f4 *)b; b += ray_q; }
     c->wf.hits = (WfHitRec *)b; b += (size_t)rays * sizeof(WfHitRec);
     for (int i = 0; i < 2; i++) { c->wf.st_a[i] = (f4 *)b; b += st_q; c->wf.st_b[i] = (f4 *)b; b += st_q; c->wf.st_c[i] = (f4 *)b; b += st_q; }
-    c->wf_cap_paths = paths; c->wf_cap_rays = rays;
+    for (int i = 0; i < 2; i++) { c->wf.st_d[i] = c->wf.st_e[i] = c->wf.st_f[i] = nullptr; c->wf.tag[i] = nullptr; }
+    if (c->precise) for (int i = 0; i < 2; i++) { c->wf.st_d[i] = (f4 *)b; b += st_q; c->wf.st_e[i] = (f4 *)b; b += st_q; }
+    c->wf_has_prec = c->precise;
+    c->wf.cap_paths = (uint32_t)sub_paths; c->wf.cap_rays = (uint32_t)sub_rays;
     return HR_OK;
 }
 // One launch through the split pipeline, on the main stream: camera rays, then per path iteration the traversal kernel over the step's rays
 // and the shading kernel over its live paths.  Empty steps (every path has ended) are two kernels that read one counter and leave.
-static int launch_split(hr_ctx *c, const RenderParams &rp, int slot) {
+static int launch_split(hr_ctx *c, const RenderParams &rp, int slot, std::vector<hipEvent_t> *marks = nullptr, uint32_t *plog = nullptr, const WfQueues *queues = nullptr) {
+    const WfQueues wq = queues ? *queues : c->wf;
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(c->wf.counts, 0, (WF_STEPS + 2) * sizeof(WfCounts), st));
+    auto mark = [&]() -> hipError_t { if (!marks) return hipSuccess; hipEvent_t e; hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; marks->push_back(e); return hipEventRecord(e, st); };
+    HIP_TRY(hipMemsetAsync(wq.counts, 0, (WF_STEPS + 2) * WF_SUBQ * sizeof(WfCounts), st));
     const uint32_t items = rp.tiles_x * rp.tiles_y * rp.num_k;
     const bool qn = c->dsc.qnodes != nullptr;
-    hipLaunchKernelGGL(wf_start_kernel, dim3(std::min<uint32_t>((items + 3) / 4, (uint32_t)c->num_cus * 8u)), dim3(256), 0, st, c->dsc, rp, c->recs[slot], c->wf);
+    HIP_TRY(mark());
+    // grids: whole multiples of WF_SUBQ waves (16 workgroups of 4), so that every sub-queue has the same number of waves
+    auto grid_of = [&](uint32_t wgs_per_cu) { return dim3(std::max<uint32_t>(16u, (uint32_t)c->num_cus * wgs_per_cu / 16u * 16u)); };
+    (void)items;
+    if (c->precise) hipLaunchKernelGGL(wf_start_kernel<true>, grid_of(8u), dim3(256), 0, st, c->dsc, rp, c->recs[slot], wq);
+    else hipLaunchKernelGGL(wf_start_kernel<false>, grid_of(8u), dim3(256), 0, st, c->dsc, rp, c->recs[slot], wq);
+    HIP_TRY(mark());
     RenderParams rt = rp;
     rt.adv_den = c->wf_adv_den;
-    const dim3 gt((uint32_t)c->num_cus * c->wf_trav_wgs), gs((uint32_t)c->num_cus * c->wf_shade_wgs), b(256);
+    const dim3 gt = grid_of(c->wf_trav_wgs), gs = grid_of(c->wf_shade_wgs), b(256);
     for (uint32_t step = 1; step <= WF_STEPS; step++) {
-        if (c->counters) {
-            if (qn) hipLaunchKernelGGL((wf_traverse_kernel<true, true>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
-            else hipLaunchKernelGGL((wf_traverse_kernel<true, false>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
-            hipLaunchKernelGGL((wf_shade_kernel<true>), gs, b, 0, st, c->dsc, rp, c->recs[slot], c->wf, step, c->d_counters);
+        if (c->counters && !plog) {
+            if (qn) hipLaunchKernelGGL((wf_traverse_kernel<true, true>), gt, b, 0, st, c->dsc, rt, wq, step, c->d_counters);
+            else hipLaunchKernelGGL((wf_traverse_kernel<true, false>), gt, b, 0, st, c->dsc, rt, wq, step, c->d_counters);
         } else {
-            if (qn) hipLaunchKernelGGL((wf_traverse_kernel<false, true>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
-            else hipLaunchKernelGGL((wf_traverse_kernel<false, false>), gt, b, 0, st, c->dsc, rt, c->wf, step, c->d_counters);
-            hipLaunchKernelGGL((wf_shade_kernel<false>), gs, b, 0, st, c->dsc, rp, c->recs[slot], c->wf, step, c->d_counters);
+            if (qn) hipLaunchKernelGGL((wf_traverse_kernel<false, true>), gt, b, 0, st, c->dsc, rt, wq, step, c->d_counters);
+            else hipLaunchKernelGGL((wf_traverse_kernel<false, false>), gt, b, 0, st, c->dsc, rt, wq, step, c->d_counters);
         }
+        HIP_TRY(mark());
+#define HR_LAUNCH_SHADE(C, P, L) hipLaunchKernelGGL((wf_shade_kernel<C, P, L>), gs, b, 0, st, c->dsc, rp, c->recs[slot], wq, step, c->d_counters, plog)
+        if (plog) { if (c->precise) HR_LAUNCH_SHADE(false, true, true); else HR_LAUNCH_SHADE(false, false, true); }
+        else if (c->counters) { if (c->precise) HR_LAUNCH_SHADE(true, true, false); else HR_LAUNCH_SHADE(true, false, false); }
+        else if (c->precise) HR_LAUNCH_SHADE(false, true, false);
+        else HR_LAUNCH_SHADE(false, false, false);
+#undef HR_LAUNCH_SHADE
+        HIP_TRY(mark());
     }
     HIP_TRY(hipGetLastError());
     return HR_OK;
@@ -943,7 +965,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
-    const bool split = c->trace_mode == 1 && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
+    if (c->precise && c->rr_start) return fail(HR_ERR_UNSUPPORTED, "hr_render: russian_roulette and precise_shading exclude each other (the roulette estimator lives in the megakernel)");
+    const bool split = (c->trace_mode == 1 || c->precise) && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
     if (split && (rc = ensure_wf(c, (uint64_t)tiles * 64u * batch))) return rc;
     rp.ovf_cap = c->ovf_cap;
     rp.rr_start = c->rr_start;
@@ -1386,6 +1409,13 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         if ((int)value != ISAAC_TAIL) return fail(HR_ERR_UNSUPPORTED, "rng_window is fixed at %d in this build", ISAAC_TAIL);
         return HR_OK;
     }
+    if (k == "precise_shading") {   // the bounce geometry in f64 (split pipeline): closer to the reference's f64 arithmetic, a few per cent slower
+        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "precise_shading must be 0 or 1");
+        int rc = sync_all(c);
+        if (rc) return rc;
+        c->precise = value != 0;
+        return govern_reset(c);
+    }
     if (k == "russian_roulette") {  // NOT image-preserving (see the header): 0 = off, else the first path iteration that plays
         if (value != 0 && (value < 2 || value > 9)) return fail(HR_ERR_INVALID, "russian_roulette must be 0 (off) or the first iteration that plays, in [2,9]");
         c->rr_start = (uint32_t)value;
@@ -1555,22 +1585,79 @@ int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
     if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
     const size_t words = (size_t)c->W * c->H * 4u * 8u;
     uint32_t *d_log = nullptr;
+    const bool split = (c->trace_mode == 1 || c->precise) && !c->rr_start;
+    if (split && (rc = ensure_wf(c, (uint64_t)tiles * 64u))) return rc;
     HIP_TRY(hipMalloc((void **)&d_log, words * sizeof(uint32_t)));
     hipError_t e = hipMemsetAsync(d_log, 0, words * sizeof(uint32_t), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_tile_counter, 0, sizeof(uint32_t), c->stream);
-    if (e == hipSuccess) {
-        const uint32_t kch = c->kchunk ? c->kchunk : TRACE_KCHUNK;
-        const uint64_t units = (uint64_t)tiles * ((1u + kch - 1) / kch);
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
-        dim3 g(grid), b(64 * TRACE_WAVES);
-        if (c->dsc.qnodes) hipLaunchKernelGGL((trace_kernel<false, 3, true, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
-        else hipLaunchKernelGGL((trace_kernel<false, 3, false, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
-        e = hipGetLastError();
+    void *log_block = nullptr;
+    if (e == hipSuccess && split) {
+        // the split pipeline's LOG instantiation: the event log rides in two more state quads and a tag per ray slot, allocated for this call only
+        WfQueues wq = c->wf;
+        const size_t st_q = (size_t)wq.cap_paths * WF_SUBQ * sizeof(f4), tg_q = (size_t)wq.cap_rays * WF_SUBQ * sizeof(uint32_t);
+        e = hipMalloc(&log_block, 2 * st_q + 2 * tg_q);
+        if (e == hipSuccess) {
+            char *b = (char *)log_block;
+            for (int i = 0; i < 2; i++) { wq.st_f[i] = (f4 *)b; b += st_q; }
+            for (int i = 0; i < 2; i++) { wq.tag[i] = (uint32_t *)b; b += tg_q; }
+            rc = launch_split(c, rp, 0, nullptr, d_log, &wq);
+            if (rc) { (void)hipFree(log_block); (void)hipFree(d_log); return rc; }
+        }
+    } else if (e == hipSuccess) {
+        e = hipMemsetAsync(c->d_tile_counter, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) {
+            const uint32_t kch = c->kchunk ? c->kchunk : TRACE_KCHUNK;
+            const uint64_t units = (uint64_t)tiles * ((1u + kch - 1) / kch);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
+            dim3 g(grid), b(64 * TRACE_WAVES);
+            if (c->dsc.qnodes) hipLaunchKernelGGL((trace_kernel<false, 3, true, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+            else hipLaunchKernelGGL((trace_kernel<false, 3, false, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(host_out, d_log, words * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipFree(d_log);
+    if (log_block) (void)hipFree(log_block);
     if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_path_log: %s", hipGetErrorString(e));
+    return drain_events(c);
+}
+
+int hr_debug_wf_profile(hr_ctx *c, uint32_t sampling, uint32_t num_k, double *ms_out, uint32_t *counts_out) {
+    // one launch of the split pipeline with the chip to itself, an event between every two kernels: ms_out[0] = wf_start_kernel,
+    // ms_out[2 s - 1] / ms_out[2 s] = traversal / shading kernel of step s = 1 .. WF_STEPS; counts_out[2 s] / [2 s + 1] = rays / live paths of step s
+    if (!c || !ms_out || !counts_out || !num_k) return fail(HR_ERR_INVALID, "hr_debug_wf_profile: bad argument");
+    if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_debug_wf_profile: hr_set_resolution not called");
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_debug_wf_profile: no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    RenderParams rp{};
+    rp.width = c->W; rp.height = c->H; rp.tiles_x = (c->W + 3) / 4; rp.tiles_y = (c->H + 3) / 4;
+    rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = num_k;
+    rp.adv_den = c->adv_den; rp.leaf_den = c->leaf_den; rp.node_unroll = c->node_unroll;
+    rp.pad[0] = c->seed_prio;
+    rp.nee_cull_off = ~c->nee_cull & 7u;
+    const uint32_t tiles = rp.tiles_x * rp.tiles_y;
+    if ((rc = ensure_draws(c, (size_t)tiles * num_k))) return rc;
+    if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * num_k))) return rc;
+    if ((rc = ensure_wf(c, (uint64_t)tiles * 64u * num_k))) return rc;
+    rp.ovf_cap = c->ovf_cap;
+    if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
+    std::vector<hipEvent_t> marks;
+    rc = launch_split(c, rp, 0, &marks);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (!rc && e == hipSuccess && marks.size() == 2u + 2u * WF_STEPS) {
+        for (size_t i = 0; i + 1 < marks.size(); i++) { float ms = 0; (void)hipEventElapsedTime(&ms, marks[i], marks[i + 1]); ms_out[i] = ms; }
+        std::vector<WfCounts> h((WF_STEPS + 2) * WF_SUBQ);
+        e = hipMemcpy(h.data(), c->wf.counts, h.size() * sizeof(WfCounts), hipMemcpyDeviceToHost);
+        for (uint32_t s = 0; s <= WF_STEPS; s++) {
+            counts_out[2 * s] = counts_out[2 * s + 1] = 0;
+            for (uint32_t k = 0; k < WF_SUBQ; k++) { counts_out[2 * s] += wf_rays(h[s * WF_SUBQ + k]); counts_out[2 * s + 1] += wf_paths(h[s * WF_SUBQ + k]); }
+        }
+    }
+    for (hipEvent_t ev : marks) (void)hipEventDestroy(ev);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(HR_ERR_DEVICE, "hr_debug_wf_profile: %s", hipGetErrorString(e));
     return drain_events(c);
 }
 

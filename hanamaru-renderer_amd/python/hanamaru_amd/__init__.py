@@ -163,6 +163,7 @@ def hip_lib():
         L.hr_debug_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.hr_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hr_debug_path_log.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.hr_debug_wf_profile.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.hr_comm_get_unique_id.argtypes = [C.c_void_p]
         L.hr_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.hr_comm_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -407,6 +408,14 @@ class Renderer:
         rad = raw[..., 0:3].copy().view(np.float32)
         ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(self.height, self.width, 4, 12)[..., :12]
         return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
+
+    def debug_wf_profile(self, sampling=1, num_k=4):
+        """hr_debug_wf_profile: (ms[21], counts[11, 2]) of one launch of the split pipeline, kernel by kernel (ms[0] camera rays, ms[2s-1] / ms[2s]
+        traversal / shading of step s; counts[s] = rays, live paths of step s)."""
+        ms = np.zeros(21, dtype=np.float64)
+        cn = np.zeros(22, dtype=np.uint32)
+        self._check(self.L.hr_debug_wf_profile(self._h, sampling, num_k, ms.ctypes.data, cn.ctypes.data))
+        return ms, cn.reshape(11, 2)
 
     def debug_intersect(self, rays):
         r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

@@ -47,6 +47,12 @@ int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
  * The oracle keeps the same log (orc_path_log): tests/test_gpu_parity.py compares path by path. */
 int hr_debug_path_log(hr_ctx *ctx, uint32_t sampling, uint32_t *host_out);
 
+/* The split pipeline (debug option "trace_mode" 1: the loop body of renderer.rs:174-200 cut at scene.intersect into a traversal kernel and a
+ * shading kernel per path iteration) kernel by kernel: ONE launch of num_k samplings from `sampling`, alone on the chip, an event between
+ * every two kernels.  ms_out[21]: [0] = camera rays, [2 s - 1] / [2 s] = traversal / shading kernel of step s = 1 .. 10;
+ * counts_out[22]: [2 s] / [2 s + 1] = rays / live paths of step s.  The accumulator is not touched. */
+int hr_debug_wf_profile(hr_ctx *ctx, uint32_t sampling, uint32_t num_k, double *ms_out, uint32_t *counts_out);
+
 /* Closest-hit query for n rays (scene.rs:385-401 minus the material fetch).
  * rays: n * 6 floats (origin, direction).  out per ray: 8 floats
  * { hit(0/1), distance, pos.x, pos.y, pos.z, n.x, n.y, n.z }, plus element index in out_element. */

@@ -381,22 +381,86 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
 
 // The split pipeline (csrc/wf_core.h, wf_kernels.h), one path at a time: the same step structure as the kernels — per iteration, walk the
 // shadow rays of the iteration before and the main ray, add the contributions in order, shade the main hit, emit — on the same per-lane
-// functions.  tests/test_emu_parity.py compares the accumulator with emu_render's (path_advance), bit for bit.
-int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc) {
+// functions.  PREC: precise shading (wf_surface_f64).  tests/test_emu_parity.py compares the fp32 form with emu_render's (path_advance), bit for bit.
+}  // extern "C"
+struct EmuRay { V3f o; float len; V3f d; float w; V3f o_lo, d_lo; uint32_t emitter; };
+template <bool PREC, bool LOG>
+static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sub, uint32_t sampling, uint32_t cull, PathLog *lg) {
+    ArrRec rec;
+    Path p0;
+    RenderParams rpp = rp;
+    emu_place_path(rpp, W, H, x, y, sub, p0, rec);
+    path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
+    path_start(sc, rpp, p0, x, y, sub, rec.f);
+    const float *prec = rec.f + rec.base;      // the path's record, as wf_rec_base() addresses it on the device
+    WfPath p;
+    p.pid = 0; p.st = wf_st(1u, true, (p0.q >> 12) & 15u, 0u); p.raybase = 0; p.cur_refl = 1.0f;
+    p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
+    EmuRay first{p0.ray.o, WF_MAIN_RAY, p0.ray.d, 0.0f, v3(0, 0, 0), v3(0, 0, 0), 0u};
+    if (PREC) ray_fix_load(prec, 0u, (p0.q >> 12) & 15u, first.o_lo, first.d_lo);   // path_start parked the f64 camera ray's residuals there
+    std::vector<EmuRay> rays{first}, nxt;
+    LaneCounters lc = {0, 0, 0, 0, 0, 0};
+    for (uint32_t step = 1; step <= 11u; step++) {
+        std::vector<WfHitRec> hits;
+        for (const EmuRay &r : rays) {
+            TravLane l;
+            wf_lane_begin(sc, l, r.o, r.d, r.len);
+            while (l.ts.cur != NODE_END) { trace_step<false>(sc, l.ray, l.ts, &lc); shadow_early_out(l); }
+            hits.push_back(wf_hit_pack(l.ts));
+        }
+        const uint32_t ns = wf_shadow_rays(p);
+        // (the shadow rays belong to the iteration before the main ray's — or, without a main ray, to the iteration the state still names)
+        const uint32_t it_shadow = wf_has_main(p) ? wf_iter(p) - 1u : wf_iter(p);
+        for (uint32_t k = 0; k < ns; k++) {
+            const V3f before = p.accum;
+            wf_contribute<false>(sc, p, hits[k], rays[k].o, rays[k].len, rays[k].d, rays[k].w, &lc);
+            if (LOG) {
+                lg->rays++;
+                TraceState ts;
+                wf_hit_unpack(hits[k], ts);
+                const float dt = ts.t - rays[k].len;
+                if (ts.prim >= 0 && dt * dt < OFFSET_F * 4.0f) plog_or(*lg, it_shadow, 16u << (rays[k].emitter & 3u));
+                (void)before;
+            }
+        }
+        if (!wf_has_main(p)) break;
+        p.refl = p.refl * p.cur_refl;
+        WfBounce b;
+        WfBounceX bx;
+        b.nee = false;
+        bx.next_o_lo = bx.next_d_lo = v3(0, 0, 0);
+        bool fin;
+        if (PREC) fin = wf_surface_f64<false, LOG>(sc, p, prec, rays[ns].o, rays[ns].d, rays[ns].o_lo, rays[ns].d_lo, hits[ns], b, bx, &lc, lg);
+        else fin = wf_surface<false>(sc, p, prec, rays[ns].o, rays[ns].d, hits[ns], b, &lc);
+        if (fin) break;
+        nxt.clear();
+        if (b.nee)
+            for (uint32_t k = 0; k < sc.num_emitters; k++) {
+                V3f d; float len;
+                if (wf_nee_ray(sc, b, k, LOG ? (cull & 5u) : cull, d, len)) nxt.push_back(EmuRay{b.next_o, len, d, wf_nee_weight(sc, b, k, d, len), v3(0, 0, 0), v3(0, 0, 0), k});
+                else if (LOG) lg->rays++;
+            }
+        const uint32_t ns_new = (uint32_t)nxt.size();
+        const bool bounce = wf_bounces(p, b);
+        if (!ns_new && !bounce) break;
+        if (bounce) nxt.push_back(EmuRay{b.next_o, WF_MAIN_RAY, b.next_d, 0.0f, bx.next_o_lo, bx.next_d_lo, 0u});
+        p.st = wf_st(wf_iter(p) + (bounce ? 1u : 0u), bounce, wf_a2(p), ns_new);
+        p.cur_refl = b.cur_refl;
+        rays.swap(nxt);
+    }
+    return p.accum;
+}
+extern "C" {
+static int g_wf_precise = 0;
+extern "C" void emu_set_wf_precise(int on) { g_wf_precise = on; }
+extern "C" int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc) {
     Scene sc = e->view;
     sc.qnodes = nullptr;
     RenderParams rp{};
     rp.width = W; rp.height = H;
     const uint32_t cull = (uint32_t)g_nee_cull & 7u;
+    const bool precise = g_wf_precise != 0;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-    struct RayRec { V3f o; float len; V3f d; float w; };
-    auto walk = [&](const RayRec &r) {
-        TravLane l;
-        wf_lane_begin(sc, l, r.o, r.d, r.len);
-        LaneCounters lc = {0, 0, 0, 0, 0, 0};
-        while (l.ts.cur != NODE_END) { trace_step<false>(sc, l.ray, l.ts, &lc); shadow_early_out(l); }
-        return wf_hit_pack(l.ts);
-    };
     for (uint32_t sampling = s_begin; sampling < s_end; sampling += stride) {
         std::atomic<uint32_t> next{0};
         auto work = [&]() {
@@ -406,44 +470,8 @@ int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, 
                 for (uint32_t x = 0; x < W; x++) {
                     float sum[3] = {0, 0, 0};
                     for (uint32_t sub = 0; sub < 4; sub++) {
-                        ArrRec rec;
-                        Path p0;
-                        RenderParams rpp = rp;
-                        emu_place_path(rpp, W, H, x, y, sub, p0, rec);
-                        path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
-                        path_start(sc, rpp, p0, x, y, sub, rec.f);
-                        const float *prec = rec.f + rec.base;      // the path's record, as wf_rec_base() addresses it on the device
-                        WfPath p;
-                        p.pid = 0; p.st = wf_st(1u, true, (p0.q >> 12) & 15u, 0u); p.raybase = 0; p.cur_refl = 1.0f;
-                        p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
-                        std::vector<RayRec> rays{RayRec{p0.ray.o, WF_MAIN_RAY, p0.ray.d, 0.0f}}, nxt;
-                        LaneCounters lc = {0, 0, 0, 0, 0, 0};
-                        for (uint32_t step = 1;; step++) {
-                            std::vector<WfHitRec> hits;
-                            for (const RayRec &r : rays) hits.push_back(walk(r));
-                            const uint32_t ns = wf_shadow_rays(p);
-                            for (uint32_t k = 0; k < ns; k++) wf_contribute<false>(sc, p, hits[k], rays[k].o, rays[k].len, rays[k].d, rays[k].w, &lc);
-                            if (!wf_has_main(p)) break;
-                            p.refl = p.refl * p.cur_refl;
-                            WfBounce b;
-                            b.nee = false;
-                            if (wf_surface<false>(sc, p, prec, rays[ns].o, rays[ns].d, hits[ns], b, &lc)) break;
-                            nxt.clear();
-                            if (b.nee)
-                                for (uint32_t k = 0; k < sc.num_emitters; k++) {
-                                    V3f d; float len;
-                                    if (wf_nee_ray(sc, b, k, cull, d, len)) nxt.push_back(RayRec{b.next_o, len, d, wf_nee_weight(sc, b, k, d, len)});
-                                }
-                            const uint32_t ns_new = (uint32_t)nxt.size();
-                            const bool bounce = wf_bounces(p, b);
-                            if (!ns_new && !bounce) break;
-                            if (bounce) nxt.push_back(RayRec{b.next_o, WF_MAIN_RAY, b.next_d, 0.0f});
-                            p.st = wf_st(wf_iter(p) + (bounce ? 1u : 0u), bounce, wf_a2(p), ns_new);
-                            p.cur_refl = b.cur_refl;
-                            rays.swap(nxt);
-                            if (step > 10u) return;   // (cannot happen: nine iterations + one collecting step)
-                        }
-                        sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
+                        const V3f a = precise ? emu_wf_path<true, false>(sc, rp, W, H, x, y, sub, sampling, cull, nullptr) : emu_wf_path<false, false>(sc, rp, W, H, x, y, sub, sampling, cull, nullptr);
+                        sum[0] += a.x; sum[1] += a.y; sum[2] += a.z;
                     }
                     float *o = &acc[((size_t)y * W + x) * 3];
                     o[0] += sum[0]; o[1] += sum[1]; o[2] += sum[2];
@@ -454,6 +482,35 @@ int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, 
         for (int t = 0; t < nthreads; t++) th.emplace_back(work);
         for (auto &t : th) t.join();
     }
+    return 0;
+}
+// emu_path_log's layout from the split pipeline with precise shading
+extern "C" int emu_path_log_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, int nthreads, uint32_t *out) {
+    Scene sc = e->view;
+    sc.qnodes = nullptr;
+    RenderParams rp{};
+    rp.width = W; rp.height = H;
+    const uint32_t cull = (uint32_t)g_nee_cull & 7u;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            uint32_t y = next.fetch_add(1);
+            if (y >= H) break;
+            for (uint32_t x = 0; x < W; x++)
+                for (uint32_t sub = 0; sub < 4; sub++) {
+                    PathLog lg;
+                    plog_reset(lg);
+                    const V3f a = emu_wf_path<true, true>(sc, rp, W, H, x, y, sub, sampling, cull, &lg);
+                    uint32_t *o = out + (((size_t)y * W + x) * 4 + sub) * 8;
+                    o[0] = float_as_uint(a.x); o[1] = float_as_uint(a.y); o[2] = float_as_uint(a.z); o[3] = lg.rays;
+                    o[4] = (uint32_t)lg.ev; o[5] = (uint32_t)(lg.ev >> 32); o[6] = lg.ev9; o[7] = lg.hash;
+                }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+    for (auto &t : th) t.join();
     return 0;
 }
 

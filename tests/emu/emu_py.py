@@ -26,6 +26,8 @@ def lib():
         L.emu_raw_draws_seg.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_render_wf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.emu_path_log_wf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.emu_set_wf_precise.argtypes = [C.c_int]
         L.emu_path_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_render_debug.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -67,6 +69,14 @@ class EmuScene:
         acc = np.zeros((h, w, 3), dtype=np.float32)
         lib().emu_render_wf(self._h, w, h, s_begin, s_end, stride, threads, acc.ctypes.data)
         return acc
+
+    def path_log_wf(self, w, h, sampling, threads=0):
+        """path_log's layout from the split pipeline with PRECISE shading (wf_surface_f64)"""
+        raw = np.zeros((h, w, 4, 8), dtype=np.uint32)
+        lib().emu_path_log_wf(self._h, w, h, sampling, threads, raw.ctypes.data)
+        rad = raw[..., 0:3].copy().view(np.float32)
+        ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(h, w, 4, 12)[..., :12]
+        return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
 
     def path_log(self, w, h, sampling, threads=0):
         """(radiance [h, w, 4, 3] float32, rays, events [h, w, 4, 12] uint8 (nine event bytes, the count of sphere hits, the 16-bit texel-quad sum), element hash) — the layout of Renderer.debug_path_log"""
