@@ -121,7 +121,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="samplings per step per GPU; 0 (default) = BASELINE's headline: exactly 1,024 samplings per GPU spread over --steps steps, whatever --steps is")
+    ap.add_argument("--headline-samplings", type=int, default=1024, help="samplings per GPU of the default plan (BASELINE: 1024)")
+    ap.add_argument("--precise", action="store_true", help="option precise_shading: the split pipeline with the bounce geometry in f64 (DESIGN.md §4.5)")
     ap.add_argument("--total-samplings", type=int, default=0,
                     help="strong scaling: render exactly samplings 1..S in total, sharded over the GPUs and spread over --steps steps (BASELINE config 4: --gpus 8 --total-samplings 4096)")
     ap.add_argument("--batch", type=int, default=0, help="samplings per kernel launch (0 = the library's automatic choice: 4 at 1080p)")
@@ -143,7 +146,7 @@ def main():
     import numpy as np
     import torch
     import hanamaru_amd as ha
-    from hanamaru_amd.sharding import step_range, strong_plan, strong_step_range
+    from hanamaru_amd.sharding import headline_step_range, step_range, strong_plan, strong_step_range
 
     exit_code = 0
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,6 +188,17 @@ def main():
 
     W, H, SPS = args.width, args.height, args.spp_per_step
     S_TOTAL = args.total_samplings
+    # the default plan (neither --spp-per-step nor --total-samplings): the literal BASELINE configuration — samplings 1 .. 1024 per GPU
+    # in exactly --steps steps (steps differ by at most one sampling); more steps than samplings: one sampling per step
+    HEADLINE = 0
+    if not SPS and not S_TOTAL:
+        if args.steps <= args.headline_samplings:
+            HEADLINE = args.headline_samplings
+            SPS = -(-HEADLINE // args.steps)      # the largest step (for the record; steps hold SPS or SPS - 1 samplings)
+        else:
+            SPS = 1
+    elif not SPS:
+        SPS = 16
     if S_TOTAL:
         # strong scaling: a fixed total of samplings 1..S_TOTAL, whatever N is.  A step covers SPS * world consecutive sampling
         # indices as always; SPS is chosen so that --steps steps cover S_TOTAL, and the last step is clipped to it.
@@ -214,6 +228,8 @@ def main():
             r.set_option("max_tail_gib", args.max_tail_gib)
         if args.russian_roulette:
             r.set_option("russian_roulette", args.russian_roulette)
+        if args.precise:
+            r.set_option("precise_shading", 1)
         for kv in args.debug:
             k, v = kv.split("=")
             r.set_debug_option(k, float(v))
@@ -250,7 +266,10 @@ def main():
     def run_step(i):
         # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; rank g takes (s-1) % world == g
         for r, (g, _) in zip(rs, mine):
-            b, e, stride = strong_step_range(i, SPS, world, g, S_TOTAL) if S_TOTAL else step_range(i, SPS, world, g)   # --total-samplings: the last step ends at sampling S_TOTAL
+            if HEADLINE:
+                b, e, stride = headline_step_range(i, args.steps, HEADLINE, world, g)
+            else:
+                b, e, stride = strong_step_range(i, SPS, world, g, S_TOTAL) if S_TOTAL else step_range(i, SPS, world, g)   # --total-samplings: the last step ends at sampling S_TOTAL
             r.render(b, e, stride)
 
     def barrier():
@@ -341,7 +360,7 @@ def main():
     # ---- outside the timed region, rank 0: the post chain (renderer.rs:64-90 as two HIP kernels) on the all-reduced accumulator
     post = None
     if rank == 0 and not args.debug_skip:
-        n_s = S_TOTAL if S_TOTAL else SPS * world * args.steps
+        n_s = S_TOTAL if S_TOTAL else HEADLINE * world if HEADLINE else SPS * world * args.steps
         p0 = r0.stats()["post_kernel_ms"]
         tp0 = time.perf_counter()
         img = r0.resolve(max(1, n_s))
@@ -375,7 +394,7 @@ def main():
         trav = (tc, ts["debug_kernel_ms"] / max(1, ts["debug_launches"]))
 
     if rank == 0:
-        samplings_run = S_TOTAL if S_TOTAL else SPS * world * args.steps      # sampling indices 1..samplings_run, over all GPUs
+        samplings_run = S_TOTAL if S_TOTAL else HEADLINE * world if HEADLINE else SPS * world * args.steps      # sampling indices 1..samplings_run, over all GPUs
         total_paths = W * H * 4 * samplings_run
         assert sum(x["paths"] for x in per_rank) == total_paths, (per_rank, total_paths)
         value = total_paths / elapsed / 1e6
@@ -388,11 +407,13 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if S_TOTAL else "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
-            "config": {"workload": "%s %dx%d x %d samplings (x4 sub-samples = %d paths) in this run: %d steps x %d samplings per step per GPU x %d GPU(s)%s; "
-                                   "BASELINE's headline is the same image at 1024 samplings (--steps 64 at the default 16 per step), the rate does not depend on the count"
-                                   % (args.scene, W, H, samplings_run, total_paths, args.steps, SPS, world, (", last step clipped to --total-samplings %d" % S_TOTAL) if S_TOTAL else ""),
+            "config": {"workload": "%s %dx%d x %d samplings (x4 sub-samples = %d paths) in this run: %d steps x %s samplings per step per GPU x %d GPU(s)%s%s"
+                                   % (args.scene, W, H, samplings_run, total_paths, args.steps, ("%d or %d" % (SPS - 1, SPS)) if HEADLINE and HEADLINE % args.steps else str(SPS), world,
+                                      (", last step clipped to --total-samplings %d" % S_TOTAL) if S_TOTAL else "",
+                                      ("; the default plan: BASELINE's %d samplings per GPU whatever --steps is" % HEADLINE) if HEADLINE else ""),
+                       "shading": "precise_shading: split pipeline, bounce geometry in f64" if args.precise else "default: megakernel, fp32 shading",
                        "samplings_total": samplings_run, "paths_total": total_paths,
-                       "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": paths_per_step_gpu * world,
+                       "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": round(total_paths / args.steps) if HEADLINE else paths_per_step_gpu * world,
                        "parallelism": "spp-sharded x%d, one all-reduce (%s)" % (world, how), "devices": sorted(set(d for _, d in mine)) if not launcher else [local_rank],
                        "estimator": "reference (no Russian roulette)" if not args.russian_roulette else "NON-PARITY: Russian roulette from iteration %d" % args.russian_roulette},
             "rays_per_s_M": None,
@@ -419,6 +440,13 @@ def main():
                 "allreduces_per_rank": sorted(set(c["allreduces"] for c in comms)),
                 "source": "hr_comm_info() of every context after the timed region: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion as the communicator answers them"
                           if world > 1 and not one_device else ("single rank: no communicator, no collective" if world == 1 else "HR_BENCH_ONE_DEVICE debugging aid: torch.distributed gloo on a host copy, no RCCL")}
+        if world > 1 and not one_device and any(c["path"].startswith("rccl") for c in comms):
+            try:      # which RCCL build the collective ran on: ONE per process — the one the host (torch) had mapped, if any
+                lp, reused = ha.comm_library()
+                n_mapped = len({line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line})
+                rccl["library"] = {"path": lp, "reused_the_hosts": reused, "librccl_objects_mapped_in_this_process": n_mapped}
+            except (ha.HipError, OSError) as ex:
+                rccl["library"] = {"error": str(ex)}
         out["multi_gpu"]["rccl"] = rccl
         failures = []
         if not one_device:

@@ -1296,6 +1296,14 @@ int hr_comm_info(hr_ctx *c, hr_comm_info_t *out) {
     return HR_OK;
 }
 
+int hr_comm_library(char *path_out, size_t cap, int *reused_out) {
+    if (!path_out || !cap) return fail(HR_ERR_INVALID, "hr_comm_library: null argument");
+    if (!hrcomm::load()) return fail(HR_ERR_UNSUPPORTED, "%s", hrcomm::api().error.c_str());
+    snprintf(path_out, cap, "%s", hrcomm::api().path.c_str());
+    if (reused_out) *reused_out = hrcomm::api().reused ? 1 : 0;
+    return HR_OK;
+}
+
 // Sum of an accumulator in f64, per channel, on the device: sum_of(rank's own accumulators) == sum(all-reduced total) is the checksum of
 // the exchange (bench.py multi_gpu.checksum).  Deterministic: a fixed grid, every workgroup leaves its partial sums (waves in order), the
 // host adds the 1,024 partial sums in order — two contexts that hold the same total report the same sum to the last bit.

@@ -5,6 +5,8 @@
 // Included by hr_api.hip only.
 #pragma once
 #include <dlfcn.h>
+#include <link.h>
+#include <string.h>
 #include <hip/hip_runtime.h>
 
 namespace hrcomm {
@@ -29,6 +31,8 @@ struct Api {
     int (*CommCuDevice)(Comm, int *) = nullptr;
     int (*GetVersion)(int *) = nullptr;
     std::string error;
+    std::string path;     // the shared object ncclAllReduce was resolved from (dladdr)
+    bool reused = false;  // true: an RCCL that was already mapped into the process (the host's own — e.g. PyTorch's — build) was taken
 };
 
 inline Api &api() {
@@ -39,10 +43,26 @@ inline Api &api() {
 inline bool load() {
     Api &a = api();
     if (a.lib) return true;
+    // ONE RCCL per process.  A host that has its own RCCL mapped already (PyTorch ships torch/lib/librccl.so and maps it with libtorch_hip;
+    // under torch.distributed.run its NCCL backend runs on that build) must not get a second build beside it — two RCCL runtimes in one
+    // process, each with its own proxy threads and IPC handles, is the kind of thing that only fails on the first real 8-GPU run.  So:
+    // look for a mapped object called librccl* first and take THAT (RTLD_NOLOAD: a handle to what is there, nothing new is loaded).
+    {
+        std::string found;
+        dl_iterate_phdr([](struct dl_phdr_info *info, size_t, void *data) -> int {
+            const char *nm = info->dlpi_name;
+            if (nm && strstr(nm, "librccl")) { *static_cast<std::string *>(data) = nm; return 1; }
+            return 0;
+        }, &found);
+        if (!found.empty()) {
+            a.lib = dlopen(found.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            a.reused = a.lib != nullptr;
+        }
+    }
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
-        a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (a.lib) break;
+        a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!a.lib) { a.error = std::string("cannot load RCCL: ") + dlerror(); return false; }
     bool ok = true;
@@ -63,7 +83,9 @@ inline bool load() {
     a.CommUserRank = (int (*)(Comm, int *))sym("ncclCommUserRank");
     a.CommCuDevice = (int (*)(Comm, int *))sym("ncclCommCuDevice");
     a.GetVersion = (int (*)(int *))sym("ncclGetVersion");
-    if (!ok) { dlclose(a.lib); a.lib = nullptr; }
+    if (!ok) { dlclose(a.lib); a.lib = nullptr; return false; }
+    Dl_info di;
+    if (dladdr((void *)a.AllReduce, &di) && di.dli_fname) a.path = di.dli_fname;
     return ok;
 }
 

@@ -191,6 +191,18 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def comm_library():
+    """hr_comm_library: (path of the RCCL shared object the library's collective runs on, True when it reused one already mapped into the process)."""
+    L = hip_lib()
+    L.hr_comm_library.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    buf = C.create_string_buffer(4096)
+    reused = C.c_int(0)
+    rc = L.hr_comm_library(buf, 4096, C.byref(reused))
+    if rc != 0:
+        raise HipError(rc, L.hr_last_error().decode())
+    return buf.value.decode(), bool(reused.value)
+
+
 def comm_init_local(renderers):
     """One process driving several GPUs: ncclCommInitAll over the renderers' devices."""
     L = hip_lib()

@@ -29,3 +29,13 @@ def strong_step_range(step, samplings_per_rank, world, rank, total_samplings):
     """step_range with the end clipped to the total: hr_render(begin, end, stride) arguments (an empty range when begin >= end)."""
     b, e, s = step_range(step, samplings_per_rank, world, rank)
     return b, min(e, total_samplings + 1), s
+
+
+def headline_step_range(step, steps, per_gpu_total, world, rank):
+    """bench.py's default plan: exactly `per_gpu_total` samplings per GPU (BASELINE's 1,024) whatever --steps is.  Step i of K covers
+    the per-GPU sampling counts [floor(i*T/K), floor((i+1)*T/K)) — steps differ by at most one sampling — i.e. the 1-origin sampling
+    indices floor(i*T/K)*world + 1 .. floor((i+1)*T/K)*world over all GPUs, of which rank r takes those with (s-1) % world == r.
+    hr_render(begin, end, stride) arguments; requires steps <= per_gpu_total (every step renders at least one sampling per GPU)."""
+    lo = (step * per_gpu_total) // steps
+    hi = ((step + 1) * per_gpu_total) // steps
+    return lo * world + 1 + rank, hi * world + 1, world

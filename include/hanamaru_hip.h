@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 6
+#define HR_ABI_VERSION 7
 
 typedef enum hr_status {
     HR_OK = 0,
@@ -228,6 +228,11 @@ typedef struct hr_comm_info_t {
     uint64_t allreduces;
 } hr_comm_info_t;
 int hr_comm_info(hr_ctx *ctx, hr_comm_info_t *out);
+/* Which RCCL the library runs its collective on: the path of the shared object ncclAllReduce was resolved from (NUL-terminated into
+ * path_out, truncated to cap), *reused_out = 1 when an RCCL already mapped into the process was taken instead of loading another one —
+ * the library never puts a second RCCL build beside the host's (PyTorch maps its own torch/lib/librccl.so).  Loads RCCL if nothing has
+ * yet; HR_ERR_UNSUPPORTED (and the loader's message) when there is none. */
+int hr_comm_library(char *path_out, size_t cap, int *reused_out);
 /* Per-channel sum of an accumulator, in f64 on the device: which = 0 this context's own accumulator, 1 = the all-reduced total.
  * The checksum of the exchange: the ranks' own sums add up to the total's sum (to fp32 rounding of the all-reduce: ~1e-7 relative). */
 int hr_accumulator_sum(hr_ctx *ctx, int which, double out_rgb[3]);

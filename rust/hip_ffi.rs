@@ -61,13 +61,15 @@ extern "C" {
     pub fn hr_allreduce_accumulators(ctxs: *mut *mut HrCtx, n: c_int) -> c_int;
     pub fn hr_comm_destroy(ctx: *mut HrCtx) -> c_int;
     pub fn hr_comm_info(ctx: *mut HrCtx, out: *mut HrCommInfo) -> c_int;
+    /// the RCCL the library's collective runs on (path of the shared object; reused = 1: one that was already mapped, e.g. the host's own)
+    pub fn hr_comm_library(path_out: *mut c_char, cap: usize, reused_out: *mut c_int) -> c_int;
     /// which: 0 = this context's own accumulator, 1 = the all-reduced total; per-channel f64 sums (the checksum of the exchange)
     pub fn hr_accumulator_sum(ctx: *mut HrCtx, which: c_int, out_rgb: *mut f64) -> c_int;
 }
 
 // ---- GENERATED by tools/gen_rust_layout.py from include/hanamaru_hip.h: do not edit ----
 /// the ABI these mirrors were checked against (hr_abi_version() of the library must return it)
-pub const HR_ABI_VERSION: i32 = 6;
+pub const HR_ABI_VERSION: i32 = 7;
 const _: () = assert!(std::mem::size_of::<HrTexture>() == 32 && std::mem::align_of::<HrTexture>() == 8);   // hr_texture
 const _: () = assert!(std::mem::size_of::<HrMaterial>() == 112 && std::mem::align_of::<HrMaterial>() == 8);   // hr_material
 const _: () = assert!(std::mem::size_of::<HrImage>() == 16 && std::mem::align_of::<HrImage>() == 8);   // hr_image

@@ -78,6 +78,30 @@ def test_strong_scaling_plan_covers_exactly_the_total():
 
 
 @pytest.mark.timeout(300)
+def test_headline_plan_is_exactly_1024_samplings_per_gpu_for_any_step_count():
+    """bench.py's default plan (no --spp-per-step, no --total-samplings): BASELINE's 1,024 samplings per GPU in exactly --steps steps,
+    whatever --steps is — the driver's `--steps 20` renders samplings 1..1024, not 320 (main.rs:1249-1251: `-s` is the sampling count)."""
+    sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
+    from hanamaru_amd.sharding import headline_step_range
+    for world in (1, 2, 3, 8):
+        for steps in (1, 7, 20, 64, 333, 1000, 1024):
+            seen, per_rank = [], [0] * world
+            sizes = set()
+            for i in range(steps):
+                n_step = 0
+                for r in range(world):
+                    b, e, st = headline_step_range(i, steps, 1024, world, r)
+                    mine = list(range(b, e, st))
+                    assert all((s - 1) % world == r for s in mine)
+                    seen += mine
+                    per_rank[r] += len(mine)
+                    n_step += len(mine)
+                assert n_step % world == 0 and n_step >= world     # every rank the same count, at least one sampling per step
+                sizes.add(n_step // world)
+            assert sorted(seen) == list(range(1, 1024 * world + 1))
+            assert per_rank == [1024] * world and max(sizes) - min(sizes) <= 1
+
+
 def test_two_ranks_equal_one(tmp_path, emu, ha):
     world = 2
     out = str(tmp_path / "sum.npy")

@@ -1821,6 +1821,29 @@ def test_rccl_allreduce_of_the_accumulator(gpu, scenes, ha):
         gpu.allreduce_accumulator()            # no communicator any more
 
 
+def test_one_rccl_per_process(gpu, ha):
+    """PyTorch maps its own RCCL build (torch/lib/librccl.so) with libtorch_hip; under torch.distributed.run its NCCL backend runs on it.
+    The library must run its collective on THAT object, not load /opt/rocm's librccl beside it: hr_comm_library names what it resolved
+    ncclAllReduce from, and afterwards the process still maps exactly one librccl."""
+    import torch  # noqa: F401  (what bench.py and the launcher path import first)
+
+    def mapped():
+        return sorted({line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line})
+    before = mapped()
+    path, reused = ha.comm_library()
+    after = mapped()
+    assert os.path.exists(path) and "librccl" in os.path.basename(path)
+    assert len(after) == 1 and os.path.realpath(after[0]) == os.path.realpath(path), (before, after, path)
+    if before:      # torch had mapped one: that is the one in use
+        assert reused and os.path.realpath(before[0]) == os.path.realpath(path)
+    # the launcher path at world size 1 runs on it
+    gpu.comm_init_rank(ha.comm_unique_id(), 1, 0)
+    try:
+        assert gpu.comm_info()["nranks"] == 1 and mapped() == after
+    finally:
+        gpu.comm_destroy()
+
+
 def test_rccl_group_path_of_one_process_driving_its_gpus(scenes, ha):
     """The one-process form of the exchange — hr_comm_init_local + hr_allreduce_accumulators, what `python bench.py --gpus N` and the
     CLI's --gpus use on a multi-GPU node — with ONE context: n = 1 is not "all contexts on one device" (that needs two), so the
