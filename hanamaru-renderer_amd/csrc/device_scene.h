@@ -232,7 +232,7 @@ struct GovDev {
     // trace kernel is the faster kernel of the pair by a margin, every wave it does not need is a wave that does not take issue slots
     // from the seed kernel beside it: the headline runs 3 workgroups per CU instead of 4 and the seed kernel 4 % faster.
     uint32_t budget;                         // what trace kernels that start now obey
-    uint32_t bud[2];                         // the budget the trace kernel of each slot read
+    uint32_t bud[2];                         // the budget the trace kernel of each slot runs with, + 1 (0 = unset): fixed by its first wave, obeyed by all
     uint32_t budget_lo, budget_hi, budget_step;   // smallest budget, largest budget below "all", step (workgroups; set by the host from the CU count)
     uint32_t budget_moves;
 };
@@ -264,7 +264,7 @@ struct RenderParams {
     uint32_t ovf_cap;                 // seed kernels: entries of each consumer wave's fix-up list (sized per launch by hr_api.hip)
     uint32_t rr_start;                // trace kernel: Russian roulette from this iteration on (0 = off, the default: the reference has none)
     uint32_t gov_slot;                // parity of the launch: which slot of gov-> its two kernels stamp
-    uint32_t nee_cull_off;            // trace kernel: which of nee_setup's three shortcuts are switched OFF (bit 0 far side, 1 GGX below the horizon, 2 own sphere); 7 = trace every NEE shadow ray (debug option nee_cull: the A/B and the bit-equality test)
+    uint32_t nee_cull_off;            // trace kernel: which of nee_setup's two shortcuts are switched OFF (bit 0 far side, 1 GGX below the horizon; bit 2 reserved, nothing reads it); 7 = trace every NEE shadow ray (debug option nee_cull: the A/B and the bit-equality test)
     uint32_t tail_div;                // trace kernel: the last tiles / tail_div tiles of a launch are handed out one sampling at a time (0 = none): finer work units where the launch runs dry
     uint32_t wg_budget;               // trace kernel: workgroups with blockIdx.x >= wg_budget leave at once (0 = all stay) — debug option trace_budget
     GovDev *gov;                      // nullptr: no governor (debug kernels, host emulation) — trace_boost / pad[1] as given

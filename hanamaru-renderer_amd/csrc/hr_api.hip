@@ -119,7 +119,7 @@ struct hr_ctx {
     int seed_mode = 2;                       // 2 = three-run seed kernel (default), 1 = producer / consumer kernel with the state ring, 0 = fused seed kernel
     int seed_prof = 0;                       // phase timing build of the seed kernel (three-run kernel; ring kernel: splits 16 and 20)
     uint32_t seed_prio = 3;                  // s_setprio of the seed / round kernel's waves
-    uint32_t nee_cull = 7;                   // debug option nee_cull: mask of nee_setup's shortcuts in force (1 far side | 2 GGX below the horizon | 4 own sphere); 0 = trace every NEE shadow ray (bit-identical image, more rays)
+    uint32_t nee_cull = 7;                   // debug option nee_cull: mask of nee_setup's shortcuts in force (1 far side | 2 GGX below the horizon; bit 2 reserved); 0 = trace every NEE shadow ray (bit-identical image, more rays)
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
     // the split pipeline (wf_kernels.h): queues of the launch being traced, sized for the largest launch so far
@@ -208,7 +208,7 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
         // seed kernel; the priority levels only come into play with every workgroup in place.  Measured on the headline (1080p,
         // 256 CUs; trace / seed ms per launch): all 1,536 workgroups 19.4 / 25.3, 896 20.6 / 24.7, 768 22.0 / 24.4, 704 23.3 / 24.3,
         // 640 24.5 / 24.3 — the seed kernel gains what the trace kernel's waves no longer take, +3.5 % on the pair at 704 - 768.
-        const uint32_t B = g->bud[slot];
+        const uint32_t B = g->bud[slot] ? g->bud[slot] - 1u : ~0u;   // what every workgroup of the judged launch obeyed (stored + 1; unset: no trace kernel stamped it)
         // (a trace kernel far shorter than the seed kernel — the sphere scenes: 6 ms against 24 — never covers 70 % of a seed kernel, but that it
         // has workgroups to spare is beyond doubt: it is judged for the budget when it ran beside the next launch's seed kernel itself)
         const bool spare = trace_t < 0.7f * seed_t && ov_trace > 0.7f;
@@ -240,6 +240,7 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
     }
     if (r0 != none && r1 > r0) { g->prev_t0 = r0; g->prev_t1 = r1; }
     for (int k = 0; k < 2; k++) { g->t0[k][slot] = none; g->t1[k][slot] = 0; }
+    g->bud[slot] = 0;   // unset: the next launch in this slot fixes its own
     if (g->fixed >= 0) __hip_atomic_store(&g->level, g->fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // a new scene, resolution or option: the balance of the two kernels is another one.  The governor starts at level 0 — next to a trace

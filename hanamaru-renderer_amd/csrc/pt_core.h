@@ -650,7 +650,8 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
 
 // scene.rs:92-101 + renderer.rs:276-279: shadow ray toward the sample point on emitter path_emitter(p).
 // Returns false when the ray need not be traced at all, because its contribution is known to be exactly zero (round 5; `cull` = 0
-// switches the three shortcuts off: debug option nee_cull 0, the A/B and the bit-equality test; bit 0 = (1), bit 1 = (2), bit 2 = (3) — the
+// switches the shortcuts off: debug option nee_cull 0, the A/B and the bit-equality test; bit 0 = (1), bit 1 = (2); bit 2 is reserved — a third
+// shortcut, "the shaded sphere itself in the way", is exact too and was dropped: one more live register cost more than its rays gave — the
 // logging instantiation keeps (2) off, because the log records the visibility verdict of renderer.rs:280 also where the BSDF is zero):
 //   (1) the sample point lies on the FAR side of the emitter.  sample_on_surface draws uniformly over the whole sphere (scene.rs:92-101), so
 //       for more than half of the samples the shadow ray runs through the emitter itself before it reaches the sample: the closest hit of
@@ -663,10 +664,6 @@ HD void path_start(const Scene &sc, const RenderParams &rp, Path &p, uint32_t px
 //       Marginal samples (a chord of about 0.02: within 1.3 degrees of the silhouette of an r = 1 emitter) are traced as before.
 //   (2) GGX, emitter below the shaded point's horizon: material.rs:64-67 returns 0 (`l_dot_n.is_sign_negative()`), the contribution is
 //       emission * 0 — nothing is added whatever the shadow ray finds (bsdf_eval tests the same sign bit on the same two vectors).
-//   (3) the shaded point lies on a SPHERE and the emitter is below its horizon: the shadow ray starts OFFSET above the sphere and runs
-//       into it.  Same geometry as (1) from the other end: xo = (ro + OFFSET) (-n . d) is the distance from the origin to the closest
-//       approach, the ray enters the sphere (xo^2 > 2 ro OFFSET + OFFSET^2, with the same factor 2) at a distance of at most xo, and that
-//       hit is more than 0.0201 in front of the sample when L - xo > 0.0201 + slack.  own_r = 0: the shaded point is not on a sphere.
 // A culled ray is one the reference traces and then discards; the accumulator is the same to the bit (test_nee_culls_do_not_change_a_bit).
 HD bool nee_setup(const Scene &sc, Path &p, uint32_t cull) {
     const Emitter em = sc.emitters[path_emitter(p)];

@@ -121,10 +121,20 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uin
 template <bool CNT, int MINW, bool QN, bool RR = false, bool LOG = false>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter, uint32_t *plog = nullptr) {
     // the wave budget (device_scene.h GovDev::budget; debug option trace_budget pins it): surplus workgroups leave before they touch anything
+    // ONE budget per launch: the governor of the launch before may store a new one while this launch's workgroups are still starting, so the
+    // first wave to arrive fixes what it read in bud[slot] (compare-and-swap from "unset") and every other wave takes that — the governor then
+    // judges the launch by the budget all of its workgroups really obeyed.  Stored + 1: 0 = unset (governor_kernel resets it).
     {
         uint32_t budget = rp.wg_budget;
-        if (!budget && rp.gov) budget = __hip_atomic_load(&rp.gov->budget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (rp.gov && blockIdx.x == 0 && threadIdx.x == 0) rp.gov->bud[rp.gov_slot] = budget;
+        if (rp.gov) {
+            uint32_t fixed = 0;
+            if ((threadIdx.x & 63u) == 0u) {
+                const uint32_t want = (budget ? budget : __hip_atomic_load(&rp.gov->budget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+                const uint32_t prev = atomicCAS(&rp.gov->bud[rp.gov_slot], 0u, want);
+                fixed = prev ? prev : want;
+            }
+            budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)fixed) - 1u;
+        }
         if (budget && blockIdx.x >= budget) return;
     }
     const uint32_t lane = threadIdx.x & 63u;

@@ -1,10 +1,11 @@
 // hanamaru-hip — host driver with the reference binary's flag surface and outputs (main.rs:1226-1295,
 // renderer.rs:205-251): `hanamaru-hip -w W -h H -s S -t SEC -i SEC`.  Stand-in for the Rust host (no Rust
 // toolchain here): scene authoring + PNG writing stay on the host, the render loop calls the C ABI.
-// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N, --inflight K, --gpus N / --gpu-ids LIST,
+// Additive flags (do not change defaults): --scene NAME, --assets DIR, --batch N, --launch L, --inflight K, --precise, --gpus N / --gpu-ids LIST,
 // --checkpoint FILE (write the fp32 accumulator + sampling count when the render stops) and --resume FILE
 // (continue from such a file: samplings are independent and seeded by index, so a resumed render adds exactly
 // the samplings that are missing — SURVEY.md §8f rank 3; the reference has no resumable state).
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -49,7 +50,11 @@ static void usage(const char *prog) {
            "                        spheres | rtcamp6_dodeca | cornell_mini\n"
            "        --assets DIR    directory holding models/ and textures/ (default: ./assets, then .)\n"
            "        --batch N       samplings per progress report (default 1: one \"rendering:\" line per sampling, as the reference)\n"
-           "        --inflight K    reports' worth of work enqueued ahead on the GPU (default 8; 1 = wait for every report before the next starts)\n"
+           "        --launch L      reports per GPU launch (default 0: as many as fill the chip — 4 samplings per device at 1920x1080); the lines of a\n"
+           "                        launch are printed when it is done, its time split evenly over them; 1 = a launch per report\n"
+           "        --inflight K    launches enqueued ahead on the GPU (default 8; 1 = wait for every launch before the next starts)\n"
+           "        --precise       precise shading: the geometry of every bounce in f64 (hr_set_option \"precise_shading\"): closer to the reference's\n"
+           "                        f64 arithmetic on refraction chains and small spheres, a few per cent slower\n"
            "        --gpus N        render on devices 0..N-1 of this node from this one process: device r takes every N-th sampling,\n"
            "                        the accumulators are summed with one RCCL all-reduce when an image is written (default 1)\n"
            "        --gpu-ids LIST  the same with an explicit comma-separated device list\n"
@@ -64,8 +69,9 @@ int main(int argc, char **argv) {
     std::string scene_name = "rtcamp6_v3_1", assets, ckpt_out, ckpt_in, gpu_ids;
     int gpus = 1;
     int batch = 1;      // samplings per report_progress call ("rendering:" line); 1 = the reference's cadence
-    int inflight = 8;   // chunks enqueued ahead of the one being reported
-    bool debug = false;
+    int launch = 0;     // reports per GPU launch; 0 = as many as fill the chip (4 samplings per device at 1920x1080)
+    int inflight = 8;   // launches enqueued ahead of the one being reported
+    bool debug = false, precise = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -82,7 +88,9 @@ int main(int argc, char **argv) {
         else if (a == "--scene") scene_name = val("scene");
         else if (a == "--assets") assets = val("assets");
         else if (a == "--batch") batch = atoi(val("batch"));
+        else if (a == "--launch") launch = atoi(val("launch"));
         else if (a == "--inflight") inflight = atoi(val("inflight"));
+        else if (a == "--precise") precise = true;
         else if (a == "--gpus") gpus = atoi(val("gpus"));
         else if (a == "--gpu-ids") gpu_ids = val("gpu-ids");
         else if (a == "--checkpoint") ckpt_out = val("checkpoint");
@@ -90,6 +98,7 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "Unrecognized option: '%s'.\n", a.c_str()); return 1; }
     }
     if (batch < 1) { fprintf(stderr, "--batch must be at least 1.\n"); return 1; }
+    if (launch < 0) { fprintf(stderr, "--launch must be at least 1 (or 0: automatic).\n"); return 1; }
     if (inflight < 1) { fprintf(stderr, "--inflight must be at least 1.\n"); return 1; }
     if (width == 0 || height == 0) { fprintf(stderr, "width and height must be positive.\n"); return 1; }
     if (gpus < 1) { fprintf(stderr, "--gpus must be at least 1.\n"); return 1; }
@@ -128,6 +137,7 @@ int main(int argc, char **argv) {
         CHECK_HR(hr_create(devices[r], &ctxs[r]));
         CHECK_HR(hr_upload_scene(ctxs[r], hh_scene_desc(scene)));
         CHECK_HR(hr_set_resolution(ctxs[r], width, height));
+        if (precise) CHECK_HR(hr_set_option(ctxs[r], "precise_shading", 1.0));
     }
     hr_ctx *ctx = ctxs[0];
     if (ndev > 1) tee("devices: %u.", ndev);
@@ -200,54 +210,78 @@ int main(int argc, char **argv) {
         sampled = 1;
         sampling = 0;
     }
-    // Renderer::render's loop with report_progress (renderer.rs:32-43, 205-251).  A chunk = `--batch` samplings = one "rendering:" line;
-    // the default, --batch 1, is the reference's own cadence: one line per sampling.  What is reported and what is launched are two
-    // things: up to `--inflight` chunks are enqueued ahead (hr_render only enqueues; hr_mark behind every chunk, hr_wait for the oldest),
-    // so the GPU never drains between progress lines.  report_progress's three rules keep their order and their meaning:
-    //   * time limit (renderer.rs:222-231: stop when used + 1.1 x last > limit).  The reference asks this after a sampling, before it
-    //     starts the next; here the question is asked when a chunk is ISSUED, for the moment that chunk would finish: it is issued only
-    //     if used + 1.1 x last x (chunks in flight + 1) <= limit.  With one chunk in flight at a time (-i 0, or --inflight 1) that is the
-    //     reference's rule to the letter; with k in flight it looks k chunks ahead — the render stops at the same sampling the
-    //     reference's prediction would have stopped at had `last` not changed meanwhile, never later.  When the chunks in flight have
-    //     been reported and none may follow, the final image is written: "reached time limit" if the rule says so, else "reached max
-    //     sampling" (in that order, renderer.rs:222-241).
-    //   * progress image (renderer.rs:243-251): when the interval has passed at a report, the chunks in flight are awaited and reported
-    //     first, so that the image holds exactly the samplings of the "rendering:" line before it, as in the reference (one pipeline
-    //     drain per image).  An interval of 0 asks for an image after every report: the loop then keeps one chunk in flight, and
-    //     `-s 5 -i 0` prints and writes exactly what the reference does — 000.png .. 003.png after samplings 1 .. 4, final 004.png.
-    struct Chunk { uint32_t begin, end; std::vector<uint64_t> ticket; };
-    std::vector<Chunk> q;     // issued, not yet reported; oldest first
+    // Renderer::render's loop with report_progress (renderer.rs:32-43, 205-251).  What is REPORTED and what is LAUNCHED are two things:
+    //   * a REPORT = `--batch` samplings = one "rendering:" line; the default, --batch 1, is the reference's own cadence: a line per sampling;
+    //   * the GPU is fed LAUNCHES of whole reports — `--launch` of them, by default as many as fill the chip (4 samplings per device at
+    //     1920x1080: one kernel launch per sampling costs 3 - 8 % of the rate) — and up to --inflight launches are enqueued ahead
+    //     (hr_render only enqueues; hr_mark behind every launch, hr_wait for the oldest), so the GPU never drains between progress lines.
+    //     When a launch is done its reports are printed together: the launch's wall time is split EVENLY over their lines (said once in the log).
+    // report_progress's three rules keep their order and their meaning:
+    //   * time limit (renderer.rs:222-231: stop when used + 1.1 x last > limit, `last` = seconds per report).  The reference asks this after
+    //     a sampling, before it starts the next; here the question is asked when reports are ISSUED, for the moment they would finish: n
+    //     reports are issued only if used + 1.1 x last x (reports in flight + n) <= limit, and a launch shrinks to the n that still fits
+    //     (down to one report).  With one report in flight at a time (-i 0, or --launch 1 --inflight 1) that is the reference's rule to the
+    //     letter.  When everything in flight has been reported and nothing may follow, the final image is written: "reached time limit"
+    //     if the rule says so, else "reached max sampling" (in that order, renderer.rs:222-241).
+    //   * progress image (renderer.rs:243-251): asked at launch boundaries (the accumulator holds whole launches); when the interval has
+    //     passed, the launches in flight are awaited and reported first, so that the image holds exactly the samplings of the
+    //     "rendering:" line before it, as in the reference (one pipeline drain per image).  An interval of 0 asks for an image after
+    //     every report: launches are then one report long, one in flight, and `-s 5 -i 0` prints and writes exactly what the
+    //     reference does — 000.png .. 003.png after samplings 1 .. 4, final 004.png.
+    struct Launch { uint32_t begin, end; double issued; std::vector<uint64_t> ticket; };
+    std::vector<Launch> q;     // issued, not yet reported; oldest first
     uint32_t next_s = first;
-    auto issue = [&]() -> int {
-        Chunk c;
+    const uint32_t B = (uint32_t)batch;
+    uint32_t lrep = launch > 0 ? (uint32_t)launch : 0;   // reports per launch
+    if (!lrep) {   // as many reports as make the library's own automatic launch size (hanamaru_hip.h "batch": about 33 M paths) on every device
+        const uint64_t per_sampling = ((uint64_t)(width + 3) / 4) * ((height + 3) / 4) * 64u;
+        const uint64_t lsize = std::min<uint64_t>(64, std::max<uint64_t>(4, (33177600ull + per_sampling - 1) / per_sampling));
+        lrep = (uint32_t)std::max<uint64_t>(1, lsize * ndev / B);
+    }
+    if (interval <= 0.0) lrep = 1;
+    if (lrep > 1 && !debug) printf("launches of %u reports (%u samplings): a launch's time is split evenly over its reports' lines.\n", lrep, lrep * B);
+    uint32_t in_flight = 0;   // reports issued, not yet printed
+    auto reports_of = [&](uint32_t b, uint32_t e) { return (e - b + B - 1) / B; };
+    auto issue = [&](uint32_t nrep) -> int {
+        Launch c;
         c.begin = next_s;
-        c.end = next_s + (uint32_t)batch;
-        if (c.end > sampling + 1) c.end = sampling + 1;
+        c.end = (uint64_t)next_s + (uint64_t)nrep * B > (uint64_t)sampling + 1 ? sampling + 1 : next_s + nrep * B;
+        c.issued = now_sec();
         c.ticket.assign(ndev, 0);
         for (uint32_t r = 0; r < ndev; r++) {
-            // device r of N renders the samplings with (s - 1) mod N == r, whatever the chunk's first sampling is — a chunk
+            // device r of N renders the samplings with (s - 1) mod N == r, whatever the launch's first sampling is — a launch
             // shorter than N leaves some devices without work, their marker is then reached at once
             const uint32_t b = c.begin + (r + ndev - (c.begin - 1u) % ndev) % ndev;
             if (hr_render(ctxs[r], b, c.end, ndev) != 0 || hr_mark(ctxs[r], &c.ticket[r]) != 0) { fprintf(stderr, "hr_render: %s\n", hr_last_error()); return 1; }
         }
         next_s = c.end;
+        in_flight += reports_of(c.begin, c.end);
         q.push_back(c);
         return 0;
     };
-    double chunk_sec = 0.0;   // `from_last_sampling_sec` of the last report (0 = nothing reported yet)
+    bool measured = false;    // has any launch been reported?  (a measured zero is a measurement)
+    double last = 0.0;        // `from_last_sampling_sec`: seconds per report of the last launch reported
     double used = 0.0;
-    // wait for the oldest chunk in flight and print its line (renderer.rs:206-214)
+    // wait for the oldest launch in flight and print its reports' lines (renderer.rs:206-214)
     auto report = [&]() -> int {
-        const Chunk c = q.front();
+        const Launch c = q.front();
         q.erase(q.begin());
         for (uint32_t r = 0; r < ndev; r++)
             if (hr_wait(ctxs[r], c.ticket[r]) != 0) { fprintf(stderr, "hr_wait: %s\n", hr_last_error()); return 1; }
-        sampled = c.end - 1;
         const double now = now_sec();
-        used = now - begin;
-        chunk_sec = now - last_progress;
+        const uint32_t n = reports_of(c.begin, c.end);
+        // the launch's own time: from the previous report (the pipeline is full: launches finish back to back), or from its issue if that is later
+        const double t0 = std::max(last_progress, c.issued);
+        last = (now - t0) / (double)n;
+        measured = true;
+        for (uint32_t j = 0; j < n; j++) {
+            sampled = std::min(c.begin + (j + 1) * B, c.end) - 1;
+            used = t0 + last * (double)(j + 1) - begin;
+            printf("rendering: %ux4 sampled (last %.3f sec). total: %.3f sec (%.2f %%).\n", sampled, last, used, used / time_limit * 100.0);
+        }
+        in_flight -= n;
         last_progress = now;
-        printf("rendering: %ux4 sampled (last %.3f sec). total: %.3f sec (%.2f %%).\n", sampled, chunk_sec, used, used / time_limit * 100.0);
+        used = now - begin;
         return 0;
     };
     // renderer.rs:222-241: the final image takes the current counter
@@ -259,14 +293,16 @@ int main(int argc, char **argv) {
         printf("remain: %.3f sec.\n", time_limit - used);
         return save(sampled);
     };
-    // may another chunk be enqueued?  (samplings left, room in the pipeline, and the time-limit rule asked for the moment it would finish)
-    // (with N devices a chunk of one sampling is work for ONE of them: N times as many chunks are kept in flight, and an interval of 0 keeps
-    // one per device — the images then come after every N-th report; the reference has no multi-GPU form to be faithful to)
-    const size_t depth = (interval <= 0.0 ? 1 : (size_t)inflight) * (size_t)ndev;
-    auto may_issue = [&]() -> bool {
-        if (next_s > sampling || q.size() >= depth) return false;
-        if (chunk_sec <= 0.0) return true;   // nothing measured yet: fill the pipeline
-        return (now_sec() - begin) + 1.1 * chunk_sec * (double)(q.size() + 1) <= time_limit;
+    // how many reports may be enqueued now?  (samplings left, room in the pipeline, and the time-limit rule asked for the moment they would finish)
+    const size_t depth = interval <= 0.0 ? 1 : (size_t)inflight;
+    auto may_issue = [&]() -> uint32_t {
+        if (next_s > sampling || q.size() >= depth) return 0;
+        const uint32_t n = std::min<uint32_t>(lrep, reports_of(next_s, sampling + 1));
+        if (!measured) return n;   // nothing measured yet: fill the pipeline
+        const double room = time_limit - (now_sec() - begin);
+        const double fit = last > 0.0 ? room / (1.1 * last) - (double)in_flight : (room >= 0.0 ? (double)n : 0.0);
+        if (fit < 1.0) return 0;
+        return fit < (double)n ? (uint32_t)fit : n;
     };
     if (first > sampling && !debug && sampled > 0) {   // resumed from a checkpoint that already holds every requested sampling: just resolve it
         printf("reached max sampling\n");
@@ -274,17 +310,17 @@ int main(int argc, char **argv) {
     }
     bool running = first <= sampling;
     while (running) {
-        while (may_issue()) if (issue()) return 1;
+        for (uint32_t n; (n = may_issue()) != 0;) if (issue(n)) return 1;
         if (q.empty()) {   // nothing in flight and nothing may follow: the render ends here (renderer.rs:222-241, the time limit asked first)
             // (samplings left over: only the time-limit rule can have refused them)
-            if (finish(next_s <= sampling || used + 1.1 * chunk_sec > time_limit ? "reached time limit" : "reached max sampling")) return 1;
+            if (finish(next_s <= sampling || used + 1.1 * last > time_limit ? "reached time limit" : "reached max sampling")) return 1;
             break;
         }
         if (report()) return 1;
         if (last_progress - last_image >= interval) {   // renderer.rs:243-251, with the `now` of the report
-            while (!q.empty()) if (report()) return 1;   // the chunks in flight: the image then holds exactly the samplings reported
+            while (!q.empty()) if (report()) return 1;   // the launches in flight: the image then holds exactly the samplings reported
             // nothing is in flight now: the reference's own rules apply as they stand, in their order (renderer.rs:222-241)
-            if (used + 1.1 * chunk_sec > time_limit) { if (finish("reached time limit")) return 1; break; }
+            if (used + 1.1 * last > time_limit) { if (finish("reached time limit")) return 1; break; }
             if (sampled >= sampling) { if (finish("reached max sampling")) return 1; break; }
             for (uint32_t r = 0; r < ndev; r++) CHECK_HR(hr_synchronize(ctxs[r]));
             printf("output progress image: %03u.png\n", counter);

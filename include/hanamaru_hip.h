@@ -129,7 +129,7 @@ typedef struct hr_stats {
      * trace kernel's box and leaf phases first), launches it has judged since the last scene / resolution / option change, level changes */
     uint64_t governor_level, governor_decisions, governor_moves;
     /* counters build: NEE shadow rays the reference traces and discards, which the kernel knows to add nothing before it traces them
-     * (sample on the emitter's far side; GGX with the emitter below the horizon; the shaded sphere itself in the way) — not in `rays` */
+     * (sample on the emitter's far side; GGX with the emitter below the horizon) — not in `rays` */
     uint64_t shadow_culled;
     /* the governor's wave budget: how many of the trace kernel's persistent workgroups stay (0 = all of them) — fewer where the trace
      * kernel is the faster kernel of the pair and its surplus waves only slow the seed kernel beside it —, and how often it changed */

@@ -23,7 +23,7 @@ extern "C" {
  * (phase timing build of the seed kernel -> hr_stats.seed_phase_cycles; seed_mode 3: 1 | 2 | 3 = consumer 0, consumer 1, producer 0), "ploc_top" (bvh_builder 2: clusters the bottom-up merges
  * leave for the top-down build over them; 1 = merge to the root; takes effect at the next hr_upload_scene), "debug_skip" (bit mask that drops parts of the pipeline
  * for timing experiments: THE IMAGE IS GARBAGE), "nee_cull" (mask of pt_core.h nee_setup's shortcuts in force: 1 = far side of the emitter, 2 = GGX below the
- * horizon, 4 = the shaded sphere in the way; default 7; 0 = trace every NEE shadow ray — the bit-identical A/B of the shortcuts). */
+ * horizon; bit 2 is reserved — a third shortcut was measured and dropped, DESIGN.md §4.2 —; default 7; 0 = trace every NEE shadow ray — the bit-identical A/B of the shortcuts). */
 int hr_set_debug_option(hr_ctx *ctx, const char *key, double value);
 
 /* ---- unit-level entry points used by the parity tests (same kernels' device functions) ---- */

@@ -77,14 +77,18 @@ impl Flat {
 }
 
 impl HipRenderer {
-    fn used(&self) -> f64 { (time::now() - self.begin).num_milliseconds() as f64 * 0.001 }
-    fn since_last_report(&self) -> f64 { (time::now() - self.last_report_progress).num_milliseconds() as f64 * 0.001 }
-    fn image_due(&self) -> bool { (time::now() - self.last_report_image).num_milliseconds() as f64 * 0.001 >= self.report_interval_sec }
-    /// the "rendering:" line of renderer.rs:211-214 alone (for the samplings that are reported on the way to a progress image)
-    fn report_line(&mut self, sampling: u32) {
-        let (used, last) = (self.used(), self.since_last_report());
-        println!("rendering: {}x{} sampled (last {:.3} sec). total: {:.3} sec ({:.2} %).", sampling, config::SUPERSAMPLING * config::SUPERSAMPLING, last, used, used / self.time_limit_sec * 100.0);
-        self.last_report_progress = time::now();
+    fn secs(t: time::Tm, since: time::Tm) -> f64 { (t - since).num_milliseconds() as f64 * 0.001 }
+    /// renderer.rs:222-251 once nothing is in flight: writes the image the rule asks for.  `why`: Some(..) = final image (the render ends).
+    fn write_image(&mut self, why: Option<&str>, sampling: u32, used: f64, imgbuf: &mut ImageBuffer<Rgb<u8>, Vec<u8>>) {
+        let path = format!("{:>03}.png", self.report_image_counter);
+        match why {
+            Some(w) => { println!("{}", w); println!("output final image: {}", path); println!("remain: {:.3} sec.", self.time_limit_sec - used); }
+            None => println!("output progress image: {}", path),
+        }
+        check(unsafe { hr_synchronize(self.ctx) });
+        check(unsafe { hr_resolve(self.ctx, sampling, imgbuf.as_mut_ptr()) }); // RGB8, row-major, top row first
+        let _ = image::ImageRgb8(imgbuf.clone()).save(&path);
+        if why.is_none() { self.report_image_counter += 1; }
     }
     pub fn new(sampling: u32, time_limit_sec: f64, report_interval_sec: f64) -> HipRenderer {
         // the #[repr(C)] mirrors of hip_ffi.rs were generated for this ABI (their sizes are compile-time assertions there)
@@ -147,39 +151,80 @@ impl Renderer for HipRenderer {
         // main.rs:1216 always passes a BvhScene; the trait object needs `fn as_bvh_scene(&self) -> &BvhScene` (one line in scene.rs)
         self.upload(scene.as_bvh_scene(), camera);
         check(unsafe { hr_set_resolution(self.ctx, imgbuf.width(), imgbuf.height()) });
-        // renderer.rs:32-43 with the samplings pipelined: one sampling per report as in the reference, up to IN_FLIGHT of them enqueued
-        // ahead (hr_mark behind each, hr_wait for the oldest).  The three rules of report_progress keep their order; the time-limit rule
-        // (renderer.rs:222-231) is asked when a sampling is ISSUED, for the moment it would finish — exactly the reference's rule with one
-        // sampling in flight (report_interval_sec <= 0 keeps it at one: an image is due after every report).  A progress image holds
-        // exactly the samplings reported: the ones in flight are awaited and reported first.  (hanamaru-hip's cli_main.cpp is this loop,
-        // compiled and tested.)
+        // renderer.rs:32-43 with report_progress (renderer.rs:205-251) — the loop of hanamaru-hip's cli_main.cpp (compiled and tested there),
+        // statement for statement.  Every sampling gets its own "rendering:" line; the GPU is fed LAUNCHES of `lrep` samplings (what fills the
+        // chip: 4 at 1920x1080) and up to IN_FLIGHT launches are enqueued ahead (hr_mark behind each, hr_wait for the oldest).  A launch's lines
+        // are printed when it is done, its wall time split evenly over them.  The time-limit rule (renderer.rs:222-231) is asked when samplings
+        // are ISSUED, for the moment they would finish: n are issued only if used + 1.1 x last x (in flight + n) <= limit — with one sampling
+        // in flight (report_interval_sec <= 0: an image is due after every report) the reference's rule to the letter.  A progress image is
+        // written at a launch boundary, after the launches in flight have been reported: it holds exactly the samplings of the line before it.
+        let per_sampling = ((imgbuf.width() as u64 + 3) / 4) * ((imgbuf.height() as u64 + 3) / 4) * 64;
+        let lrep: u32 = if self.report_interval_sec <= 0.0 { 1 } else { ((33_177_600 + per_sampling - 1) / per_sampling).max(4).min(64) as u32 };
         let depth = if self.report_interval_sec <= 0.0 { 1 } else { IN_FLIGHT };
-        let mut tickets: std::collections::VecDeque<(u32, u64)> = std::collections::VecDeque::new();
-        let (mut next, mut done, mut last) = (1u32, 0u32, 0.0f64);
+        if lrep > 1 { println!("launches of {} reports ({} samplings): a launch's time is split evenly over its reports' lines.", lrep, lrep); }
+        struct Launch { begin: u32, end: u32, issued: time::Tm, ticket: u64 }
+        let mut q: std::collections::VecDeque<Launch> = std::collections::VecDeque::new();
+        let (mut next, mut done, mut in_flight) = (1u32, 0u32, 0u32);
+        let (mut measured, mut last, mut used) = (false, 0.0f64, 0.0f64);
+        let spp = config::SUPERSAMPLING * config::SUPERSAMPLING;
         loop {
-            while next <= self.sampling && tickets.len() < depth && (last <= 0.0 || self.used() + 1.1 * last * (tickets.len() + 1) as f64 <= self.time_limit_sec) {
+            // issue: samplings left, room in the pipeline, and the time-limit rule asked for the moment they would finish
+            loop {
+                if next > self.sampling || q.len() >= depth { break; }
+                let mut n = lrep.min(self.sampling + 1 - next);
+                if measured {
+                    let room = self.time_limit_sec - Self::secs(time::now(), self.begin);
+                    let fit = if last > 0.0 { room / (1.1 * last) - in_flight as f64 } else if room >= 0.0 { n as f64 } else { 0.0 };
+                    if fit < 1.0 { break; }
+                    if fit < n as f64 { n = fit as u32; }
+                }
                 let mut t = 0u64;
-                check(unsafe { hr_render(self.ctx, next, next + 1, 1) });
+                check(unsafe { hr_render(self.ctx, next, next + n, 1) });
                 check(unsafe { hr_mark(self.ctx, &mut t) });
-                tickets.push_back((next, t));
-                next += 1;
+                q.push_back(Launch { begin: next, end: next + n, issued: time::now(), ticket: t });
+                next += n;
+                in_flight += n;
             }
-            let (s, t) = match tickets.pop_front() { Some(x) => x, None => break };
-            check(unsafe { hr_wait(self.ctx, t) });
-            done = s;
-            let nothing_follows = tickets.is_empty() && (next > self.sampling || self.used() + 1.1 * self.since_last_report() > self.time_limit_sec);
-            let image_due = self.image_due();
-            if image_due && !nothing_follows {          // drain first: the image then holds exactly the samplings reported
-                self.report_line(done);
-                while let Some((s2, t2)) = tickets.pop_front() { check(unsafe { hr_wait(self.ctx, t2) }); done = s2; if !tickets.is_empty() { self.report_line(done); } }
+            // nothing in flight and nothing may follow: the render ends here (renderer.rs:222-241, the time limit asked first)
+            let c = match q.pop_front() {
+                Some(c) => c,
+                None => {
+                    let why = if next <= self.sampling || used + 1.1 * last > self.time_limit_sec { "reached time limit" } else { "reached max sampling" };
+                    self.write_image(Some(why), done, used, imgbuf);
+                    return done;
+                }
+            };
+            // report: wait for the oldest launch and print its samplings' lines (renderer.rs:206-214)
+            let mut report = |c: Launch, me: &mut HipRenderer, done: &mut u32, used: &mut f64, last: &mut f64, in_flight: &mut u32| {
+                check(unsafe { hr_wait(me.ctx, c.ticket) });
+                let now = time::now();
+                let n = c.end - c.begin;
+                let t0 = if c.issued > me.last_report_progress { c.issued } else { me.last_report_progress };
+                *last = Self::secs(now, t0) / n as f64;
+                for j in 0..n {
+                    *done = c.begin + j;
+                    *used = Self::secs(t0, me.begin) + *last * (j + 1) as f64;
+                    println!("rendering: {}x{} sampled (last {:.3} sec). total: {:.3} sec ({:.2} %).", *done, spp, *last, *used, *used / me.time_limit_sec * 100.0);
+                }
+                *in_flight -= n;
+                me.last_report_progress = now;
+                *used = Self::secs(now, me.begin);
+            };
+            report(c, self, &mut done, &mut used, &mut last, &mut in_flight);
+            measured = true;
+            if Self::secs(self.last_report_progress, self.last_report_image) >= self.report_interval_sec {   // renderer.rs:243-251, with the `now` of the report
+                while let Some(c2) = q.pop_front() { report(c2, self, &mut done, &mut used, &mut last, &mut in_flight); }
+                // nothing is in flight now: the reference's own rules apply as they stand, in their order (renderer.rs:222-241)
+                if used + 1.1 * last > self.time_limit_sec { self.write_image(Some("reached time limit"), done, used, imgbuf); return done; }
+                if done >= self.sampling { self.write_image(Some("reached max sampling"), done, used, imgbuf); return done; }
+                self.write_image(None, done, used, imgbuf);
+                self.last_report_image = self.last_report_progress;     // `now` of the report that triggered it (renderer.rs:250)
             }
-            last = self.since_last_report();
-            if self.report_progress(&Vec::new(), done, imgbuf) { return done; }   // prints the line, applies the three rules, writes images
         }
-        done
     }
 
-    // renderer.rs:205-251 with update_imgbuf (renderer.rs:64-90) replaced by hr_resolve
+    // renderer.rs:205-251: the trait asks for it; the loop above applies its three rules itself (it has to ask the time-limit rule at issue
+    // time and to report a launch's samplings together), so nothing calls this.  Kept for a caller that drives samplings one by one.
     fn report_progress(&mut self, _acc: &Vec<Vector3>, sampling: u32, imgbuf: &mut ImageBuffer<Rgb<u8>, Vec<u8>>) -> bool {
         let now = time::now();
         let used = (now - self.begin).num_milliseconds() as f64 * 0.001;

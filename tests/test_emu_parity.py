@@ -455,7 +455,7 @@ def test_per_path_event_log(emu_scenes, name, w, h):
 
 @pytest.mark.parametrize("name", ["rtcamp6_v3_1", "rtcamp6_v2", "tbf3", "rtcamp5", "spheres", "cornell_mini", "material_examples"])
 def test_nee_culls_do_not_change_a_bit(emu, emu_scenes, name):
-    """The shadow rays nee_setup does not trace (sample on the emitter's far side, GGX below the horizon, the shaded sphere in the way) are
+    """The shadow rays nee_setup does not trace (sample on the emitter's far side, GGX below the horizon) are
     rays the reference traces and discards (renderer.rs:279-280): with the shortcuts off the per-lane code renders the same accumulator,
     bit for bit, from more rays."""
     _, _, e = emu_scenes(name)
