@@ -795,14 +795,16 @@ def test_cli_progress_images_at_the_report_interval(tmp_path, scenes, orc):
     for k in range(5):
         _crops_match_oracle(np.asarray(Image.open(sub / ("%03d.png" % k))), o, orc, W, H, k + 1, [(30, 20)])
     assert np.array_equal(np.asarray(Image.open(sub / "004.png")), np.asarray(Image.open(sub / "result.png"))) and not (sub / "005.png").exists()
-    # an interval that passes now and then while eight samplings are in flight: every image is written after the samplings in flight were
+    # an interval that passes now and then while eight launches are in flight: every image is written after the samplings in flight were
     # reported, and holds exactly the samplings of the "rendering:" line before it
     sub = tmp_path / "pipe"
     sub.mkdir()
-    out = _run_cli(sub, ["-w", 320, "-h", 180, "-s", 600, "-t", "1000", "-i", "0.1"])
+    # (round 6: a launch holds 64 samplings at this size — the lines still come one per sampling — so the render is made long enough
+    # for the interval to pass between launches several times)
+    out = _run_cli(sub, ["-w", 320, "-h", 180, "-s", 4000, "-t", "1000", "-i", "0.1"])
     events = re.findall(r"rendering: (\d+)x4 sampled \(last|output (progress|final) image: (\d+)\.png", out)
     seq = [("r", int(e[0])) if e[0] else (e[1][0], int(e[2])) for e in events]
-    assert [x[1] for x in seq if x[0] == "r"] == list(range(1, 601)) and seq[-1][0] == "f" and seq[-2] == ("r", 600)
+    assert [x[1] for x in seq if x[0] == "r"] == list(range(1, 4001)) and seq[-1][0] == "f" and seq[-2] == ("r", 4000)
     prog = [(i, x[1]) for i, x in enumerate(seq) if x[0] == "p"]
     assert len(prog) >= 1 and [k for _, k in prog] == list(range(len(prog))) and seq[-1][1] == len(prog)
     i, k = prog[len(prog) // 2]
