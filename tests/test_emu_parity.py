@@ -492,6 +492,26 @@ def test_split_pipeline_is_the_same_arithmetic(emu, emu_scenes, name):
     assert np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("name,fp32_at_least,precise_at_most", [("rtcamp6_v2", 400.0, 40.0), ("spheres", 20.0, 40.0), ("material_examples", 0.0, 15.0)])
+def test_precise_shading_closes_the_same_branch_tail(emu, emu_scenes, name, fp32_at_least, precise_at_most):
+    """Option precise_shading on the host: csrc/wf_core.h wf_surface_f64 — hit distance, hit point, normal, mirror / Snell / Fresnel and the
+    sampled lobe directions in f64, the ray carried as fp32 + residual — driven path by path against the oracle's path log.  The paths that
+    take the oracle's branches and still differ by more than 1e-3 (refraction chains through faceted glass, bounces off r = 0.1 spheres)
+    all but vanish, and fewer paths diverge; ray counts stay equal.  (GPU: test_per_path_parity_accounting_precise_shading.)"""
+    import path_parity
+    sc, o, e = emu_scenes(name)
+    w, h = 128, 72
+    ref = o.path_log(w, h, 1)
+    a32 = path_parity.account(e.path_log(w, h, 1), ref)
+    a64 = path_parity.account(e.path_log_wf(w, h, 1), ref)
+    s32, s64 = a32["same_branch"], a64["same_branch"]
+    print("%s: fp32 divergent %.0f ppm, same-branch beyond 1e-3 %.0f ppm (worst %.3g); precise %.0f / %.0f ppm (worst %.3g)" % (
+        name, a32["divergent_ppm"], s32["over_1e-3_floor1_ppm"], s32["max_rel_floor1"], a64["divergent_ppm"], s64["over_1e-3_floor1_ppm"], s64["max_rel_floor1"]))
+    assert s64["rays_equal"] and s32["over_1e-3_floor1_ppm"] >= fp32_at_least and s64["over_1e-3_floor1_ppm"] <= precise_at_most
+    assert a64["divergent_ppm"] <= a32["divergent_ppm"] + 30.0 and s64["over_1e-4_floor1_ppm"] <= s32["over_1e-4_floor1_ppm"]
+    assert abs(a64["mean_radiance"]["gpu"] - a64["mean_radiance"]["oracle"]) <= 1e-3 * a64["mean_radiance"]["oracle"]
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_scenes_path_by_path(ha, orc, emu, seed):
     """Fuzz tier (tests/random_scenes.py): every element kind x surface type x textured / constant parameters, overlapping and nested —

@@ -42,6 +42,9 @@ GATES = {
     "material_examples": (0.9997, 0.9990), "simple": (0.9998, 0.9995), "cornell_mini": (0.9997, 0.9995), "tbf3": (0.9995, 0.9980),
     "rtcamp6_v2": (0.9990, 0.9965), "spheres": (0.9997, 0.9993), "rtcamp5": (0.9990, 0.9972),
 }
+# the same with option precise_shading (f64 bounce geometry): the four scenes whose gates the fp32 same-branch tail had pulled down
+GATES_PRECISE = dict(GATES)
+GATES_PRECISE.update({"tbf3": (0.9995, 0.9990), "rtcamp6_v2": (0.9995, 0.9990), "spheres": (0.9997, 0.9995), "rtcamp5": (0.9995, 0.9990)})
 CROP_SLACK = (0.0015, 0.006)
 FRAC_OK = 0.9995   # the headline scene's gate, for the tests that render rtcamp6_v3_1
 
@@ -55,9 +58,9 @@ def _compare(acc, ref):
     return _fractions(acc, ref)[0], float(acc.mean()), float(ref.mean())
 
 
-def _check_scene(name, acc, ref, what=""):
+def _check_scene(name, acc, ref, what="", gates=None):
     f2, f3 = _fractions(acc, ref)
-    g2, g3 = GATES[name]
+    g2, g3 = (gates or GATES)[name]
     print("parity %s %s: within 1e-2 %.5f (gate %.4f), within 1e-3 %.5f (gate %.4f), mean gpu %.6g oracle %.6g" % (name, what, f2, g2, f3, g3, acc.mean(), ref.mean()))
     assert np.isfinite(acc).all()
     assert f2 >= g2 and f3 >= g3, (name, what, f2, f3)
@@ -280,16 +283,21 @@ def test_production_traversal_shadow_rays_match_oracle(gpu, scenes, name):
                                          ("rtcamp6_dodeca", 195, 111, 2), ("rtcamp6_v3", 256, 144, 3), ("simple", 256, 144, 3),
                                          ("material_examples", 256, 144, 3), ("rtcamp6_v1", 256, 144, 2), ("rtcamp6_v2", 192, 108, 1),
                                          ("rtcamp5", 256, 144, 2), ("tbf3", 256, 144, 2)])
-def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s):
+@pytest.mark.parametrize("precise", [0, 1])
+def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s, precise):
     sc, o = scenes(name)
     gpu.upload_scene(sc)
     gpu.set_resolution(w, h)
     gpu.set_option("batch", 3)
-    gpu.render(1, s + 1)
-    acc = gpu.read_accumulator()
-    gpu.set_option("batch", 0)   # back to automatic
+    gpu.set_option("precise_shading", precise)
+    try:
+        gpu.render(1, s + 1)
+        acc = gpu.read_accumulator()
+    finally:
+        gpu.set_option("batch", 0)   # back to automatic
+        gpu.set_option("precise_shading", 0)
     ref, _ = o.render(w, h, 1, s + 1, threads=0)
-    _check_scene(name, acc, ref, "%dx%dx%d" % (w, h, s))
+    _check_scene(name, acc, ref, "%dx%dx%d%s" % (w, h, s, " precise" if precise else ""), GATES_PRECISE if precise else GATES)
     m_gpu, m_ref = float(acc.mean()), float(ref.mean())
     assert abs(m_gpu - m_ref) <= 2e-3 * max(1.0, abs(m_ref)), (m_gpu, m_ref)
 
@@ -320,15 +328,49 @@ PATH_LIMITS = {
 }
 
 
+# Option precise_shading (round 6: the split pipeline's shading kernel computes a bounce's geometry in f64 and carries the ray as fp32 +
+# residual; csrc/wf_core.h wf_surface_f64).  What it is for: the same-branch tail of the refraction-chain and small-sphere scenes.  Limits =
+# the targets the round-5 verdict set (rtcamp6_v2 <= 300, rtcamp5 <= 100, tbf3 <= 80, spheres <= 30 ppm beyond 1e-3; measured at 480x270,
+# samplings 1 and 2, profiles/r06_precise_parity.txt: 3.9 - 7.7, 25 - 33, 17 - 29, 29 - 31), with room for the one or two paths that a
+# test-sized image turns into 7 - 12 ppm each; same_max = 2 x the worst path measured there.  What is left is the fp32 rounding of the
+# DRAWS (the hand-off record holds them rounded once: a diffuse bounce's direction is off by ~4e-7 whatever the arithmetic after it).
+PATH_LIMITS_PRECISE = {
+    #                 w,   h,  divergent_ppm, over_ppm, flat_over_ppm, same_max
+    "rtcamp6_v3_1": (320, 180, 60.0, 15.0, 10.0, 1e-3),
+    "cornell_mini": (160, 100, 60.0, 0.0, 0.0, 1e-3),
+    "spheres": (256, 144, 60.0, 60.0, 0.0, 0.05),
+    "rtcamp6_v2": (192, 108, 400.0, 60.0, 60.0, 0.05),
+    "rtcamp5": (192, 108, 300.0, 100.0, 100.0, 0.04),
+    "tbf3": (192, 108, 150.0, 80.0, 80.0, 0.03),
+    "rtcamp6_v1": (192, 108, 150.0, 10.0, 10.0, 2.5e-3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PATH_LIMITS_PRECISE))
+def test_per_path_parity_accounting_precise_shading(gpu, scenes, name):
+    """test_per_path_parity_accounting with option precise_shading: the path log comes from the split pipeline's LOG instantiation (the
+    event log rides in the path's state), its radiances are what hr_render accumulates in that mode, and the same-branch tail meets the
+    tighter limits above."""
+    gpu.set_option("precise_shading", 1)
+    try:
+        _per_path_accounting(gpu, scenes, name, PATH_LIMITS_PRECISE, "precise")
+    finally:
+        gpu.set_option("precise_shading", 0)
+
+
 @pytest.mark.parametrize("name", sorted(PATH_LIMITS))
 def test_per_path_parity_accounting(gpu, scenes, name):
+    _per_path_accounting(gpu, scenes, name, PATH_LIMITS, "default")
+
+
+def _per_path_accounting(gpu, scenes, name, limits, label):
     """Path by path instead of pixel by pixel: hr_debug_path_log (the render kernel's LOG instantiation — same traversal, same path state
     machine) against the oracle's path log.  (i) the logged radiances ARE what hr_render accumulates (bit for bit, in the accumulate
     kernel's order); (ii) a path that took the oracle's branches traced the same number of rays; (iii) divergent paths and same-branch
     outliers stay below the stated parts per million, each divergent path classified by the first event that differs; (iv) the fraction
     of accumulator channels within 1e-3 that the per-path figures predict for a 4-sampling render is met by a real one."""
     import path_parity
-    w, h, div_ppm, over_ppm, flat_ppm, same_max = PATH_LIMITS[name]
+    w, h, div_ppm, over_ppm, flat_ppm, same_max = limits[name]
     sc, o = scenes(name)
     gpu.upload_scene(sc)
     gpu.set_resolution(w, h)
@@ -342,8 +384,8 @@ def test_per_path_parity_accounting(gpu, scenes, name):
     assert np.array_equal(acc, want.astype(np.float32)), "the path log's radiances are not what hr_render accumulates"
     a = path_parity.account(g, o.path_log(w, h, 1))
     sb = a["same_branch"]
-    print("per-path %s: %d paths, divergent %.1f ppm %s; same-branch over 1e-3: %.1f ppm (by sphere bounces %s, no sphere %.1f ppm), max %.3g, p99.9 %.3g" % (
-        name, a["paths"], a["divergent_ppm"], a["divergent_by_class_ppm"], sb["over_1e-3_floor1_ppm"], sb["over_1e-3_by_sphere_bounces_ppm"],
+    print("per-path %s [%s]: %d paths, divergent %.1f ppm %s; same-branch over 1e-3: %.1f ppm (by sphere bounces %s, no sphere %.1f ppm), max %.3g, p99.9 %.3g" % (
+        name, label, a["paths"], a["divergent_ppm"], a["divergent_by_class_ppm"], sb["over_1e-3_floor1_ppm"], sb["over_1e-3_by_sphere_bounces_ppm"],
         sb["no_sphere_bounce"]["over_1e-3_floor1_ppm"], sb["max_rel_floor1"], sb["p999_rel_floor1"]))
     assert sb["rays_equal"]                                                    # (ii)
     assert a["divergent_ppm"] <= div_ppm, a                                    # (iii)
@@ -385,8 +427,8 @@ def test_per_path_parity_at_full_size(gpu, scenes):
 
 
 
-@pytest.mark.parametrize("seed,builder", [(1, 0), (2, 0), (3, 0), (4, 0), (5, 2), (6, 1), (7, 0), (8, 2)])
-def test_random_scenes_path_by_path(gpu, ha, orc, seed, builder):
+@pytest.mark.parametrize("seed,builder,precise", [(1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 2, 0), (6, 1, 0), (7, 0, 0), (8, 2, 0), (1, 0, 1), (3, 0, 1), (5, 2, 1), (6, 1, 1)])
+def test_random_scenes_path_by_path(gpu, ha, orc, seed, builder, precise):
     """Fuzz tier (tests/random_scenes.py): every element kind x surface type x textured / constant albedo, emission and roughness,
     overlapping and nested primitives, three NEE emitters of any surface type, an emissive cuboid, square and round lenses — combinations
     the reference's eight scenes do not contain — on the host-built and the device-built trees.  Path by path against the oracle: the logged
@@ -403,20 +445,27 @@ def test_random_scenes_path_by_path(gpu, ha, orc, seed, builder):
     finally:
         gpu.set_option("bvh_builder", -1)
     gpu.set_resolution(w, h)
-    g = gpu.debug_path_log(1)
-    gpu.clear()
-    gpu.render(1, 2)
+    gpu.set_option("precise_shading", precise)
+    try:
+        g = gpu.debug_path_log(1)
+        gpu.clear()
+        gpu.render(1, 2)
+        acc1 = gpu.read_accumulator().copy()
+        gpu.clear()
+        gpu.render(1, 3)
+        acc = gpu.read_accumulator().copy()
+    finally:
+        gpu.set_option("precise_shading", 0)
     rad = g[0]
-    assert np.array_equal(gpu.read_accumulator(), ((rad[:, :, 0] + rad[:, :, 1]) + (rad[:, :, 2] + rad[:, :, 3])).astype(np.float32))
+    assert np.array_equal(acc1, ((rad[:, :, 0] + rad[:, :, 1]) + (rad[:, :, 2] + rad[:, :, 3])).astype(np.float32))
     a = path_parity.account(g, o.path_log(w, h, 1))
     sb = a["same_branch"]
-    print("random scene %d (builder %d): divergent %.0f ppm %s, same-branch over 1e-3 %.0f ppm, max %.3g, mean %.6g / %.6g" % (
-        seed, builder, a["divergent_ppm"], a["divergent_by_class_ppm"], sb["over_1e-3_floor1_ppm"], sb["max_rel_floor1"], a["mean_radiance"]["gpu"], a["mean_radiance"]["oracle"]))
-    assert sb["rays_equal"] and a["divergent_ppm"] <= 2000.0 and sb["over_1e-3_floor1_ppm"] <= 2000.0, a
+    print("random scene %d (builder %d, precise %d): divergent %.0f ppm %s, same-branch over 1e-3 %.0f ppm, max %.3g, mean %.6g / %.6g" % (
+        seed, builder, precise, a["divergent_ppm"], a["divergent_by_class_ppm"], sb["over_1e-3_floor1_ppm"], sb["max_rel_floor1"], a["mean_radiance"]["gpu"], a["mean_radiance"]["oracle"]))
+    # gates at ~3 x what the campaigns measure (profiles/r05_fuzz_campaign_1000.txt: divergent <= 291 ppm, same-branch beyond 1e-3 <= 35 ppm;
+    # until round 5 both gates stood at 2,000)
+    assert sb["rays_equal"] and a["divergent_ppm"] <= 900.0 and sb["over_1e-3_floor1_ppm"] <= 120.0, a
     assert abs(a["mean_radiance"]["gpu"] - a["mean_radiance"]["oracle"]) <= 3e-3 * a["mean_radiance"]["oracle"], a["mean_radiance"]
-    gpu.clear()
-    gpu.render(1, 3)
-    acc = gpu.read_accumulator()
     ref, _ = o.render(w, h, 1, 3, threads=0)
     f2, f3 = _fractions(acc, ref)
     assert np.isfinite(acc).all() and f2 >= 0.998 and f3 >= 0.99, (seed, f2, f3)
