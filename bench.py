@@ -632,6 +632,52 @@ def main():
             ceiling = 80.0 / (SEED_CEILING_US_PER_GROUP * 1e-6) * 256 / 1e6
             out["seed_kernel"] = {"kernel": "seed_seg_kernel", "bound": "lds_capacity_x_single_wave_serial_chain", "avg_launch_ms": round(seed_ms, 4),
                                   "achieved": round(seed_rate, 1), "peak": round(ceiling, 1), "unit": "Mpaths/s", "frac": round(seed_rate / ceiling, 4)}
+            # the headline against the ceiling of the kernel that bounds it, and where the difference goes: the consumer
+            # wave's cycles per group of 40 paths by phase, from the phase-timing build of the seed kernel run alone, outside the timed region
+            head = {"ceiling": round(ceiling, 1), "unit": "Mpaths/s", "frac_of_ceiling": round(value / world / ceiling, 4),
+                    "note": "whole-pipeline rate per GPU over the seed kernel's model ceiling (80 LDS-resident generator states per CU x a window of 11 x 510 cycles + a round of 256 x 101 cycles)"}
+            if world == 1 and not args.no_counters and not args.debug_skip:
+                try:
+                    r0.set_debug_option("seed_prof", 1)
+                    r0.set_debug_option("debug_skip", 16)      # no trace kernel beside it
+                    s_a = r0.stats()
+                    r0.render(1, 9)
+                    r0.synchronize()
+                    s_b = r0.stats()
+                    ph = [b - a for a, b in zip(s_a["seed_phase_cycles"], s_b["seed_phase_cycles"])]
+                    groups = max(1, ph[7])
+                    alone_seed_ms = (s_b["seed_kernel_ms"] - s_a["seed_kernel_ms"]) / max(1, s_b["seed_launches"] - s_a["seed_launches"])
+                    per = {k: ph[i] / groups for i, k in enumerate(["issue_reg_loads", "wait_regs", "window_11_init_blocks", "barrier_b", "round_256_steps_and_record", "fixup_note", "barrier_a"])}
+                    total = sum(per.values())
+                    model = {"window": 11 * 510.0, "round": 256 * 101.0}
+                    probe = {"window": 11 * 577.0, "round": 256 * 107.6}     # NOTES.md A: what the isolated loops measure (a block of the three-run window 577 cycles, a round step 107.6: profiles/r03_roundprobe4.txt)
+                    ticks_to_cycles = SHADER_CLOCK_HZ / 1e8                 # s_memtime counts the 100 MHz constant clock
+                    cyc = {k: v * ticks_to_cycles for k, v in per.items()} if total < 5000 else dict(per)
+                    tot_c = sum(cyc.values())
+                    groups_per_wave = paths_per_launch / 40.0 / (2 * 256)
+                    in_phases_ms = tot_c * groups_per_wave / SHADER_CLOCK_HZ * 1e3
+                    head["account"] = {
+                        "cycles_per_group": {k: round(v, 0) for k, v in cyc.items()}, "cycles_per_group_total": round(tot_c, 0),
+                        "model_cycles_per_group": model["window"] + model["round"], "probe_floor_cycles_per_group": probe["window"] + probe["round"],
+                        "terms": {
+                            "1_phases_vs_model": round((model["window"] + model["round"]) / tot_c, 4),
+                            "  window_over_model": round(cyc["window_11_init_blocks"] / model["window"], 4), "  window_over_probe_floor": round(cyc["window_11_init_blocks"] / probe["window"], 4),
+                            "  round_over_model": round(cyc["round_256_steps_and_record"] / model["round"], 4), "  round_over_probe_floor": round(cyc["round_256_steps_and_record"] / probe["round"], 4),
+                            "  bookkeeping_share": round((tot_c - cyc["window_11_init_blocks"] - cyc["round_256_steps_and_record"]) / tot_c, 4),
+                            "2_kernel_ramp_tail_fixup": round(in_phases_ms / alone_seed_ms, 4) if alone_seed_ms > 0 else None,
+                            "3_beside_the_trace_side": round(alone_seed_ms / seed_ms, 4) if seed_ms > 0 else None,
+                            "4_pair_over_seed_kernel": round(value / seed_rate, 4)},
+                        "seed_kernel_alone_ms": round(alone_seed_ms, 4),
+                        "note": "frac_of_ceiling = term 1 x term 2 x term 3 x term 4: (1) the consumer wave's measured cycles per group against the model's window + round, "
+                                "(2) the time its groups account for against the kernel's own duration alone (launch ramp, the last groups, the fix-up pass), (3) alone against beside the "
+                                "trace side, (4) the pipeline's rate against the seed kernel's.  window / round _over_probe_floor: against what the isolated probes measure for the same loops "
+                                "(NOTES.md A) — at ~1.0 nothing is left in the kernel that the probes do not have too"}
+                except Exception as ex:      # a measurement aid: never the reason a bench line is missing
+                    head["account"] = {"error": str(ex)}
+                finally:
+                    r0.set_debug_option("seed_prof", 0)
+                    r0.set_debug_option("debug_skip", 0)
+            out["headline"] = head
 
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

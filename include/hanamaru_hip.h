@@ -249,6 +249,14 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *                   (hr_stats.governor_level / governor_budget say where it stands)
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
+ *   "precise_shading"  0 (default) = the megakernel, a bounce shaded in fp32; 1 = the split pipeline (a traversal kernel and a shading
+ *                   kernel per path iteration, the path parked in HBM between them) with the GEOMETRY of every bounce in the reference's
+ *                   own f64: hit distance again from the f64 ray and the f64 primitive, hit point, normal, mirror / Snell / Fresnel
+ *                   (material.rs:154-199) and the sampled lobe directions; the ray is carried as fp32 + residual, the walk stays fp32.
+ *                   Same estimator, same draws, closer to the reference: the paths that take the reference's branches and still differ
+ *                   by more than 1e-3 — refraction chains through faceted glass, bounces off small spheres — fall from 90 - 990 to
+ *                   4 - 33 per million.  Costs 5 % where the seed kernel bounds the pair, ~20 % where the traversal does.
+ *                   (Excludes "russian_roulette".)
  *   next hr_upload_scene:
  *   "bvh_builder"   -1 = by scene size (default): the host's binned-SAH build below 200,000 primitives (the best tree; one host thread,
  *                   < 1 s), the device PLOC build from there on (0.97 - 0.99 of that tree's quality; 4 x 10^6 triangles in 38 ms instead of
