@@ -485,7 +485,7 @@ def main():
         # tree is L2-resident, physical HBM traffic is ~6 % of peak); `bound_contract` / `peak`: BASELINE's metric prices the traversal
         # against the HBM peak, and that normalisation is what `achieved` / `frac` are (SURVEY.md 8(d)'s byte booking).
         roof = {"schema": "r04+: achieved / frac = SURVEY 8(d) byte booking (until r03 these two fields were what is now loaded_bytes.achieved / .frac)",
-                "bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel",
+                "bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel" if not args.precise else "split pipeline: wf_start_kernel + 10 x (wf_traverse_kernel, wf_shade_kernel) — avg_launch_ms is the whole sequence of a launch",
                 "pair_bound": "seed_seg_kernel" if st["seed_kernel_ms"] / max(1, st["seed_launches"]) >= avg_ms else "trace_kernel",   # the slower kernel of the concurrent pair
                 "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "frac_survey_8d": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),

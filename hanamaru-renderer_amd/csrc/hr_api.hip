@@ -128,7 +128,7 @@ struct hr_ctx {
     bool wf_has_prec = false;                // the queues hold the residual quads
     WfQueues wf{};
     void *wf_block = nullptr;                // one allocation behind every pointer of wf
-    uint32_t wf_adv_den = 4, wf_trav_wgs = 8, wf_shade_wgs = 8;   // debug: traversal kernel leaves its walk when 1/wf_adv_den of the lanes are done; workgroups per CU
+    uint32_t wf_adv_den = 2, wf_trav_wgs = 8, wf_shade_wgs = 8;   // debug: traversal kernel leaves its walk when 1/wf_adv_den of the lanes are done; workgroups per CU
     int debug_skip = 0;                      // timing experiments only (garbage image): 2 = skip the seed kernel, 4 = no ring stores, 8 = no ring fills, 16 = skip the trace kernel
     // timing (HIP events around every launch, summed when the streams are drained)
     std::vector<EventPair> seed_events, trace_events, post_events, debug_events;

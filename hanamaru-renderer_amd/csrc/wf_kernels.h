@@ -60,6 +60,13 @@ __device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v, uint32_t lan
 template <bool PREC>
 __global__ __launch_bounds__(256) void wf_start_kernel(Scene sc, RenderParams rp, float *recs, WfQueues q) {
     const uint32_t lane = threadIdx.x & 63u;
+    // the governor (device_scene.h GovDev): the launch's trace side starts here — its first thread stamps the start, records the level and
+    // fixes the wave budget the launch's traversal kernels obey (one value per launch, as the megakernel's first wave does)
+    if (rp.gov && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicMin(&rp.gov->t0[1][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        rp.gov->lvl[1][rp.gov_slot] = (uint32_t)__hip_atomic_load(&rp.gov->level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rp.gov->bud[rp.gov_slot] = (rp.wg_budget ? rp.wg_budget : __hip_atomic_load(&rp.gov->budget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+    }
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u, items = rp.tiles_x * rp.tiles_y * rp.num_k;
     const uint32_t k = w % WF_SUBQ, per = waves / WF_SUBQ;     // (the grid is a multiple of WF_SUBQ waves)
     WfCounts *cn = q.counts + (size_t)1 * WF_SUBQ + k;
@@ -103,6 +110,14 @@ __global__ __launch_bounds__(256) void wf_start_kernel(Scene sc, RenderParams rp
 template <bool CNT, bool QN>
 __global__ __launch_bounds__(256, 8) void wf_traverse_kernel(Scene sc, RenderParams rp, WfQueues q, uint32_t step, Counters *cnt) {
     const uint32_t lane = threadIdx.x & 63u;
+    // the wave budget the launch's first kernel fixed (workgroups that stay; 0 = all) and the priority level its kernels started at
+    uint32_t blocks = gridDim.x, boost_mask = rp.trace_boost;
+    if (rp.gov) {
+        const uint32_t b = rp.gov->bud[rp.gov_slot];
+        if (b > 1u && b - 1u < blocks) blocks = (b - 1u) / 16u * 16u;      // whole multiples of WF_SUBQ waves
+        if (blockIdx.x >= blocks) return;
+        boost_mask = gov_trace_mask((int32_t)rp.gov->lvl[1][rp.gov_slot]);
+    }
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
     WfCounts *cn = q.counts + (size_t)step * WF_SUBQ;
     const f4 *ra = q.ray_a[step & 1u], *rb = q.ray_b[step & 1u];
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256, 8) void wf_traverse_kernel(Scene sc, RenderPar
     const uint32_t my_n = wf_rays(cn[lane]);
     unsigned long long avail = wave_ballot(my_n != 0u);
     // chunk size: 256 rays, less when the step is small (every wave should see several chunks), never less than a wave
-    uint32_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)my_n, (int)k) / (gridDim.x * 4u / WF_SUBQ * 4u + 1u);
+    uint32_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)my_n, (int)k) / (blocks * 4u / WF_SUBQ * 4u + 1u);
     chunk = chunk > 256u ? 256u : chunk < 64u ? 64u : (chunk & ~63u);
     TravLane p;
     p.ts.cur = NODE_END; p.ts.leaf = 0; p.ts.leaf2 = 0;
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(256, 8) void wf_traverse_kernel(Scene sc, RenderPar
             if (exhausted) break;
             continue;
         }
-        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, exhausted ? 0u : adv_den, leaf_den, lc, ws, tick, 0u);
+        traverse_wave<CNT, QN>(sc, rp, p, active, n_active, exhausted ? 0u : adv_den, leaf_den, lc, ws, tick, boost_mask);
         if (active && trace_done(p.ts)) {
             sth(&q.hits[slot], wf_hit_pack(p.ts));
             slot = NONE;
@@ -174,6 +189,8 @@ __global__ __launch_bounds__(256, 8) void wf_traverse_kernel(Scene sc, RenderPar
 template <bool CNT, bool PREC, bool LOG>
 __global__ __launch_bounds__(256) void wf_shade_kernel(Scene sc, RenderParams rp, float *recs, WfQueues q, uint32_t step, Counters *cnt, uint32_t *plog) {
     const uint32_t lane = threadIdx.x & 63u, in = step & 1u, out = in ^ 1u;
+    // the launch's last kernel (the stream runs them one after the other; this one is all but empty): its first thread stamps the trace side's end
+    if (rp.gov && step == WF_STEPS && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&rp.gov->t1[1][rp.gov_slot], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u;
     const uint32_t sq = w % WF_SUBQ, per = waves / WF_SUBQ;
     const uint32_t n = wf_paths(q.counts[(size_t)step * WF_SUBQ + sq]);

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r05
+# Everything under profiles/ for one round, on the GPU box:  tools/final_profiles.sh r06
 # SKIP_PMC=1: the bench lines, kernel statistics and parity lines only — when bench.py changed but the kernel sources did not (the PMC passes
 # under profiles/ stay valid: bench.py checks their sha of csrc/)
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -20,9 +20,9 @@ for sc in rtcamp6_v2 rtcamp6_v1 tbf3; do
   cp $OUT/pmc_$sc/summary.txt $OUT/${TAG}_pmc_summary_$sc.txt; cp $OUT/pmc_$sc/pmc_traffic.json $OUT/${TAG}_pmc_traffic_$sc.json
   cp $OUT/${TAG}_pmc_summary_$sc.txt $OUT/${TAG}_pmc_traffic_$sc.json profiles/
   fi
-  rocprofv3 --kernel-trace --stats -d $OUT/prof_$sc -o ${TAG}_$sc -- python bench.py --scene $sc --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_$sc.json.log 2>> $OUT/bench_full.err
+  rocprofv3 --kernel-trace --stats -d $OUT/prof_$sc -o ${TAG}_$sc -- python bench.py --scene $sc --spp-per-step 16 --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_$sc.json.log 2>> $OUT/bench_full.err
   DB=$(find $OUT/prof_$sc -name "*_results.db" | head -1)
-  python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_${sc}_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --scene $sc --steps 32 --no-cpu-baseline" > /dev/null
+  python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_${sc}_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --scene $sc --spp-per-step 16 --steps 32 --no-cpu-baseline" > /dev/null
 done
 # the bench line and the kernel-trace statistics of the SAME run
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o ${TAG} -- python bench.py > $OUT/${TAG}_bench_full.json.log 2> $OUT/bench_full.err
@@ -32,24 +32,24 @@ python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_kernel_stats.md "rocprof
 python bench.py > $OUT/${TAG}_bench_full_unprofiled.json.log 2>> $OUT/bench_full.err
 python bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_steps20_as_the_driver.json.log 2>> $OUT/bench_full.err
 # the shortcuts of round 5 switched off, same box: every NEE shadow ray traced (bit-identical image), every trace workgroup kept
-python bench.py --steps 32 --no-cpu-baseline --debug nee_cull=0 > $OUT/${TAG}_bench_full_nee_cull_off.json.log 2>> $OUT/bench_full.err
-python bench.py --steps 32 --no-cpu-baseline --debug trace_budget=1536 > $OUT/${TAG}_bench_full_wave_budget_off.json.log 2>> $OUT/bench_full.err
+python bench.py --spp-per-step 16 --steps 32 --no-cpu-baseline --debug nee_cull=0 > $OUT/${TAG}_bench_full_nee_cull_off.json.log 2>> $OUT/bench_full.err
+python bench.py --spp-per-step 16 --steps 32 --no-cpu-baseline --debug trace_budget=1536 > $OUT/${TAG}_bench_full_wave_budget_off.json.log 2>> $OUT/bench_full.err
 # other BASELINE configurations on one GPU
 python bench.py --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres.json.log 2>> $OUT/bench_full.err
 python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --steps 64 --warmup 1 --spp-per-step 4 --no-cpu-baseline > $OUT/${TAG}_bench_c5_4k_dodeca.json.log 2>> $OUT/bench_full.err
-python bench.py --bvh-builder 1 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_lbvh.json.log 2>> $OUT/bench_full.err
-python bench.py --bvh-builder 2 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
+python bench.py --bvh-builder 1 --spp-per-step 16 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_lbvh.json.log 2>> $OUT/bench_full.err
+python bench.py --bvh-builder 2 --spp-per-step 16 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_ploc.json.log 2>> $OUT/bench_full.err
 # N > 1 exactly as the driver runs N = 1 (no launcher): one process, two contexts; on this 1-GPU box both share device 0
-python bench.py --gpus 2 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_gpus2_one_device.json.log 2>> $OUT/bench_full.err
+python bench.py --gpus 2 --spp-per-step 16 --steps 8 --no-cpu-baseline > $OUT/${TAG}_bench_gpus2_one_device.json.log 2>> $OUT/bench_full.err
 # the command lines of BASELINE configs 4 and 5 with everything but the node: eight contexts on this one device at full size (8 x 2 hand-off
 # buffers of 4.25 GB + 8 scenes in HBM), weak scaling as the driver runs it and the fixed totals of C4 / C5 cut to 64 / 32 samplings
-python bench.py --gpus 8 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_gpus8_one_device.json.log 2>> $OUT/bench_full.err
+python bench.py --gpus 8 --spp-per-step 16 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_gpus8_one_device.json.log 2>> $OUT/bench_full.err
 python bench.py --gpus 8 --total-samplings 64 --steps 2 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_c4_strong_64_of_4096_one_device.json.log 2>> $OUT/bench_full.err
 python bench.py --scene rtcamp6_dodeca --width 3840 --height 2160 --gpus 8 --total-samplings 32 --steps 2 --warmup 1 --max-tail-gib 5 --no-cpu-baseline --no-counters > $OUT/${TAG}_bench_c5_strong_32_of_1024_one_device.json.log 2>> $OUT/bench_full.err
-python bench.py --russian-roulette 3 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_russian_roulette_nonparity.json.log 2>> $OUT/bench_full.err
+python bench.py --russian-roulette 3 --spp-per-step 16 --steps 16 --no-cpu-baseline > $OUT/${TAG}_bench_russian_roulette_nonparity.json.log 2>> $OUT/bench_full.err
 # every scene at 1080p, one line each
 for sc in rtcamp6_v3_1 rtcamp6_dodeca spheres rtcamp6_v3 rtcamp6_v2 rtcamp6_v1 rtcamp5 tbf3 material_examples simple cornell_mini; do
-  python bench.py --scene $sc --steps 16 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+  python bench.py --scene $sc --spp-per-step 16 --steps 16 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']; g = r['priority_governor']
 print('%-18s %7.1f Mpaths/s  trace %.2f ms (alone %.2f)  seed %.2f ms  rays/path %.2f (+ %.2f culled)  nodes/ray %.1f  tris/ray %.1f  lanes/box %.1f  8d-frac %.2f  pair bound %s  gov level %d wgs %s' % ('$sc', d['value'], r['avg_launch_ms'], r.get('avg_launch_ms_alone', 0), r['seed_kernel_avg_ms'], r['rays_per_path'], r['nee_shadow_rays_culled_per_path'], r['node_tests_per_ray'], r['tri_tests_per_ray'], r['lanes_per_box_pass'], r['frac'], r['pair_bound'], g['level'], g['trace_workgroups']))"
@@ -57,4 +57,14 @@ done > $OUT/${TAG}_all_scenes_1080p.txt
 python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_from or million or russian or per_path or post_chain or full_length or ragged or nee_culls" 2>&1 | grep -E "^\.?parity|simple \+|device builder|builder [0-9]|4 M tri|4K post|per-path|russian roulette|config [45] full|ragged sizes|nee culls|passed|failed" > $OUT/${TAG}_parity_lines.txt
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
+# round 6: the split pipeline against the megakernel and with precise shading, pair and kernel by kernel; precise shading's parity; the CLI's rate
+python tools/ab/split_ab.py --samplings 128 --scenes rtcamp6_v3_1,rtcamp6_v2,rtcamp6_v1,rtcamp6_dodeca,tbf3,rtcamp5,spheres --modes 0,1,2 2>&1 | grep -v libdrm > $OUT/${TAG}_split_ab.txt
+python tools/ab/split_ab.py --scenes rtcamp6_v3_1,rtcamp6_v2,spheres --modes 2 --profile-only --counters 2>&1 | grep -v libdrm > $OUT/${TAG}_split_profile.txt
+python tools/ab/precise_check.py 2>&1 | grep -v libdrm > $OUT/${TAG}_precise_parity_480x270.txt
+bash tools/ab/cli_batch.sh > $OUT/${TAG}_cli_report_granularity.txt 2>&1
+python bench.py --precise --spp-per-step 16 --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_precise.json.log 2>> $OUT/bench_full.err
+python bench.py --precise --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres_precise.json.log 2>> $OUT/bench_full.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_precise -o ${TAG}_precise -- python bench.py --precise --spp-per-step 16 --steps 16 --no-cpu-baseline --no-counters > /dev/null 2>> $OUT/bench_full.err
+DB=$(find $OUT/prof_precise -name "*_results.db" | head -1)
+python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_precise_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --precise --spp-per-step 16 --steps 16 --no-cpu-baseline --no-counters" > /dev/null
 tail -3 $OUT/pytest_gpu.log; cat $OUT/${TAG}_bench_full_unprofiled.json.log | head -c 400; echo; cat $OUT/${TAG}_bench_kernel_stats.md | head -12
