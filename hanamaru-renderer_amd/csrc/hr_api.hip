@@ -963,11 +963,18 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
         batch = (uint32_t)std::min<uint64_t>(batch, fit);
     }
+    if (c->precise && c->rr_start) return fail(HR_ERR_UNSUPPORTED, "hr_render: russian_roulette and precise_shading exclude each other (the roulette estimator lives in the megakernel)");
+    const bool split = (c->trace_mode == 1 || c->precise) && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
+    if (split) {
+        // the split pipeline's queues are sized for the worst case (a main ray + a shadow ray per emitter for every path, both parities): keep
+        // them under the same cap as a hand-off buffer — a 3840x2160 launch then holds one sampling (33 M paths) instead of four
+        const uint64_t per_path = (1ull + c->dsc.num_emitters) * (4 * sizeof(f4) + sizeof(WfHitRec)) + (c->precise ? 10 : 6) * sizeof(f4);
+        const uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, (uint64_t)tiles * 64u * per_path));
+        batch = (uint32_t)std::min<uint64_t>(batch, fit);
+    }
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
-    if (c->precise && c->rr_start) return fail(HR_ERR_UNSUPPORTED, "hr_render: russian_roulette and precise_shading exclude each other (the roulette estimator lives in the megakernel)");
-    const bool split = (c->trace_mode == 1 || c->precise) && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
     if (split && (rc = ensure_wf(c, (uint64_t)tiles * 64u * batch))) return rc;
     rp.ovf_cap = c->ovf_cap;
     rp.rr_start = c->rr_start;
