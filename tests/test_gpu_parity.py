@@ -1337,6 +1337,30 @@ def test_config5_4k_crops(gpu, scenes):
     assert np.abs(capped.astype(np.float64) - whole).max() <= 1e-4 * max(1.0, float(np.abs(whole).max()))
 
 
+def test_config5_4k_crops_precise_shading(gpu, scenes):
+    """The same crops with option precise_shading: the split pipeline at 3840x2160 (its queues are sized for the worst case and kept under
+    max_tail_gib: a launch holds ONE 4K sampling, 33 M paths, instead of four), exact path count, parity on the crops, and a bit-identical
+    accumulator whatever the launch size."""
+    sc, o = scenes("rtcamp6_dodeca")
+    gpu.upload_scene(sc)
+    W, H, S = 3840, 2160, 2
+    gpu.set_option("precise_shading", 1)
+    gpu.set_option("counters", 1)
+    try:
+        a = _crop_parity(gpu, o, "rtcamp6_dodeca", W, H, S, [(1950, 150), (1850, 520), (3040, 640)])
+        st = gpu.stats()
+        assert st["paths"] == W * H * 4 * S and st["rng_overflow"] == 0 and st["trace_launches"] == 2
+        gpu.set_option("counters", 0)
+        gpu.set_option("max_tail_gib", 64)                # room for both samplings in one launch
+        gpu.clear()
+        gpu.render(1, S + 1)
+        assert np.array_equal(a, gpu.read_accumulator())
+    finally:
+        gpu.set_option("max_tail_gib", 20)
+        gpu.set_option("counters", 0)
+        gpu.set_option("precise_shading", 0)
+
+
 def test_config5_full_length_through_the_cli(tmp_path, scenes, orc):
     """BASELINE config 5 end to end at its FULL length on one GPU: `hanamaru-hip --scene rtcamp6_dodeca -w 3840 -h 2160 -s 1024` —
     3.4e10 paths (half a minute), the reference's log lines, and the 4K PNG that comes out of accumulate -> Reinhard -> gamma ->

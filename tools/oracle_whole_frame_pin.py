@@ -8,8 +8,8 @@ closes the gap: the oracle (oracle/oracle.cpp, f64) renders ALL 1920 x 1080 pixe
 Output (data only, committed): tests/golden/oracle_whole_frame_pin.npz
     rows_exact[1080], rows_within1[1080]   channels of each row (of 5760) that are identical / within 1 LSB
     diff_yxc[n, 3] (uint16), diff_val[n] (int16)   every channel where oracle - reference != 0
-    acc_rows[16, 1920, 3] float64 + acc_row_index[16]   the oracle's accumulator of 16 rows spread over the frame: what the CPU test
-                                                        re-derives segments of (tests/test_oracle.py)
+    acc_rows[18, 1920, 3] float64 + acc_row_index[18]   the oracle's accumulator of six row triples spread over the frame: the CPU test
+                                                        re-derives segments of them and resolves the middle rows (tests/test_oracle.py)
     meta: samplings, seconds, threads
 The render runs in bands of rows with a checkpoint (gpurun_out-style scratch under oracle/_pin/, git-ignored) so that it can be resumed.
 
@@ -73,7 +73,10 @@ def main():
     rows_within1 = (ad <= 1).reshape(H, -1).sum(axis=1).astype(np.uint16)
     yxc = np.argwhere(d != 0).astype(np.uint16)
     val = d[d != 0].astype(np.int16)
-    idx = np.linspace(3, H - 4, 16).astype(int)
+    # six row TRIPLES spread over the frame (sky, the mirror, the glass armadillo, the frame, the floor's lettering, the bottom edge): the
+    # middle row of a triple can be resolved on its own (the 3x3 bilateral sees its neighbours), so the CPU test ties accumulator -> 8-bit row
+    mid = np.array([40, 300, 520, 700, 880, 1040])
+    idx = np.stack([mid - 1, mid, mid + 1], axis=1).reshape(-1)
     np.savez_compressed(a.out, rows_exact=rows_exact, rows_within1=rows_within1, diff_yxc=yxc, diff_val=val, acc_rows=acc[idx], acc_row_index=idx.astype(np.uint16),
                         meta=np.array([S, spent, a.threads], dtype=np.float64))
     mse = float((d.astype(np.float64) ** 2).mean())
