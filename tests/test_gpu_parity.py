@@ -1056,8 +1056,12 @@ def test_kernel_variants_render_the_same_bits(gpu, scenes):
             assert np.array_equal(ref, render()), ("min_waves", mw)
         gpu.set_debug_option("min_waves", 5)
         # the split pipeline (traversal kernel + shading kernel per path iteration, wf_kernels.h) is the megakernel cut at scene.intersect
+        log_mega = gpu.debug_path_log(3)
         gpu.set_debug_option("trace_mode", 1)
         assert np.array_equal(ref, render()), "split pipeline"
+        # ... and its LOG instantiation (the event log rides in the path's state) writes the megakernel's path log, word for word
+        for a, b in zip(log_mega, gpu.debug_path_log(3)):
+            assert np.array_equal(a, b), "split pipeline, path log"
         gpu.set_option("counters", 1)
         assert np.array_equal(ref, render()), "split pipeline, instrumented build"
         gpu.set_option("counters", 0)
