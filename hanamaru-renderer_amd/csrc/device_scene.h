@@ -235,16 +235,20 @@ struct GovDev {
     uint32_t bud[2];                         // the budget the trace kernel of each slot runs with, + 1 (0 = unset): fixed by its first wave, obeyed by all
     uint32_t budget_lo, budget_hi, budget_step;   // smallest budget, largest budget below "all", step (workgroups; set by the host from the CU count)
     uint32_t budget_moves;
+    float thr_down, thr_up;                  // the control law's thresholds on trace time / seed time (gov_budget_next; set by the host per pipeline)
 };
 // the trace kernel's priority mask of a level (bits 0-3: which of every four box phases run at priority 1, bit 4: the leaf phase too)
 HD uint32_t gov_trace_mask(int32_t level) { return level >= 4 ? 0x1fu : level == 3 ? 0xfu : 0u; }
 // The wave budget's control law (governor_kernel; also compiled for the host: tests/test_host_layer.py drives it against the measured plant).
 // B = the budget a judged launch ran with (0 = every workgroup), ratio = its trace kernel's time / its seed kernel's time at level 0.  One step
 // down while the trace kernel has more than 12 % to spare, one step up when it comes within 3 % of the seed kernel, "all" above budget_hi.
-HD uint32_t gov_budget_next(uint32_t B, float ratio, uint32_t lo, uint32_t hi, uint32_t step) {
+// The split pipeline (wf_kernels.h) has other thresholds: its traversal workgroups cost the seed kernel beside them more than they gain their own
+// kernel, and the pair is best where the two sides take the same time (measured on the headline with precise shading, workgroups 768 / 1,024 /
+// 1,280 / 1,536 / all: seed 25.4 / 25.6 / 26.2 / 26.9 / 26.9 ms, trace side 26.4 / 25.2 / 24.5 / 24.5 / 24.6 ms) — down below 0.96, up above 1.02.
+HD uint32_t gov_budget_next(uint32_t B, float ratio, uint32_t lo, uint32_t hi, uint32_t step, float down = 0.88f, float up = 0.97f) {
     if (!step) return B;
-    if (ratio > 0.97f && B) return B + step > hi ? 0u : B + step;
-    if (ratio < 0.88f) return !B ? hi : (B >= lo + step ? B - step : B);
+    if (ratio > up && B) return B + step > hi ? 0u : B + step;
+    if (ratio < down) return !B ? hi : (B >= lo + step ? B - step : B);
     return B;
 }
 // the seed kernel's producer priorities of a level: bits 0-1 even groups, bits 2-3 odd groups

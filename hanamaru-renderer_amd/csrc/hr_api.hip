@@ -216,7 +216,7 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
             g->decisions++;
             bool budget_moved = false;
             if (L == 0 && g->level == 0 && B == g->budget && g->budget_step) {
-                const uint32_t nb = gov_budget_next(B, trace_t / seed_t, g->budget_lo, g->budget_hi, g->budget_step);
+                const uint32_t nb = gov_budget_next(B, trace_t / seed_t, g->budget_lo, g->budget_hi, g->budget_step, g->thr_down, g->thr_up);
                 if (nb != B) {
                     budget_moved = true;
                     g->budget_moves++;
@@ -256,6 +256,12 @@ static int govern_reset(hr_ctx *c) {
     h.level = c->trace_boost >= 0 ? c->trace_boost : 0;
     // the wave budget is governed with the level (a fixed level pins it at "all"): 2.5 .. 3.5 workgroups per CU in steps of a quarter
     if (c->trace_boost < 0) { h.budget_step = (uint32_t)c->num_cus / 4u; h.budget_lo = (uint32_t)c->num_cus * 5u / 2u; h.budget_hi = (uint32_t)c->num_cus * 7u / 2u; }
+    h.thr_down = 0.88f; h.thr_up = 0.97f;
+    if ((c->trace_mode == 1 || c->precise) && c->trace_boost < 0) {
+        // the split pipeline's traversal kernel: 3 .. 7 workgroups of four 64-VGPR waves per CU in steps of a half, "all" = 8 (device_scene.h gov_budget_next)
+        h.budget_step = (uint32_t)c->num_cus / 2u; h.budget_lo = (uint32_t)c->num_cus * 3u; h.budget_hi = (uint32_t)c->num_cus * 7u;
+        h.thr_down = 0.96f; h.thr_up = 1.02f;
+    }
     HIP_TRY(hipMemcpy(c->gov, &h, sizeof h, hipMemcpyHostToDevice));
     return HR_OK;
 }

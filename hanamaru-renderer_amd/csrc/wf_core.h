@@ -89,15 +89,18 @@ struct WfBounce { V3f next_o, next_d, n, view; float cur_refl, param, roughness,
 
 // The main ray's result (renderer.rs:175-196 = path_advance's main-ray branch up to the NEE loop): returns true when the path ends here.
 // rec = the path's hand-off record (recs + wf_rec_base(pid)): the iteration's two draws, and for a primary ray on a sphere the f64 residuals.
-template <bool CNT>
-HD bool wf_surface(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f rd, const WfHitRec &h, WfBounce &b, LaneCounters *cn) {
+// LOG: the per-path event log of pt_core.h (PathLog), exactly as path_advance<.., LOG> keeps it.
+template <bool CNT, bool LOG = false>
+HD bool wf_surface(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f rd, const WfHitRec &h, WfBounce &b, LaneCounters *cn, PathLog *lg = nullptr) {
     if (CNT) cn->rays++;
+    if (LOG) lg->rays++;
     TraceState ts;
     wf_hit_unpack(h, ts);
     const uint32_t a2 = wf_a2(p), it = wf_iter(p);
     const f2v r01 = *reinterpret_cast<const f2v *>(rec + rec_slot(0u, a2 + 2u * it));   // renderer.rs:175
     b.r0 = r01[0]; b.r1 = r01[1];
     if (ts.prim < 0) {  // scene.rs:398 + renderer.rs:196,199
+        if (LOG) { plog_or(*lg, it, 1u); plog_sky(sc, *lg, rd); }
         p.accum = p.accum + p.refl * sky_sample(sc, rd);
         return true;
     }
@@ -112,6 +115,15 @@ HD bool wf_surface(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f rd,
     b.view = -rd;
     bool transmitted;
     const bool sampled = bsdf_sample(m, b.r0, b.r1, s.pos, b.view, s.n, b.next_o, b.next_d, b.cur_refl, transmitted);
+    if (LOG) {
+        if (ts.type == 2) plog_hit(*lg, 0x1000 + cuboid_face_of(s.n));
+        const Material mt = sc.materials[s.elem];
+        plog_quad(sc, *lg, mt.albedo_img, s.u, s.v); plog_quad(sc, *lg, mt.emission_img, s.u, s.v); plog_quad(sc, *lg, mt.roughness_img, s.u, s.v);
+        plog_hit(*lg, s.elem);
+        if (ts.type == 1) lg->ev9 += 256u;
+        if (ts.type == 0) plog_hit(*lg, (int32_t)(sc.tri_face[ts.prim] + 0x9e3779b9u));
+        plog_or(*lg, it, sampled ? (2u + (uint32_t)m.surface) | (transmitted ? 8u : 0u) : 7u);
+    }
     if (!sampled) return true;  // renderer.rs:190-193
     p.accum = p.accum + p.refl * m.emission;          // renderer.rs:196
     p.refl = p.refl * m.albedo;                       // renderer.rs:183,295 and the first factor of :197

@@ -431,7 +431,7 @@ static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint
         bx.next_o_lo = bx.next_d_lo = v3(0, 0, 0);
         bool fin;
         if (PREC) fin = wf_surface_f64<false, LOG>(sc, p, prec, rays[ns].o, rays[ns].d, rays[ns].o_lo, rays[ns].d_lo, hits[ns], b, bx, &lc, lg);
-        else fin = wf_surface<false>(sc, p, prec, rays[ns].o, rays[ns].d, hits[ns], b, &lc);
+        else fin = wf_surface<false, LOG>(sc, p, prec, rays[ns].o, rays[ns].d, hits[ns], b, &lc, lg);
         if (fin) break;
         nxt.clear();
         if (b.nee)

@@ -1343,13 +1343,14 @@ def test_config5_4k_crops(gpu, scenes):
 
 def test_config5_4k_crops_precise_shading(gpu, scenes):
     """The same crops with option precise_shading: the split pipeline at 3840x2160 (its queues are sized for the worst case and kept under
-    max_tail_gib: a launch holds ONE 4K sampling, 33 M paths, instead of four), exact path count, parity on the crops, and a bit-identical
-    accumulator whatever the launch size."""
+    max_tail_gib: with a cap of 8 GiB a launch holds ONE 4K sampling, 33 M paths), exact path count, parity on the crops, and the same
+    accumulator (to the summation order) whatever the launch size."""
     sc, o = scenes("rtcamp6_dodeca")
     gpu.upload_scene(sc)
     W, H, S = 3840, 2160, 2
     gpu.set_option("precise_shading", 1)
     gpu.set_option("counters", 1)
+    gpu.set_option("max_tail_gib", 8)                     # this scene's queues take 10.6 GB per 4K sampling (one emitter): a launch per sampling
     try:
         a = _crop_parity(gpu, o, "rtcamp6_dodeca", W, H, S, [(1950, 150), (1850, 520), (3040, 640)])
         st = gpu.stats()
@@ -1358,7 +1359,8 @@ def test_config5_4k_crops_precise_shading(gpu, scenes):
         gpu.set_option("max_tail_gib", 64)                # room for both samplings in one launch
         gpu.clear()
         gpu.render(1, S + 1)
-        assert np.array_equal(a, gpu.read_accumulator())
+        whole = gpu.read_accumulator()      # (another launch size is another summation order of a pixel's records: equal to fp32 rounding)
+        assert np.abs(a.astype(np.float64) - whole).max() <= 1e-4 * max(1.0, float(np.abs(whole).max()))
     finally:
         gpu.set_option("max_tail_gib", 20)
         gpu.set_option("counters", 0)

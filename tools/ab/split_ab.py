@@ -84,8 +84,9 @@ def main():
             same = "-" if ref is None else (str(bool(np.array_equal(ref, acc))) + ("" if np.array_equal(ref, acc) else " (%d channels differ, max %.3g)" % (int((ref != acc).sum()), float(np.abs(ref - acc).max()))))
             if ref is None:
                 ref = acc
-            print("%-16s mode %d  %8.1f Mpaths/s   seed %6.2f ms   trace %6.2f ms   trace alone %6.2f ms   same bits %s   %s"
-                  % (name, mode, rate, seed, trace, alone, same, " ".join(a.opt) if mode else ""), flush=True)
+            st = r.stats()
+            print("%-16s mode %d  %8.1f Mpaths/s   seed %6.2f ms   trace %6.2f ms   trace alone %6.2f ms   same bits %s   governor: level %d, %s workgroups   %s"
+                  % (name, mode, rate, seed, trace, alone, same, st["governor_level"], st["governor_budget"] or "all", " ".join(a.opt) if mode else ""), flush=True)
         if a.profile or a.profile_only:
             r.set_option("precise_shading", 1 if "2" in a.modes.split(",") else 0)
             for kv in a.opt:
