@@ -124,7 +124,8 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=0,
                     help="samplings per step per GPU; 0 (default) = BASELINE's headline: exactly 1,024 samplings per GPU spread over --steps steps, whatever --steps is")
     ap.add_argument("--headline-samplings", type=int, default=1024, help="samplings per GPU of the default plan (BASELINE: 1024)")
-    ap.add_argument("--precise", action="store_true", help="option precise_shading: the split pipeline with the bounce geometry in f64 (DESIGN.md §4.5)")
+    ap.add_argument("--precise", action="store_true", help="option precise_shading 1: the bounce geometry in f64 (DESIGN.md §4.5); default: the library's automatic choice (on for scenes without meshes)")
+    ap.add_argument("--no-precise", action="store_true", help="option precise_shading 0: fp32 shading whatever the scene")
     ap.add_argument("--total-samplings", type=int, default=0,
                     help="strong scaling: render exactly samplings 1..S in total, sharded over the GPUs and spread over --steps steps (BASELINE config 4: --gpus 8 --total-samplings 4096)")
     ap.add_argument("--batch", type=int, default=0, help="samplings per kernel launch (0 = the library's automatic choice: 4 at 1080p)")
@@ -228,8 +229,8 @@ def main():
             r.set_option("max_tail_gib", args.max_tail_gib)
         if args.russian_roulette:
             r.set_option("russian_roulette", args.russian_roulette)
-        if args.precise:
-            r.set_option("precise_shading", 1)
+        if args.precise or args.no_precise:
+            r.set_option("precise_shading", 1 if args.precise else 0)
         for kv in args.debug:
             k, v = kv.split("=")
             r.set_debug_option(k, float(v))
@@ -411,7 +412,8 @@ def main():
                                    % (args.scene, W, H, samplings_run, total_paths, args.steps, ("%d or %d" % (SPS - 1, SPS)) if HEADLINE and HEADLINE % args.steps else str(SPS), world,
                                       (", last step clipped to --total-samplings %d" % S_TOTAL) if S_TOTAL else "",
                                       ("; the default plan: BASELINE's %d samplings per GPU whatever --steps is" % HEADLINE) if HEADLINE else ""),
-                       "shading": "precise_shading: split pipeline, bounce geometry in f64" if args.precise else "default: megakernel, fp32 shading",
+                       "shading": ["fp32 shading (megakernel)", "precise shading: bounce geometry in f64, in the megakernel", "precise shading: bounce geometry in f64, in the split pipeline",
+                                   "fp32 shading in the split pipeline (debug)"][int(st.get("shading_in_force", 0))] + (" [option precise_shading %d]" % (1 if args.precise else 0) if args.precise or args.no_precise else " [automatic]"),
                        "samplings_total": samplings_run, "paths_total": total_paths,
                        "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": round(total_paths / args.steps) if HEADLINE else paths_per_step_gpu * world,
                        "parallelism": "spp-sharded x%d, one all-reduce (%s)" % (world, how), "devices": sorted(set(d for _, d in mine)) if not launcher else [local_rank],
@@ -485,7 +487,7 @@ def main():
         # tree is L2-resident, physical HBM traffic is ~6 % of peak); `bound_contract` / `peak`: BASELINE's metric prices the traversal
         # against the HBM peak, and that normalisation is what `achieved` / `frac` are (SURVEY.md 8(d)'s byte booking).
         roof = {"schema": "r04+: achieved / frac = SURVEY 8(d) byte booking (until r03 these two fields were what is now loaded_bytes.achieved / .frac)",
-                "bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel" if not args.precise else "split pipeline: wf_start_kernel + 10 x (wf_traverse_kernel, wf_shade_kernel) — avg_launch_ms is the whole sequence of a launch",
+                "bound": "l1_ta_issue", "bound_contract": "hbm", "kernel": "trace_kernel" if int(st.get("shading_in_force", 0)) < 2 else "split pipeline: wf_start_kernel + 10 x (wf_traverse_kernel, wf_shade_kernel) — avg_launch_ms is the whole sequence of a launch",
                 "pair_bound": "seed_seg_kernel" if st["seed_kernel_ms"] / max(1, st["seed_launches"]) >= avg_ms else "trace_kernel",   # the slower kernel of the concurrent pair
                 "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "frac_survey_8d": None, "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(st["trace_launches"]),

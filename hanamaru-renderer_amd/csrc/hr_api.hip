@@ -123,8 +123,10 @@ struct hr_ctx {
     uint32_t rr_start = 0;                   // Russian roulette from this path iteration on (0 = off: the reference has none; NOT image-preserving)
     uint32_t ploc_top = hr::lbvh::PLOC_TOP_CLUSTERS;   // builder 2: clusters the bottom-up merges leave for the top-down build (1 = merge to the root)
     // the split pipeline (wf_kernels.h): queues of the launch being traced, sized for the largest launch so far
-    int trace_mode = 0;                      // 0 = megakernel (trace_kernel), 1 = split: traversal kernel + shading kernel per path iteration
-    bool precise = false;                    // option precise_shading: the split pipeline with the bounce geometry in f64 (wf_core.h wf_surface_f64)
+    int trace_mode = 0;                      // IN FORCE (resolve_modes): 0 = megakernel (trace_kernel), 1 = split: traversal kernel + shading kernel per path iteration
+    int trace_mode_opt = -1;                 // debug option trace_mode: -1 = automatic (the split pipeline for precise shading of scenes with many triangles), 0 / 1 = pinned
+    int precise_opt = -1;                    // option precise_shading: -1 = automatic (on for scenes without triangle meshes), 0 = off, 1 = on
+    bool precise = false;                    // IN FORCE (resolve_modes) — option precise_shading: the bounce geometry in f64 (prec_core.h) — in the megakernel (path_advance<.., PREC>), or in the split pipeline's shading kernel with trace_mode 1
     bool wf_has_prec = false;                // the queues hold the residual quads
     WfQueues wf{};
     void *wf_block = nullptr;                // one allocation behind every pointer of wf
@@ -243,10 +245,23 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
     g->bud[slot] = 0;   // unset: the next launch in this slot fixes its own
     if (g->fixed >= 0) __hip_atomic_store(&g->level, g->fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// What options precise_shading / trace_mode mean for the scene in place.  Precise shading has two homes that render the same bits
+// (path_advance<.., PREC> in the megakernel at 128 VGPRs; the split pipeline's shading kernel), so which one runs is a question of speed only:
+// the megakernel form costs 0.4 - 1.6 % on scenes whose trace side is light (no or few triangles), the split form less than the megakernel form
+// on mesh scenes (5 - 20 %; profiles/r06_precise_pipelines.txt).  AUTOMATIC precise shading: on for scenes without triangle meshes — small
+// spheres are what multiplies an fp32 ray's error, and there it is all but free —, off where it costs.
+static const uint32_t PRECISE_SPLIT_TRIS = 10000;
+static void resolve_modes(hr_ctx *c) {
+    const bool has_scene = c->have_scene;
+    const uint32_t tris = has_scene ? c->dsc.num_tris : 0u;
+    c->precise = c->precise_opt == 1 || (c->precise_opt < 0 && has_scene && tris == 0u && !c->rr_start);
+    c->trace_mode = c->trace_mode_opt >= 0 ? c->trace_mode_opt : (c->precise && tris > PRECISE_SPLIT_TRIS ? 1 : 0);
+}
 // a new scene, resolution or option: the balance of the two kernels is another one.  The governor starts at level 0 — next to a trace
 // kernel that needs 16 ms per 33 M paths on the reference's scenes the seed kernel (24 ms) is the slower one almost everywhere.
 // (Callers have synchronised the context: no kernel is stamping.)
 static int govern_reset(hr_ctx *c) {
+    resolve_modes(c);
     if (!c->gov) return HR_OK;
     GovDev h;
     memset(&h, 0, sizeof h);
@@ -257,7 +272,7 @@ static int govern_reset(hr_ctx *c) {
     // the wave budget is governed with the level (a fixed level pins it at "all"): 2.5 .. 3.5 workgroups per CU in steps of a quarter
     if (c->trace_boost < 0) { h.budget_step = (uint32_t)c->num_cus / 4u; h.budget_lo = (uint32_t)c->num_cus * 5u / 2u; h.budget_hi = (uint32_t)c->num_cus * 7u / 2u; }
     h.thr_down = 0.88f; h.thr_up = 0.97f;
-    if ((c->trace_mode == 1 || c->precise) && c->trace_boost < 0) {
+    if (c->trace_mode == 1 && c->trace_boost < 0) {
         // the split pipeline's traversal kernel: 3 .. 7 workgroups of four 64-VGPR waves per CU in steps of a half, "all" = 8 (device_scene.h gov_budget_next)
         h.budget_step = (uint32_t)c->num_cus / 2u; h.budget_lo = (uint32_t)c->num_cus * 3u; h.budget_hi = (uint32_t)c->num_cus * 7u;
         h.thr_down = 0.96f; h.thr_up = 1.02f;
@@ -386,7 +401,8 @@ HIP_TRY(hipFuncSetAttribute((const void *)seed_pc_kernel<8>, hipFuncAttributeMax
                                         (const void *)trace_kernel<false, 6, true>, (const void *)trace_kernel<true, 3, true>, (const void *)trace_kernel<true, 3, false>,
                                         (const void *)trace_kernel<false, 5, true, true>, (const void *)trace_kernel<false, 5, false, true>,
                                         (const void *)trace_kernel<true, 3, true, true>, (const void *)trace_kernel<true, 3, false, true>,
-                                        (const void *)trace_kernel<false, 3, true, false, true>, (const void *)trace_kernel<false, 3, false, false, true>};
+                                        (const void *)trace_kernel<false, 3, true, false, true>, (const void *)trace_kernel<false, 3, false, false, true>,
+                                        (const void *)trace_kernel<false, 4, true, false, false, true>, (const void *)trace_kernel<false, 4, false, false, false, true>};
         for (const void *f : trace_variants) {
             hipFuncAttributes fa;
             HIP_TRY(hipFuncGetAttributes(&fa, f));
@@ -969,8 +985,8 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
         batch = (uint32_t)std::min<uint64_t>(batch, fit);
     }
-    if (c->precise && c->rr_start) return fail(HR_ERR_UNSUPPORTED, "hr_render: russian_roulette and precise_shading exclude each other (the roulette estimator lives in the megakernel)");
-    const bool split = (c->trace_mode == 1 || c->precise) && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
+    if (c->precise_opt == 1 && c->rr_start) return fail(HR_ERR_UNSUPPORTED, "hr_render: russian_roulette and precise_shading exclude each other (the roulette estimator has no f64 instantiation)");
+    const bool split = c->trace_mode == 1 && !c->rr_start;   // (the roulette estimator lives in the megakernel only)
     if (split) {
         // the split pipeline's queues are sized for the worst case (a main ray + a shadow ray per emitter for every path, both parities): keep
         // them under the same cap as a hand-off buffer — a 3840x2160 launch then holds one sampling (33 M paths) instead of four
@@ -1026,6 +1042,14 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
                 if (c->counters) { if (qn) HR_LAUNCH_TRACE_RR(true, 3, true); else HR_LAUNCH_TRACE_RR(true, 3, false); }
                 else if (qn) HR_LAUNCH_TRACE_RR(false, 5, true);
                 else HR_LAUNCH_TRACE_RR(false, 5, false);
+            } else if (c->precise) {    // precise shading: path_advance<.., PREC>, 128 VGPRs
+#define HR_LAUNCH_TRACE_PREC(C, W, Q) hipLaunchKernelGGL((trace_kernel<C, W, Q, false, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[slot], c->d_counters, c->d_tile_counter + slot)
+                if (c->counters) { if (qn) HR_LAUNCH_TRACE_PREC(true, 3, true); else HR_LAUNCH_TRACE_PREC(true, 3, false); }
+                else if (qn && c->min_waves == 6) HR_LAUNCH_TRACE_PREC(false, 5, true);      // debug option min_waves 6 -> the 96-VGPR form, 4 -> the 168-VGPR form (A/B only)
+                else if (qn && c->min_waves == 4) HR_LAUNCH_TRACE_PREC(false, 3, true);
+                else if (qn) HR_LAUNCH_TRACE_PREC(false, 4, true);
+                else HR_LAUNCH_TRACE_PREC(false, 4, false);
+#undef HR_LAUNCH_TRACE_PREC
             } else if (c->counters) { if (qn) HR_LAUNCH_TRACE(true, 3, true); else HR_LAUNCH_TRACE(true, 3, false); }
             else if (!qn) HR_LAUNCH_TRACE(false, 5, false);
             else if (c->min_waves == 4) HR_LAUNCH_TRACE(false, 4, true);
@@ -1371,6 +1395,7 @@ int hr_get_stats(hr_ctx *c, hr_stats *out) {
     out->seed_kernel_ms = c->seed_ms; out->trace_kernel_ms = c->trace_ms; out->post_kernel_ms = c->post_ms;
     out->seed_launches = c->seed_launches; out->trace_launches = c->trace_launches;
     out->bvh_build_ms = c->bvh_build_ms; out->bvh_builder_used = (uint64_t)c->builder_in_use;
+    out->shading_in_force = c->precise ? (c->trace_mode == 1 ? 2u : 1u) : (c->trace_mode == 1 ? 3u : 0u);
     out->debug_kernel_ms = c->debug_ms; out->debug_launches = c->debug_launches;
     {
         GovDev g;
@@ -1432,15 +1457,16 @@ int hr_set_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "precise_shading") {   // the bounce geometry in f64 (split pipeline): closer to the reference's f64 arithmetic, a few per cent slower
-        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "precise_shading must be 0 or 1");
+        if (value != -1 && value != 0 && value != 1) return fail(HR_ERR_INVALID, "precise_shading must be -1 (automatic), 0 or 1");
         int rc = sync_all(c);
         if (rc) return rc;
-        c->precise = value != 0;
+        c->precise_opt = (int)value;
         return govern_reset(c);
     }
     if (k == "russian_roulette") {  // NOT image-preserving (see the header): 0 = off, else the first path iteration that plays
         if (value != 0 && (value < 2 || value > 9)) return fail(HR_ERR_INVALID, "russian_roulette must be 0 (off) or the first iteration that plays, in [2,9]");
         c->rr_start = (uint32_t)value;
+        resolve_modes(c);     // (automatic precise shading stands back: the roulette estimator has no f64 instantiation)
         return HR_OK;
     }
     return fail(HR_ERR_INVALID, "unknown option '%s' (measurement knobs live behind hr_set_debug_option)", key);
@@ -1517,10 +1543,10 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         return HR_OK;
     }
     if (k == "trace_mode") {
-        if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "trace_mode must be 0 (megakernel) or 1 (split: traversal kernel + shading kernel)");
+        if (value != -1 && value != 0 && value != 1) return fail(HR_ERR_INVALID, "trace_mode must be -1 (automatic), 0 (megakernel) or 1 (split: traversal kernel + shading kernel)");
         int rc = sync_all(c);
         if (rc) return rc;
-        c->trace_mode = (int)value;
+        c->trace_mode_opt = (int)value;
         return govern_reset(c);
     }
     if (k == "wf_adv_den") { if (value < 0 || value > 64) return fail(HR_ERR_INVALID, "wf_adv_den must be in [0,64]"); c->wf_adv_den = (uint32_t)value; return HR_OK; }
@@ -1607,7 +1633,7 @@ int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
     if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
     const size_t words = (size_t)c->W * c->H * 4u * 8u;
     uint32_t *d_log = nullptr;
-    const bool split = (c->trace_mode == 1 || c->precise) && !c->rr_start;
+    const bool split = c->trace_mode == 1 && !c->rr_start;
     if (split && (rc = ensure_wf(c, (uint64_t)tiles * 64u))) return rc;
     HIP_TRY(hipMalloc((void **)&d_log, words * sizeof(uint32_t)));
     hipError_t e = hipMemsetAsync(d_log, 0, words * sizeof(uint32_t), c->stream);
@@ -1631,7 +1657,10 @@ int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
             const uint64_t units = (uint64_t)tiles * ((1u + kch - 1) / kch);
             const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * c->trace_wgs, (units + TRACE_WAVES - 1) / TRACE_WAVES);
             dim3 g(grid), b(64 * TRACE_WAVES);
-            if (c->dsc.qnodes) hipLaunchKernelGGL((trace_kernel<false, 3, true, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+            if (c->precise) {
+                if (c->dsc.qnodes) hipLaunchKernelGGL((trace_kernel<false, 3, true, false, true, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+                else hipLaunchKernelGGL((trace_kernel<false, 3, false, false, true, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
+            } else if (c->dsc.qnodes) hipLaunchKernelGGL((trace_kernel<false, 3, true, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
             else hipLaunchKernelGGL((trace_kernel<false, 3, false, false, true>), g, b, 0, c->stream, c->dsc, rp, c->recs[0], c->d_counters, c->d_tile_counter, d_log);
             e = hipGetLastError();
         }

@@ -707,6 +707,10 @@ HD int32_t hit_element(const Scene &sc, const TraceState &ts) {
     return (ts.type == 0) ? sc.tri_shade[ts.prim].element : (ts.type == 1 ? sc.sphere_elem[ts.prim] : float_as_int(sc.cuboids[2 * ts.prim].w));
 }
 
+}  // namespace hr
+#include "prec_core.h"
+namespace hr {
+
 // Per-path event log (hr_debug_path_log: the parity accounting of tests/test_gpu_parity.py and profiles/r04_parity_report.json).  The
 // oracle keeps the same log (oracle.cpp PathLog): two paths "took the same branches" when their logs are equal.
 //   one byte per iteration i = 1..9 (renderer.rs:174), byte i - 1 of ev (i <= 8) / ev9:
@@ -775,7 +779,10 @@ HD float rr_uniform(uint32_t tile, uint32_t q, uint32_t salt, uint32_t iter) {
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-template <bool CNT, bool RR = false, bool LOG = false>
+// PREC (option precise_shading): the geometry of the bounce in f64 (prec_core.h shade_hit_f64).  The ray's residuals — what rounding the f64 ray
+// to the fp32 ray the traversal walks took away — do not live in registers: they are parked in the six dead slots of the path's own record that
+// path_start uses for the camera ray's (ray_fix_slot), read when the main ray's hit is shaded and overwritten with the next ray's.
+template <bool CNT, bool RR = false, bool LOG = false, bool PREC = false>
 HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const float *recs, LaneCounters *cn, uint32_t rr_start = 0u, uint32_t rr_salt = 0u, PathLog *lg = nullptr) {
     if (CNT) cn->rays++;
     if (LOG) lg->rays++;
@@ -791,6 +798,31 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
             p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
             return true;
         }
+        if (PREC) {
+            const uint32_t lb = path_draw_base(p), a2 = (p.q >> 12) & 15u;
+            V3f fo, fd;
+            ray_fix_load(recs, lb, a2, fo, fd);
+            PrecHit x;
+            shade_hit_f64(sc, p.ray.o, p.ray.d, fo, fd, p.ts, p.r0, p.r1, x);
+            p.view = -p.ray.d;
+            if (LOG) {
+                if (p.ts.type == 2) plog_hit(*lg, 0x1000 + cuboid_face_of(x.nf));
+                const Material mt = sc.materials[x.s.elem];
+                plog_quad(sc, *lg, mt.albedo_img, x.s.u, x.s.v); plog_quad(sc, *lg, mt.emission_img, x.s.u, x.s.v); plog_quad(sc, *lg, mt.roughness_img, x.s.u, x.s.v);
+                plog_hit(*lg, x.s.elem);
+                if (p.ts.type == 1) lg->ev9 += 256u;
+                if (p.ts.type == 0) plog_hit(*lg, (int32_t)(sc.tri_face[p.ts.prim] + 0x9e3779b9u));
+                plog_or(*lg, path_iter(p), x.sampled ? (2u + (uint32_t)x.m.surface) | (x.transmitted ? 8u : 0u) : 7u);
+            }
+            if (!x.sampled) return true;
+            p.accum = p.accum + p.refl * x.m.emission;
+            p.refl = p.refl * x.m.albedo;
+            p.next_o = narrow(x.no); p.next_d = narrow(x.nd); p.cur_refl = x.cur_refl;
+            ray_fix_store(const_cast<float *>(recs), lb, a2, residual(x.no, p.next_o), residual(x.nd, p.next_d));
+            if (!(nee_available(x.m.surface) && sc.num_emitters > 0)) goto bounce;
+            p.n = x.nf; p.param = x.m.param; p.roughness = x.m.roughness;
+            p.st = (p.st & 15u) | ((uint32_t)x.m.surface << 5);
+        } else {
         Surf s;
         RayFix fix = no_ray_fix();
         if (p.ts.type == 1 && path_iter(p) == 1u) {   // a primary ray on a sphere: hit point and normal from the f64 camera ray (path_start's residuals)
@@ -815,6 +847,7 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         if (!(nee_available(m.surface) && sc.num_emitters > 0)) goto bounce;
         p.n = s.n; p.param = m.param; p.roughness = m.roughness;
         p.st = (p.st & 15u) | ((uint32_t)m.surface << 5);   // emitter 0; the phase bit is set by nee_setup
+        }
     } else {
         // renderer.rs:280-292.  Hit point and sample point lie on the same ray: |hit - sample| = |t - shadow_len|
         float dt = p.ts.t - p.shadow_len;

@@ -118,7 +118,8 @@ __device__ __forceinline__ void flush_counters(Counters *cnt, uint32_t lane, uin
 // LOG (hr_debug_path_log only): every path also leaves its event log (pt_core.h PathLog) and its own radiance in plog — eight 32-bit
 // words per path, indexed ((y * W + x) * 4 + sub-sample) for the launch's first sampling: {r, g, b (float bits), rays, ev low, ev high, ev9, hash}.
 // The same kernel, the same path_advance: what is logged is what hr_render computes.
-template <bool CNT, int MINW, bool QN, bool RR = false, bool LOG = false>
+// PREC (option precise_shading): path_advance shades in f64 (prec_core.h); instantiated for 128 VGPRs (MINW 4).
+template <bool CNT, int MINW, bool QN, bool RR = false, bool LOG = false, bool PREC = false>
 __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc, RenderParams rp, float *recs, Counters *cnt, uint32_t *tile_counter, uint32_t *plog = nullptr) {
     // the wave budget (device_scene.h GovDev::budget; debug option trace_budget pins it): surplus workgroups leave before they touch anything
     // ONE budget per launch: the governor of the launch before may store a new one while this launch's workgroups are still starting, so the
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
         }
         HR_PHASE_BEGIN(ws);
         if (p.q != PATH_IDLE && trace_done(p.ts)) {
-            if (path_advance<CNT, RR, LOG>(sc, rp, p, recs + (size_t)p.tile * tile_stride, &lc, rp.rr_start, rp.sampling_begin * 64u + rp.stride, &lg)) {
+            if (path_advance<CNT, RR, LOG, PREC>(sc, rp, p, recs + (size_t)p.tile * tile_stride, &lc, rp.rr_start, rp.sampling_begin * 64u + rp.stride, &lg)) {
                 // A finished path leaves its radiance in its own hand-off record (quad 0: the draws there have been consumed), and
                 // accumulate_kernel below sums the records of a pixel into the accumulator behind this kernel.  Until round 3 the path
                 // added its radiance straight into the accumulator with three agent-scope atomics (several waves, on other XCDs,

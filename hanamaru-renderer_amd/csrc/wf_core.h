@@ -171,82 +171,7 @@ HD bool wf_bounces(const WfPath &p, const WfBounce &b) { return !(is_zero(p.refl
 
 
 // ---------------------------------------------------------------------------------------------
-// PRECISE shading (option shading_precision 1): the geometry of a bounce in the reference's own precision.  The walk stays fp32 — it only
-// has to find the right primitive —, but the ray the path really follows is carried as fp32 + residual (o + o_lo, d + d_lo: what rounding
-// the f64 ray to the fp32 ray the traversal walks took away), and everything between "this primitive was hit" and "the next ray" is f64:
-// the hit distance again from the f64 ray and the f64 primitive (triangle plane from the f64 vertices: Scene::tri_exact; sphere centre and
-// radius: sphere_lo; cuboid bounds: cuboid_lo), hit point, normal, mirror / Snell / Fresnel (material.rs:154-199, vector.rs:60-71).  A
-// faceted glass body is a billiard and a small sphere multiplies a position error by 2 t / r per bounce: fp32 ray state leaves 100 - 1,000 ppm
-// of the paths that took the reference's branches off by more than 1e-3 in such scenes; the megakernel has no registers
-// for this (profiles/NOTES.md G), the shading kernel of the split pipeline does.  What stays fp32: the draws themselves (the hand-off
-// record holds them rounded once), the directions SAMPLED from them (diffuse lobe, GGX half vector), textures, radiometry.
-struct D3 { double x, y, z; };
-HD D3 dv(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
-HD D3 operator+(D3 a, D3 b) { return dv(a.x + b.x, a.y + b.y, a.z + b.z); }
-HD D3 operator-(D3 a, D3 b) { return dv(a.x - b.x, a.y - b.y, a.z - b.z); }
-HD D3 operator*(D3 a, double s) { return dv(a.x * s, a.y * s, a.z * s); }
-HD D3 operator-(D3 a) { return dv(-a.x, -a.y, -a.z); }
-HD double ddot(D3 a, D3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
-HD D3 widen(V3f hi, V3f lo) { return dv((double)hi.x + (double)lo.x, (double)hi.y + (double)lo.y, (double)hi.z + (double)lo.z); }
-HD V3f narrow(D3 a) { return v3((float)a.x, (float)a.y, (float)a.z); }
-HD V3f residual(D3 a, V3f hi) { return v3((float)(a.x - (double)hi.x), (float)(a.y - (double)hi.y), (float)(a.z - (double)hi.z)); }
-HD D3 dreflect(D3 v, D3 n) { return v - n * (2.0 * ddot(v, n)); }   // vector.rs:60-62
-
-// material.rs:154-199 in f64.  `in` = direction of the arriving ray.  Returns the new ray and the reflectance scalar; transmitted as in pt_core.h.
-HD void sample_refraction_f64(double r0, D3 pos, D3 in, D3 n, double ior, D3 &no, D3 &nd, float &refl, bool &transmitted) {
-    transmitted = false;
-    const bool incoming = signbit(ddot(in, n));
-    const D3 on = incoming ? n : -n;
-    const double nnt = incoming ? 1.0 / ior : ior;
-    const D3 rdir = dreflect(in, on);
-    const double vn = ddot(in, on);
-    const double k = 1.0 - nnt * nnt * (1.0 - vn * vn);      // vector.rs:64-71
-    if (k < 0.0) { no = pos + on * (double)OFFSET_F; nd = rdir; refl = 1.0f; return; }
-    const D3 tdir = in * nnt - on * (nnt * vn + sqrt(k));
-    if (tdir.x == 0.0 && tdir.y == 0.0 && tdir.z == 0.0) { no = pos + on * (double)OFFSET_F; nd = rdir; refl = 1.0f; return; }
-    const double cos_i = -ddot(in, on), cos_t = -ddot(tdir, on);
-    const double a = nnt * cos_i - cos_t, b = nnt * cos_i + cos_t, c = nnt * cos_t - cos_i, d = nnt * cos_t + cos_i;
-    const double fr = 0.5 * (a * a / (b * b) + c * c / (d * d));
-    if (r0 <= fr) { no = pos + on * (double)OFFSET_F; nd = rdir; refl = 1.0f; }
-    else { no = pos - on * (double)OFFSET_F; nd = tdir; refl = (float)(nnt * nnt); transmitted = true; }
-}
-
-// sin / cos of 2 pi r for r in [0, 1), to f64 accuracy: quadrant + Taylor polynomials on [-pi/4, pi/4] (no f64 transcendental hardware;
-// the fp32 v_sin_f32 / v_cos_f32 the megakernel uses are off by up to ~1e-6 — more than the rounding of the draw itself).  The same code
-// on the host: the emulation and the kernels agree.
-HD void sincos_2pi_f64(double r, double &sn, double &cs) {
-    const double q = floor(r * 4.0 + 0.5);
-    const double x = (r - q * 0.25) * 6.28318530717958647692, x2 = x * x;
-    const double sx = x * fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0), -1.0 / 39916800.0), 1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
-    const double cx = fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 20922789888000.0, -1.0 / 87178291200.0), 1.0 / 479001600.0), -1.0 / 3628800.0), 1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
-    const int k = (int)q & 3;
-    sn = k == 0 ? sx : k == 1 ? cx : k == 2 ? -sx : -cx;
-    cs = k == 0 ? cx : k == 1 ? -sx : k == 2 ? -cx : sx;
-}
-HD D3 dcross(D3 a, D3 b) { return dv(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-HD void tangent_basis_f64(D3 n, D3 &t, D3 &b) {  // material.rs:202-211
-    const D3 up = fabs(n.x) > 1e-4 ? dv(0, 1, 0) : dv(1, 0, 0);
-    const D3 c = dcross(up, n);
-    t = c * (1.0 / sqrt(ddot(c, c)));
-    b = dcross(n, t);
-}
-HD D3 sample_diffuse_f64(double r0, double r1, D3 n) {  // material.rs:227-248
-    D3 t, b;
-    tangent_basis_f64(n, t, b);
-    double sn, cs;
-    sincos_2pi_f64(r0, sn, cs);
-    return (t * cs + b * sn) * sqrt(r1) + n * sqrt(1.0 - r1);
-}
-HD D3 sample_ggx_half_f64(double r0, double r1, D3 n, double alpha2) {  // material.rs:260-269
-    D3 t, b;
-    tangent_basis_f64(n, t, b);
-    double sn, cs;
-    sincos_2pi_f64(r0, sn, cs);
-    const double cos_theta = sqrt((1.0 - r1) / (1.0 + (alpha2 - 1.0) * r1));
-    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-    return t * (sin_theta * cs) + b * (sin_theta * sn) + n * cos_theta;
-}
-
+// precise shading in the split pipeline: prec_core.h's shade_hit_f64 (shared with the megakernel's path_advance<.., PREC>) + the queue records
 struct WfBounceX { V3f next_o_lo, next_d_lo; };   // the residuals of WfBounce::next_o / next_d (precise shading only)
 
 // wf_surface with the geometry in f64.  (ro, rd) + (fo, fd) = the ray the path follows; h = what the fp32 walk found.
@@ -265,94 +190,15 @@ HD bool wf_surface_f64(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f
         p.accum = p.accum + p.refl * sky_sample(sc, rd);
         return true;
     }
-    const D3 o = widen(ro, fo), d = widen(rd, fd);
-    D3 pos, n;
-    Surf s;
-    s.u = ts.u; s.v = ts.v;
-    const bool want_uv = material_needs_uv(sc, hit_element(sc, ts));
-    if (ts.type == 0) {            // bvh.rs:266-290: the plane of the f64 triangle
-        s.elem = sc.tri_shade[ts.prim].element;
-        const TriX tx = sc.tri_exact[sc.tri_face[ts.prim]];
-        n = dv(tx.n[0], tx.n[1], tx.n[2]);
-        const D3 v0 = dv(tx.v0[0], tx.v0[1], tx.v0[2]);
-        const double t = -ddot(n, o - v0) / ddot(n, d);
-        pos = o + d * t;
-    } else if (ts.type == 1) {     // scene.rs:58-66, the root again from the f64 ray and the f64 sphere
-        const f4 sp = sc.spheres[ts.prim], lo = sc.sphere_lo[ts.prim];
-        s.elem = sc.sphere_elem[ts.prim];
-        const D3 c = dv((double)sp.x + (double)lo.x, (double)sp.y + (double)lo.y, (double)sp.z + (double)lo.z);
-        const double cr = (double)sp.w + (double)lo.w;
-        const D3 a = o - c;
-        const double idd = 1.0 / ddot(d, d);     // (a sampled direction is a unit vector to fp32 only)
-        const double bq = ddot(a, d) * idd;
-        const D3 q = a - d * bq;
-        const double disc = (cr * cr - ddot(q, q)) * idd;
-        const double t = -bq - sqrt(disc > 0.0 ? disc : 0.0);
-        const D3 nn = a + d * t;
-        n = nn * (1.0 / sqrt(ddot(nn, nn)));
-        pos = c + nn;
-        if (want_uv) {  // scene.rs:67-71
-            const V3f nf = narrow(n);
-            s.v = 1.0f - acosf(fminf(fmaxf(nf.y, -1.0f), 1.0f)) * (1.0f / PI_F);
-            float sg = signbit(nf.z) ? -1.0f : 1.0f;
-            s.u = 0.5f - sg * acosf(fminf(fmaxf(nf.x * HR_RSQ(nf.x * nf.x + nf.z * nf.z), -1.0f), 1.0f)) * (1.0f / PI2_F);
-        }
-    } else {                       // bvh.rs:20-39 + scene.rs:152-182 on the f64 box
-        const f4 mnf = sc.cuboids[2 * ts.prim], mxf = sc.cuboids[2 * ts.prim + 1];
-        s.elem = float_as_int(mnf.w);
-        const f4 mnl = sc.cuboid_lo[2 * s.elem], mxl = sc.cuboid_lo[2 * s.elem + 1];
-        const D3 mn = dv((double)mnf.x + (double)mnl.x, (double)mnf.y + (double)mnl.y, (double)mnf.z + (double)mnl.z);
-        const D3 mx = dv((double)mxf.x + (double)mxl.x, (double)mxf.y + (double)mxl.y, (double)mxf.z + (double)mxl.z);
-        const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
-        const double t1 = (mn.x - o.x) * ix, t2 = (mx.x - o.x) * ix, t3 = (mn.y - o.y) * iy, t4 = (mx.y - o.y) * iy, t5 = (mn.z - o.z) * iz, t6 = (mx.z - o.z) * iz;
-        const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6)), tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
-        // the fp32 walk decided that the box is hit; should the f64 slabs disagree at a grazing edge, the walk's distance stands
-        const double dist = (tmin <= tmax && !signbit(tmax)) ? (signbit(tmin) ? tmax : tmin) : (double)ts.t;
-        pos = o + d * dist;
-        const D3 uvw = dv((pos.x - mn.x) / (mx.x - mn.x), (pos.y - mn.y) / (mx.y - mn.y), (pos.z - mn.z) / (mx.z - mn.z));
-        const double E = 1e-4;   // config.rs:7
-        int face;
-        if (fabs(pos.y - mx.y) < E) face = 0; else if (fabs(pos.y - mn.y) < E) face = 1; else if (fabs(pos.x - mn.x) < E) face = 2;
-        else if (fabs(pos.x - mx.x) < E) face = 3; else if (fabs(pos.z - mn.z) < E) face = 4; else if (fabs(pos.z - mx.z) < E) face = 5;
-        else {   // (cannot happen for a hit found in f64; the nearest face, as hit_surface)
-            const double dy1 = fabs(pos.y - mx.y), dy0 = fabs(pos.y - mn.y), dx0 = fabs(pos.x - mn.x), dx1 = fabs(pos.x - mx.x), dz0 = fabs(pos.z - mn.z), dz1 = fabs(pos.z - mx.z);
-            const double best = fmin(fmin(fmin(dy1, dy0), fmin(dx0, dx1)), fmin(dz0, dz1));
-            face = best == dy1 ? 0 : best == dy0 ? 1 : best == dx0 ? 2 : best == dx1 ? 3 : best == dz0 ? 4 : 5;
-        }
-        if (face == 0) { n = dv(0, 1, 0); s.u = (float)uvw.x; s.v = (float)(1.0 - uvw.z); }
-        else if (face == 1) { n = dv(0, -1, 0); s.u = (float)uvw.x; s.v = (float)(1.0 - uvw.z); }
-        else if (face == 2) { n = dv(-1, 0, 0); s.u = (float)uvw.z; s.v = (float)uvw.y; }
-        else if (face == 3) { n = dv(1, 0, 0); s.u = (float)uvw.z; s.v = (float)uvw.y; }
-        else if (face == 4) { n = dv(0, 0, -1); s.u = (float)uvw.x; s.v = (float)uvw.y; }
-        else { n = dv(0, 0, 1); s.u = (float)uvw.x; s.v = (float)uvw.y; }
-    }
-    const V3f nf = narrow(n);
-    PointMat m;
-    material_at(sc, s.elem, s.u, s.v, m);
+    PrecHit x;
+    shade_hit_f64(sc, ro, rd, fo, fd, ts, b.r0, b.r1, x);
     b.view = -rd;
-    bool transmitted = false, sampled = true;
-    D3 no, nd;
-    switch (m.surface) {       // material.rs:91-151
-        case 0: no = pos + n * (double)OFFSET_F; nd = sample_diffuse_f64((double)b.r0, (double)b.r1, n); b.cur_refl = 1.0f; break;
-        case 1: no = pos + n * (double)OFFSET_F; nd = dreflect(d, n); b.cur_refl = 1.0f; break;
-        case 2: sample_refraction_f64((double)b.r0, pos, d, n, (double)m.param, no, nd, b.cur_refl, transmitted); break;
-        case 3: {
-            const float alpha2 = m.roughness * m.roughness;
-            const D3 hh = sample_ggx_half_f64((double)b.r0, (double)b.r1, n, (double)m.roughness * (double)m.roughness);
-            nd = dreflect(d, hh);
-            const double lnd = ddot(nd, n);
-            if (signbit(lnd)) { sampled = false; break; }
-            const float ln = (float)lnd, vn = (float)-ddot(d, n), vh = (float)-ddot(d, hh), hn = (float)ddot(hh, n);
-            b.cur_refl = f_schlick(vh, m.param) * saturatef(g_smith_joint(ln, vn, alpha2) * vh * HR_RCP(hn * vn));
-            no = pos + n * (double)OFFSET_F;
-            break;
-        }
-        default: {
-            const D3 hh = sample_ggx_half_f64((double)b.r0, (double)b.r1, n, (double)m.roughness * (double)m.roughness);
-            sample_refraction_f64((double)b.r0, pos, d, hh, (double)m.param, no, nd, b.cur_refl, transmitted);
-            break;
-        }
-    }
+    b.cur_refl = x.cur_refl;
+    const PointMat &m = x.m;
+    const Surf &s = x.s;
+    const V3f nf = x.nf;
+    const bool sampled = x.sampled, transmitted = x.transmitted;
+    const D3 no = x.no, nd = x.nd;
     if (LOG) {
         if (ts.type == 2) plog_hit(*lg, 0x1000 + cuboid_face_of(nf));
         const Material mt = sc.materials[s.elem];

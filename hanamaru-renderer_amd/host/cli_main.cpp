@@ -54,7 +54,8 @@ static void usage(const char *prog) {
            "                        launch are printed when it is done, its time split evenly over them; 1 = a launch per report\n"
            "        --inflight K    launches enqueued ahead on the GPU (default 8; 1 = wait for every launch before the next starts)\n"
            "        --precise       precise shading: the geometry of every bounce in f64 (hr_set_option \"precise_shading\"): closer to the reference's\n"
-           "                        f64 arithmetic on refraction chains and small spheres, a few per cent slower\n"
+           "                        f64 arithmetic on refraction chains and small spheres; default: on for scenes without meshes (where it is all but\n"
+           "                        free), off for mesh scenes (where it costs 5 - 20 %%); --no-precise: fp32 shading whatever the scene\n"
            "        --gpus N        render on devices 0..N-1 of this node from this one process: device r takes every N-th sampling,\n"
            "                        the accumulators are summed with one RCCL all-reduce when an image is written (default 1)\n"
            "        --gpu-ids LIST  the same with an explicit comma-separated device list\n"
@@ -71,7 +72,8 @@ int main(int argc, char **argv) {
     int batch = 1;      // samplings per report_progress call ("rendering:" line); 1 = the reference's cadence
     int launch = 0;     // reports per GPU launch; 0 = as many as fill the chip (4 samplings per device at 1920x1080)
     int inflight = 8;   // launches enqueued ahead of the one being reported
-    bool debug = false, precise = false;
+    bool debug = false;
+    int precise = -1;    // option precise_shading: -1 = the library's automatic choice
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -90,7 +92,8 @@ int main(int argc, char **argv) {
         else if (a == "--batch") batch = atoi(val("batch"));
         else if (a == "--launch") launch = atoi(val("launch"));
         else if (a == "--inflight") inflight = atoi(val("inflight"));
-        else if (a == "--precise") precise = true;
+        else if (a == "--precise") precise = 1;
+        else if (a == "--no-precise") precise = 0;
         else if (a == "--gpus") gpus = atoi(val("gpus"));
         else if (a == "--gpu-ids") gpu_ids = val("gpu-ids");
         else if (a == "--checkpoint") ckpt_out = val("checkpoint");
@@ -137,7 +140,7 @@ int main(int argc, char **argv) {
         CHECK_HR(hr_create(devices[r], &ctxs[r]));
         CHECK_HR(hr_upload_scene(ctxs[r], hh_scene_desc(scene)));
         CHECK_HR(hr_set_resolution(ctxs[r], width, height));
-        if (precise) CHECK_HR(hr_set_option(ctxs[r], "precise_shading", 1.0));
+        if (precise >= 0) CHECK_HR(hr_set_option(ctxs[r], "precise_shading", (double)precise));
     }
     hr_ctx *ctx = ctxs[0];
     if (ndev > 1) tee("devices: %u.", ndev);

@@ -89,7 +89,7 @@ class Stats(C.Structure):
                 ("leaf_calls", C.c_uint64), ("leaf_lanes", C.c_uint64), ("outer_iters", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
                 ("bvh_build_ms", C.c_double), ("seed_phase_cycles", C.c_uint64 * 8),
                 ("debug_kernel_ms", C.c_double), ("debug_launches", C.c_uint64),
-                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64), ("shadow_culled", C.c_uint64), ("governor_budget", C.c_uint64), ("governor_budget_moves", C.c_uint64), ("bvh_builder_used", C.c_uint64)]
+                ("governor_level", C.c_uint64), ("governor_decisions", C.c_uint64), ("governor_moves", C.c_uint64), ("shadow_culled", C.c_uint64), ("governor_budget", C.c_uint64), ("governor_budget_moves", C.c_uint64), ("bvh_builder_used", C.c_uint64), ("shading_in_force", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if hasattr(getattr(self, k), "__len__") else getattr(self, k)) for k, _ in self._fields_}

@@ -135,6 +135,8 @@ typedef struct hr_stats {
      * kernel is the faster kernel of the pair and its surplus waves only slow the seed kernel beside it —, and how often it changed */
     uint64_t governor_budget, governor_budget_moves;
     uint64_t bvh_builder_used;  /* the builder the last hr_upload_scene used (0 host SAH, 1 device LBVH, 2 device PLOC): what option bvh_builder = -1 chose */
+    uint64_t shading_in_force;  /* what option precise_shading means for the scene in place: 0 = fp32 shading (megakernel), 1 = precise shading in the
+                                 * megakernel, 2 = precise shading in the split pipeline (same bits as 1), 3 = fp32 shading in the split pipeline (debug) */
 } hr_stats;
 
 typedef struct hr_ctx hr_ctx;
@@ -249,14 +251,16 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *                   (hr_stats.governor_level / governor_budget say where it stands)
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
- *   "precise_shading"  0 (default) = the megakernel, a bounce shaded in fp32; 1 = the split pipeline (a traversal kernel and a shading
- *                   kernel per path iteration, the path parked in HBM between them) with the GEOMETRY of every bounce in the reference's
- *                   own f64: hit distance again from the f64 ray and the f64 primitive, hit point, normal, mirror / Snell / Fresnel
- *                   (material.rs:154-199) and the sampled lobe directions; the ray is carried as fp32 + residual, the walk stays fp32.
- *                   Same estimator, same draws, closer to the reference: the paths that take the reference's branches and still differ
- *                   by more than 1e-3 — refraction chains through faceted glass, bounces off small spheres — fall from 90 - 990 to
- *                   4 - 33 per million.  Costs 5 % where the seed kernel bounds the pair, ~20 % where the traversal does.
- *                   (Excludes "russian_roulette".)
+ *   "precise_shading"  the GEOMETRY of every bounce in the reference's own f64: hit distance again from the f64 ray and the f64 primitive, hit
+ *                   point, normal, mirror / Snell / Fresnel (material.rs:154-199) and the sampled lobe directions; the ray is carried as fp32 +
+ *                   residual, the walk stays fp32.  Same estimator, same draws, closer to the reference: the paths that take the reference's
+ *                   branches and still differ by more than 1e-3 — refraction chains through faceted glass, bounces off small spheres — fall
+ *                   from 90 - 990 to 4 - 33 per million.  Two implementations that render the same bits: in the megakernel
+ *                   at 128 VGPRs (0.4 - 1.6 % slower on scenes without meshes, 9 - 25 % on mesh scenes) and in the split pipeline's shading
+ *                   kernel (5 - 20 % on mesh scenes); the library takes the faster one for the scene.
+ *                   -1 (default) = automatic: ON for scenes without triangle meshes (BASELINE config 2: small spheres are what multiplies an
+ *                   fp32 ray's error, and there it is all but free), OFF for the others; 0 = off; 1 = on.  hr_stats.shading_in_force says
+ *                   what runs.  (1 excludes "russian_roulette"; -1 stands back when the roulette is on.)
  *   next hr_upload_scene:
  *   "bvh_builder"   -1 = by scene size (default): the host's binned-SAH build below 200,000 primitives (the best tree; one host thread,
  *                   < 1 s), the device PLOC build from there on (0.97 - 0.99 of that tree's quality; 4 x 10^6 triangles in 38 ms instead of

@@ -330,6 +330,9 @@ int emu_raw_draws_seg(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t
 // nee_setup's shortcuts (pt_core.h): mask of the ones in force (7 = all: the kernel's default), 0 = every NEE shadow ray is traced
 static int g_nee_cull = 7;
 void emu_set_nee_cull(int on) { g_nee_cull = on; }
+// option precise_shading for the megakernel's per-lane code (path_advance<.., PREC>): emu_render / emu_path_log
+static int g_precise = 0;
+void emu_set_precise(int on) { g_precise = on; }
 
 // counters: paths, rays, node_tests, tri_tests, sphere_tests, cuboid_tests, shadow_culled
 int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc,
@@ -359,7 +362,7 @@ int emu_render(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uin
                         LaneCounters lc = {0, 0, 0, 0, 0, 0};
                         for (;;) {
                             while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
-                            if (path_advance<true>(sc, rpp, p, rec.f, &lc)) break;
+                            if (g_precise ? path_advance<true, false, false, true>(sc, rpp, p, rec.f, &lc) : path_advance<true>(sc, rpp, p, rec.f, &lc)) break;
                         }
                         sum[0] += p.accum.x; sum[1] += p.accum.y; sum[2] += p.accum.z;
                         cn[tid][0]++; cn[tid][1] += lc.rays; cn[tid][2] += lc.node_tests; cn[tid][3] += lc.tri_tests;
@@ -544,7 +547,7 @@ int emu_path_log(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, 
 #endif
                     for (;;) {
                         while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
-                        if (path_advance<true, false, true>(sc, rpp, p, rec.f, &lc, 0u, 0u, &lg)) break;
+                        if (g_precise ? path_advance<true, false, true, true>(sc, rpp, p, rec.f, &lc, 0u, 0u, &lg) : path_advance<true, false, true>(sc, rpp, p, rec.f, &lc, 0u, 0u, &lg)) break;
                     }
                     uint32_t *o = out + (((size_t)y * W + x) * 4 + sub) * 8;
                     o[0] = float_as_uint(p.accum.x); o[1] = float_as_uint(p.accum.y); o[2] = float_as_uint(p.accum.z); o[3] = lg.rays;

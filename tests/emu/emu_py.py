@@ -111,6 +111,12 @@ def set_walk_mode(mode):
     lib().emu_set_walk_mode(mode)
 
 
+def set_precise(on):
+    """option precise_shading for render / path_log (the megakernel's per-lane code, path_advance<.., PREC>)"""
+    lib().emu_set_precise.argtypes = [C.c_int]
+    lib().emu_set_precise(1 if on else 0)
+
+
 def set_nee_cull(on):
     """nee_setup's shortcuts (pt_core.h): shadow rays known to add nothing are not traced (default on)."""
     lib().emu_set_nee_cull.argtypes = [C.c_int]

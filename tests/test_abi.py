@@ -55,7 +55,7 @@ def test_struct_layouts_match_header(ha):
     assert C.sizeof(ha.Vec3) == 24 and C.sizeof(ha.Texture) == 32 and C.sizeof(ha.Material) == 16 + 3 * 32
     assert C.sizeof(ha.Image) == 16 and C.sizeof(ha.Camera) == 6 * 24 + 24 and C.sizeof(ha.Skybox) == 48
     assert C.sizeof(ha.Element) == 8 + 112 + 32 + 48 + 32
-    assert C.sizeof(ha.Stats) == 45 * 8 and C.sizeof(ha.CommInfo) == 32
+    assert C.sizeof(ha.Stats) == 46 * 8 and C.sizeof(ha.CommInfo) == 32
 
 
 def test_no_device_is_a_clean_error(ha):

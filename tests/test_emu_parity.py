@@ -503,7 +503,14 @@ def test_precise_shading_closes_the_same_branch_tail(emu, emu_scenes, name, fp32
     w, h = 128, 72
     ref = o.path_log(w, h, 1)
     a32 = path_parity.account(e.path_log(w, h, 1), ref)
-    a64 = path_parity.account(e.path_log_wf(w, h, 1), ref)
+    lw = e.path_log_wf(w, h, 1)
+    a64 = path_parity.account(lw, ref)
+    try:        # the megakernel's per-lane code with PREC (path_advance<.., PREC>: residuals parked in the path's record): the same log, word for word
+        emu.set_precise(True)
+        for x, y in zip(lw, e.path_log(w, h, 1)):
+            assert np.array_equal(x, y)
+    finally:
+        emu.set_precise(False)
     s32, s64 = a32["same_branch"], a64["same_branch"]
     print("%s: fp32 divergent %.0f ppm, same-branch beyond 1e-3 %.0f ppm (worst %.3g); precise %.0f / %.0f ppm (worst %.3g)" % (
         name, a32["divergent_ppm"], s32["over_1e-3_floor1_ppm"], s32["max_rel_floor1"], a64["divergent_ppm"], s64["over_1e-3_floor1_ppm"], s64["max_rel_floor1"]))

@@ -289,13 +289,13 @@ def test_radiance_accumulator_matches_oracle(gpu, scenes, name, w, h, s, precise
     gpu.upload_scene(sc)
     gpu.set_resolution(w, h)
     gpu.set_option("batch", 3)
-    gpu.set_option("precise_shading", precise)
+    gpu.set_option("precise_shading", precise)      # (0 = fp32 shading pinned: the automatic choice turns precise shading on for scenes without meshes)
     try:
         gpu.render(1, s + 1)
         acc = gpu.read_accumulator()
     finally:
         gpu.set_option("batch", 0)   # back to automatic
-        gpu.set_option("precise_shading", 0)
+        gpu.set_option("precise_shading", -1)
     ref, _ = o.render(w, h, 1, s + 1, threads=0)
     _check_scene(name, acc, ref, "%dx%dx%d%s" % (w, h, s, " precise" if precise else ""), GATES_PRECISE if precise else GATES)
     m_gpu, m_ref = float(acc.mean()), float(ref.mean())
@@ -355,12 +355,17 @@ def test_per_path_parity_accounting_precise_shading(gpu, scenes, name):
     try:
         _per_path_accounting(gpu, scenes, name, PATH_LIMITS_PRECISE, "precise")
     finally:
-        gpu.set_option("precise_shading", 0)
+        gpu.set_option("precise_shading", -1)
 
 
 @pytest.mark.parametrize("name", sorted(PATH_LIMITS))
 def test_per_path_parity_accounting(gpu, scenes, name):
-    _per_path_accounting(gpu, scenes, name, PATH_LIMITS, "default")
+    """fp32 shading (pinned: option precise_shading 0; the automatic choice would shade `spheres`, a scene without meshes, in f64)."""
+    gpu.set_option("precise_shading", 0)
+    try:
+        _per_path_accounting(gpu, scenes, name, PATH_LIMITS, "fp32 shading")
+    finally:
+        gpu.set_option("precise_shading", -1)
 
 
 def _per_path_accounting(gpu, scenes, name, limits, label):
@@ -455,7 +460,7 @@ def test_random_scenes_path_by_path(gpu, ha, orc, seed, builder, precise):
         gpu.render(1, 3)
         acc = gpu.read_accumulator().copy()
     finally:
-        gpu.set_option("precise_shading", 0)
+        gpu.set_option("precise_shading", -1)
     rad = g[0]
     assert np.array_equal(acc1, ((rad[:, :, 0] + rad[:, :, 1]) + (rad[:, :, 2] + rad[:, :, 3])).astype(np.float32))
     a = path_parity.account(g, o.path_log(w, h, 1))
@@ -1065,6 +1070,21 @@ def test_kernel_variants_render_the_same_bits(gpu, scenes):
         gpu.set_option("counters", 1)
         assert np.array_equal(ref, render()), "split pipeline, instrumented build"
         gpu.set_option("counters", 0)
+        # option precise_shading has two homes too — path_advance<.., PREC> in the megakernel (the residuals parked in the path's record) and
+        # the split pipeline's shading kernel (the residuals in the queued state): one function (prec_core.h shade_hit_f64), the same bits
+        gpu.set_option("precise_shading", 1)
+        prec_split = render()
+        prec_split_log = gpu.debug_path_log(3)
+        gpu.set_debug_option("trace_mode", 0)
+        assert np.array_equal(prec_split, render()), "precise shading: megakernel vs split pipeline"
+        assert not np.array_equal(prec_split, ref)
+        for a, b in zip(prec_split_log, gpu.debug_path_log(3)):
+            assert np.array_equal(a, b), "precise shading, path log"
+        gpu.set_option("counters", 1)
+        assert np.array_equal(prec_split, render()), "precise shading, instrumented build"
+        gpu.set_option("counters", 0)
+        gpu.set_option("precise_shading", -1)
+        gpu.set_debug_option("trace_mode", 1)
         gpu.set_option("quant_nodes", 0)
         gpu.upload_scene(sc)
         assert np.array_equal(ref, render()), "split pipeline, fp32 node records"
@@ -1076,7 +1096,8 @@ def test_kernel_variants_render_the_same_bits(gpu, scenes):
         assert np.array_equal(ref, render()), "device-built tree"
     finally:
         gpu.set_option("counters", 0)
-        gpu.set_debug_option("trace_mode", 0)
+        gpu.set_option("precise_shading", -1)
+        gpu.set_debug_option("trace_mode", -1)
         gpu.set_debug_option("min_waves", 5)
         gpu.set_option("quant_nodes", 1)
         gpu.set_option("bvh_builder", -1)
@@ -1364,7 +1385,39 @@ def test_config5_4k_crops_precise_shading(gpu, scenes):
     finally:
         gpu.set_option("max_tail_gib", 20)
         gpu.set_option("counters", 0)
-        gpu.set_option("precise_shading", 0)
+        gpu.set_option("precise_shading", -1)
+
+
+def test_precise_shading_defaults_and_finite_radiance(gpu, scenes):
+    """Option precise_shading = -1 (default): ON for scenes without triangle meshes (in the megakernel), OFF for mesh scenes; pinned on, a
+    mesh scene takes the split pipeline (same bits, faster there).  And the regression of round 6's one NaN: rtcamp5's roughness map has texels
+    of ~1e-8, where the reference's own GGX half-vector expression (material.rs:264-265) rounds to sqrt(-4e-16); sampling 192 of the 1080p
+    frame holds such a path."""
+    sc, _ = scenes("spheres")
+    gpu.upload_scene(sc)
+    assert gpu.stats()["shading_in_force"] == 1
+    gpu.set_option("russian_roulette", 3)
+    assert gpu.stats()["shading_in_force"] == 0          # the roulette estimator has no f64 instantiation: the automatic choice stands back
+    gpu.set_option("russian_roulette", 0)
+    sc, _ = scenes("rtcamp5")
+    gpu.upload_scene(sc)
+    assert gpu.stats()["shading_in_force"] == 0
+    gpu.set_option("precise_shading", 1)
+    try:
+        assert gpu.stats()["shading_in_force"] == 2
+        gpu.set_resolution(1920, 1080)
+        gpu.clear()
+        gpu.render(191, 194)
+        split = gpu.read_accumulator().copy()
+        assert np.isfinite(split).all()
+        gpu.set_debug_option("trace_mode", 0)
+        assert gpu.stats()["shading_in_force"] == 1
+        gpu.clear()
+        gpu.render(191, 194)
+        assert np.array_equal(split, gpu.read_accumulator())
+    finally:
+        gpu.set_debug_option("trace_mode", -1)
+        gpu.set_option("precise_shading", -1)
 
 
 def test_config5_full_length_through_the_cli(tmp_path, scenes, orc):

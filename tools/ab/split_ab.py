@@ -72,8 +72,8 @@ def main():
                          d["leaf_lanes"] / max(1, d["leaf_calls"]), d["box_passes"] / max(1, d["rays"]), d["leaf_calls"] / max(1, d["rays"]), pc[0], pc[1], pc[2], pc[3]), flush=True)
             r.set_debug_option("trace_mode", 0)
         for mode in ([] if a.profile_only else [int(m) for m in a.modes.split(",")]):
-            r.set_debug_option("trace_mode", min(mode, 1))
-            r.set_option("precise_shading", 1 if mode == 2 else 0)       # mode 2: the split pipeline with precise shading (other bits by design)
+            r.set_debug_option("trace_mode", 1 if mode in (1, 2) else 0)
+            r.set_option("precise_shading", 1 if mode in (2, 3) else 0)       # mode 2: the split pipeline with precise shading; mode 3: the megakernel with precise shading (other bits than modes 0 / 1 by design)
             if mode:
                 for kv in a.opt:
                     k, v = kv.split("=")

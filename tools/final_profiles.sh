@@ -58,12 +58,13 @@ python -m pytest tests -m gpu -q -s -k "radiance_accumulator or crops or far_fro
 python tools/parity_report.py $OUT/${TAG}_parity_report.json > $OUT/parity.log 2>&1
 python tools/seedprof.py 16 > $OUT/${TAG}_seed_phases.txt 2>&1
 # round 6: the split pipeline against the megakernel and with precise shading, pair and kernel by kernel; precise shading's parity; the CLI's rate
-python tools/ab/split_ab.py --samplings 128 --scenes rtcamp6_v3_1,rtcamp6_v2,rtcamp6_v1,rtcamp6_dodeca,tbf3,rtcamp5,spheres --modes 0,1,2 2>&1 | grep -v libdrm > $OUT/${TAG}_split_ab.txt
+python tools/ab/split_ab.py --samplings 128 --scenes rtcamp6_v3_1,rtcamp6_v2,rtcamp6_v1,rtcamp6_dodeca,tbf3,rtcamp5,spheres --modes 0,1,3,2 2>&1 | grep -v libdrm > $OUT/${TAG}_split_ab.txt
+python tools/ab/split_ab.py --samplings 128 --scenes simple,material_examples,cornell_mini --modes 0,3 2>&1 | grep -v libdrm >> $OUT/${TAG}_split_ab.txt
 python tools/ab/split_ab.py --scenes rtcamp6_v3_1,rtcamp6_v2,spheres --modes 2 --profile-only --counters 2>&1 | grep -v libdrm > $OUT/${TAG}_split_profile.txt
 python tools/ab/precise_check.py 2>&1 | grep -v libdrm > $OUT/${TAG}_precise_parity_480x270.txt
 bash tools/ab/cli_batch.sh > $OUT/${TAG}_cli_report_granularity.txt 2>&1
 python bench.py --precise --spp-per-step 16 --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_precise.json.log 2>> $OUT/bench_full.err
-python bench.py --precise --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres_precise.json.log 2>> $OUT/bench_full.err
+python bench.py --no-precise --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres_fp32_shading.json.log 2>> $OUT/bench_full.err
 rocprofv3 --kernel-trace --stats -d $OUT/prof_precise -o ${TAG}_precise -- python bench.py --precise --spp-per-step 16 --steps 16 --no-cpu-baseline --no-counters > /dev/null 2>> $OUT/bench_full.err
 DB=$(find $OUT/prof_precise -name "*_results.db" | head -1)
 python tools/rocprof_summary.py "$DB" $OUT/${TAG}_bench_precise_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --precise --spp-per-step 16 --steps 16 --no-cpu-baseline --no-counters" > /dev/null
