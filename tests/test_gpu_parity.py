@@ -1399,22 +1399,28 @@ def test_precise_shading_defaults_and_finite_radiance(gpu, scenes):
     gpu.set_option("russian_roulette", 3)
     assert gpu.stats()["shading_in_force"] == 0          # the roulette estimator has no f64 instantiation: the automatic choice stands back
     gpu.set_option("russian_roulette", 0)
+    sc, _ = scenes("rtcamp6_v3_1")
+    gpu.upload_scene(sc)
+    assert gpu.stats()["shading_in_force"] == 0
+    gpu.set_option("precise_shading", 1)
+    assert gpu.stats()["shading_in_force"] == 2          # 100,000 triangles: the split form is the faster one
+    gpu.set_option("precise_shading", -1)
     sc, _ = scenes("rtcamp5")
     gpu.upload_scene(sc)
     assert gpu.stats()["shading_in_force"] == 0
     gpu.set_option("precise_shading", 1)
     try:
-        assert gpu.stats()["shading_in_force"] == 2
+        assert gpu.stats()["shading_in_force"] == 1      # a few hundred triangles: the megakernel form
         gpu.set_resolution(1920, 1080)
         gpu.clear()
         gpu.render(191, 194)
-        split = gpu.read_accumulator().copy()
-        assert np.isfinite(split).all()
-        gpu.set_debug_option("trace_mode", 0)
-        assert gpu.stats()["shading_in_force"] == 1
+        mega = gpu.read_accumulator().copy()
+        assert np.isfinite(mega).all()
+        gpu.set_debug_option("trace_mode", 1)
+        assert gpu.stats()["shading_in_force"] == 2
         gpu.clear()
         gpu.render(191, 194)
-        assert np.array_equal(split, gpu.read_accumulator())
+        assert np.array_equal(mega, gpu.read_accumulator())
     finally:
         gpu.set_debug_option("trace_mode", -1)
         gpu.set_option("precise_shading", -1)
