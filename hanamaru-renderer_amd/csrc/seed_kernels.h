@@ -85,6 +85,10 @@ __device__ __forceinline__ void seed_fixup_wave(const RenderParams &rp, int lens
         count = rp.ovf_cap;
     }
     const IsaacWarm warm = isaac_warm();
+    // The list was written by OTHER lanes of this wave (ovf_note: the lane that seeded the path), the last entries only a group ago: their stores
+    // must have reached L2 before the L1-bypassing loads below ask for them — a lane that read the entry of an earlier launch instead re-derived
+    // a path that did not need it and left the one that did with its unfinished record (round 6: one path in ~10^9 with two outcomes, run to run).
+    __builtin_amdgcn_s_waitcnt(0);
     for (uint32_t base = 0; base < count; base += 40u) {
         const bool valid = lane_on && base + lane40 < count;
         const uint32_t pid = __hip_atomic_load(list + (valid ? base + lane40 : base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
