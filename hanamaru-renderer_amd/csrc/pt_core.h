@@ -795,7 +795,12 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         p.r0 = r01[0]; p.r1 = r01[1];
         if (!hit) {  // scene.rs:398 + renderer.rs:196,199
             if (LOG) { plog_or(*lg, path_iter(p), 1u); plog_sky(sc, *lg, p.ray.d); }
-            p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
+            if (PREC) {     // the sky at the f64 direction (prec_core.h): the residual is in the path's record
+                V3f fo, fd;
+                ray_fix_load(recs, path_draw_base(p), (p.q >> 12) & 15u, fo, fd);
+                p.accum = p.accum + p.refl * sky_sample_f64(sc, widen(p.ray.d, fd));
+            } else
+                p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
             return true;
         }
         if (PREC) {

@@ -187,7 +187,7 @@ HD bool wf_surface_f64(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f
     b.r0 = r01[0]; b.r1 = r01[1];
     if (ts.prim < 0) {
         if (LOG) { plog_or(*lg, it, 1u); plog_sky(sc, *lg, rd); }
-        p.accum = p.accum + p.refl * sky_sample(sc, rd);
+        p.accum = p.accum + p.refl * sky_sample_f64(sc, widen(rd, fd));
         return true;
     }
     PrecHit x;

@@ -18,6 +18,16 @@
 #include "lbvh_core.h"
 #include "post_core.h"
 #include <cstdlib>
+// Ablation hook (prec_core.h PREC_DRAW): with emu_set_exact_draws(1) precise shading computes with the path's UNROUNDED f64 draws (found by
+// their fp32 value among the path's outputs) instead of the hand-off record's fp32 values — what a record of f64 draws would buy.
+static thread_local const double *g_exact_draws = nullptr;
+static thread_local int g_exact_n = 0;
+static inline double emu_exact_draw(float r) {
+    for (int i = 0; i < g_exact_n; i++)
+        if ((float)g_exact_draws[i] == r) return g_exact_draws[i];
+    return (double)r;
+}
+#define PREC_DRAW(r) emu_exact_draw(r)
 #include "pt_core.h"
 #include "wf_core.h"
 
@@ -66,6 +76,17 @@ static bool path_record(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     ArrWindow win;
     isaac_seed_round<ISAAC_TAIL>(mem, warm, 8700304ULL, (u64)sampling, s, t, win);
     return record_from_window(win, ISAAC_TAIL, lens_shape, rec);
+}
+static int g_exact_on = 0;
+// every output of the path's generator the record could hold, as the reference's f64 (isaac_to_f64)
+static void path_exact_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, double *out) {
+    static const IsaacWarm warm = isaac_warm();
+    u64 s, t;
+    path_seed_words(W, H, px, py, sub, s, t);
+    ArrMem mem;
+    ArrWindow win;
+    isaac_seed_round<ISAAC_TAIL>(mem, warm, 8700304ULL, (u64)sampling, s, t, win);
+    for (int k = 0; k < ISAAC_TAIL; k++) out[k] = isaac_to_f64(win.ld(k));
 }
 static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
     ArrRec rec;
@@ -396,6 +417,9 @@ static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint
     path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
     path_start(sc, rpp, p0, x, y, sub, rec.f);
     const float *prec = rec.f + rec.base;      // the path's record, as wf_rec_base() addresses it on the device
+    double exact[ISAAC_TAIL];
+    if (PREC && g_exact_on) { path_exact_draws(W, H, x, y, sub, sampling, exact); g_exact_draws = exact; g_exact_n = ISAAC_TAIL; }
+    struct ExactOff { ~ExactOff() { g_exact_draws = nullptr; g_exact_n = 0; } } exact_off;
     WfPath p;
     p.pid = 0; p.st = wf_st(1u, true, (p0.q >> 12) & 15u, 0u); p.raybase = 0; p.cur_refl = 1.0f;
     p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
@@ -456,6 +480,7 @@ static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint
 extern "C" {
 static int g_wf_precise = 0;
 extern "C" void emu_set_wf_precise(int on) { g_wf_precise = on; }
+extern "C" void emu_set_exact_draws(int on) { g_exact_on = on; }
 extern "C" int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc) {
     Scene sc = e->view;
     sc.qnodes = nullptr;

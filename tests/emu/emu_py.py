@@ -111,6 +111,12 @@ def set_walk_mode(mode):
     lib().emu_set_walk_mode(mode)
 
 
+def set_exact_draws(on):
+    """ablation for path_log_wf / render_wf with precise shading: compute with the path's unrounded f64 draws (emu.cpp emu_exact_draw)"""
+    lib().emu_set_exact_draws.argtypes = [C.c_int]
+    lib().emu_set_exact_draws(1 if on else 0)
+
+
 def set_precise(on):
     """option precise_shading for render / path_log (the megakernel's per-lane code, path_advance<.., PREC>)"""
     lib().emu_set_precise.argtypes = [C.c_int]
