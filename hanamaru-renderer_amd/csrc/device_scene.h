@@ -272,6 +272,8 @@ struct RenderParams {
     uint32_t tail_div;                // trace kernel: the last tiles / tail_div tiles of a launch are handed out one sampling at a time (0 = none): finer work units where the launch runs dry
     uint32_t wg_budget;               // trace kernel: workgroups with blockIdx.x >= wg_budget leave at once (0 = all stay) — debug option trace_budget
     GovDev *gov;                      // nullptr: no governor (debug kernels, host emulation) — trace_boost / pad[1] as given
+    uint64_t rec_lo_off;              // precise shading: the records' second half, in floats from the first — slot k of a path holds what rounding draw k to fp32
+                                      // took away (isaac_core.h draw_lo_f32), same layout; 0: the launch carries no residuals (fp32 draws)
 };
 
 // lane j of tile `tile` -> pixel and sub-sample (tile = 4x4 pixels x 4 sub-samples = 64 paths per sampling)
@@ -286,6 +288,8 @@ HD void tile_lane_pixel(const RenderParams &rp, uint32_t tile, uint32_t j, uint3
 // Hand-off from the seed kernel to the trace kernel: a 128-byte record of REC_FLOATS fp32 slots per path,
 //   slots 0 .. REC_DRAWS-1   the path's first draws as the fp32 values the trace kernel computes with (draw k = k-th next_f64, rounded once)
 //   slot  REC_HEAD           index a of the accepted lens attempt (uint bits), then lens x, lens y (2 u - 1, camera.rs:69-70), spare
+// Precise shading (RenderParams::rec_lo_off != 0): a second record array of the same layout behind the first holds the draws' residuals —
+// f64 draw = (double)slot + (double)residual slot to 2^-49 — written by the same stores' twins, read by shading two floats at a time.
 // stored per item (= tile x sampling: the 64 paths of one wave-sized tile) as [quad = slot / 4][64 lanes][4 floats]: the seed kernel's
 // lanes (consecutive paths) write 16 bytes each into one contiguous row per store instruction, the trace kernel's lanes read their
 // two draws of an iteration with one 8-byte load and the head with one 16-byte load, both coalesced across the lanes of a tile.

@@ -89,6 +89,8 @@ struct hr_ctx {
     uint32_t ovf_cap = 0;                    // entries per consumer wave the list is allocated for (ensure_ovf)
     u64 *ovf_win = nullptr;                  // per consumer wave: raw-output window of that fix-up
     size_t draws_cap = 0;                    // items (tile x sampling) per buffer
+    uint64_t rec_lo_off = 0;                 // floats from a record buffer's start to its twin (the draws' residuals, precise shading); 0: the buffers have none
+    int draw_residuals = 1;                  // debug option: precise shading's records carry the draws' residuals (0: the fp32 draws alone, the A/B)
     u64 *ring = nullptr;                     // seed kernels' hand-off ring (three-run kernel: 120 KiB per CU of 16-register states; ring kernel: <= 680 KiB per CU)
     int seed_split = 16;                      // option seed_split: init blocks done by the producer waves (8, 12, 16, 20, 24, 28)
     uint32_t init_prio = 1;                  // s_setprio of the producer waves
@@ -247,15 +249,14 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
 }
 // What options precise_shading / trace_mode mean for the scene in place.  Precise shading has two homes that render the same bits
 // (path_advance<.., PREC> in the megakernel at 128 VGPRs; the split pipeline's shading kernel), so which one runs is a question of speed only:
-// the megakernel form costs 0.4 - 1.6 % on scenes whose trace side is light (no or few triangles), the split form less than the megakernel form
-// on mesh scenes (5 - 20 %; profiles/r06_precise_pipelines.txt).  AUTOMATIC precise shading: on for scenes without triangle meshes — small
-// spheres are what multiplies an fp32 ray's error, and there it is all but free —, off where it costs.
-static const uint32_t PRECISE_SPLIT_TRIS = 10000;
+// the megakernel form costs 1.7 - 3.6 % on scenes without meshes (the trace side stays hidden behind the seed kernel), on every mesh scene the
+// split form is the faster one (8 - 26 % below fp32 shading; profiles/r06_precise_pipelines.txt).  AUTOMATIC precise shading: on for scenes
+// without triangle meshes — small spheres are what multiplies an fp32 ray's error, and there it costs little —, off where it costs.
 static void resolve_modes(hr_ctx *c) {
     const bool has_scene = c->have_scene;
     const uint32_t tris = has_scene ? c->dsc.num_tris : 0u;
     c->precise = c->precise_opt == 1 || (c->precise_opt < 0 && has_scene && tris == 0u && !c->rr_start);
-    c->trace_mode = c->trace_mode_opt >= 0 ? c->trace_mode_opt : (c->precise && tris > PRECISE_SPLIT_TRIS ? 1 : 0);
+    c->trace_mode = c->trace_mode_opt >= 0 ? c->trace_mode_opt : (c->precise && tris > 0u ? 1 : 0);
 }
 // a new scene, resolution or option: the balance of the two kernels is another one.  The governor starts at level 0 — next to a trace
 // kernel that needs 16 ms per 33 M paths on the reference's scenes the seed kernel (24 ms) is the slower one almost everywhere.
@@ -810,16 +811,25 @@ int hr_clear(hr_ctx *c) {
     return HR_OK;
 }
 
+// Precise shading computes with the reference's f64 draws: the seed kernel (the default one, seed_mode 2) writes what rounding a draw to fp32
+// took away into the records' twin behind the records (device_scene.h RenderParams::rec_lo_off).
+static bool draws_twin(const hr_ctx *c) { return c->precise && c->seed_mode == 2 && c->draw_residuals; }
+static uint64_t rec_lo_off(const hr_ctx *c) { return draws_twin(c) ? c->rec_lo_off : 0; }
 static int ensure_draws(hr_ctx *c, size_t items) {
-    if (items <= c->draws_cap) return HR_OK;
+    const bool twin = draws_twin(c);
+    if (items <= c->draws_cap && (!twin || c->rec_lo_off)) return HR_OK;
     int rc = sync_all(c);   // kernels of an earlier hr_render may still be reading the buffers that are about to be replaced
     if (rc) return rc;
+    items = std::max(items, c->draws_cap);
     c->draws_cap = 0;       // stays 0 if an allocation below fails: the next call starts over
+    c->rec_lo_off = 0;
+    const size_t floats = (items + SEED_SPARE_ITEMS) * REC_ITEM_FLOATS;   // + spare items for the padding lanes of the last group
     for (int i = 0; i < 2; i++) {
         if (c->recs[i]) { HIP_TRY(hipFree(c->recs[i])); c->recs[i] = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->recs[i], (items + SEED_SPARE_ITEMS) * REC_ITEM_FLOATS * sizeof(float)));   // + spare items for the padding lanes of the last group
+        HIP_TRY(hipMalloc((void **)&c->recs[i], floats * (twin ? 2 : 1) * sizeof(float)));
     }
     c->draws_cap = items;
+    c->rec_lo_off = twin ? floats : 0;
     return HR_OK;
 }
 
@@ -919,8 +929,11 @@ static int launch_seed(hr_ctx *c, const RenderParams &rp, int slot, hipStream_t 
     if (c->debug_skip & 2) {
     } else if (c->seed_mode == 2) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
-        if (c->seed_prof) hipLaunchKernelGGL((seed_seg_kernel<true>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
-        else hipLaunchKernelGGL((seed_seg_kernel<false>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters);
+#define HR_LAUNCH_SEG(P, L) hipLaunchKernelGGL((seed_seg_kernel<P, L>), dim3(grid), dim3(256), SEED_LDS_BYTES, st, rp, c->dsc.cam.lens_shape, c->ring, c->recs[slot], c->ovf, c->ovf_win, c->d_counters)
+        if (rp.rec_lo_off) { if (c->seed_prof) HR_LAUNCH_SEG(true, true); else HR_LAUNCH_SEG(false, true); }   // + the draws' residuals (precise shading)
+        else if (c->seed_prof) HR_LAUNCH_SEG(true, false);
+        else HR_LAUNCH_SEG(false, false);
+#undef HR_LAUNCH_SEG
 #if defined(HR_EXPERIMENTS)
     } else if (c->seed_mode == 4) {
         if (!c->ring) HIP_TRY(hipMalloc((void **)&c->ring, (size_t)c->num_cus * SEED_RING_WORDS_MAX * sizeof(u64)));
@@ -981,7 +994,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
         batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(4, (33177600ull + per_sampling_paths - 1) / per_sampling_paths));
     }
     {
-        uint64_t per_sampling = (uint64_t)tiles * REC_ITEM_FLOATS * sizeof(float);
+        uint64_t per_sampling = (uint64_t)tiles * REC_ITEM_FLOATS * sizeof(float) * (draws_twin(c) ? 2 : 1);
         uint64_t fit = std::max<uint64_t>(1, c->max_tail_bytes / std::max<uint64_t>(1, per_sampling));
         batch = (uint32_t)std::min<uint64_t>(batch, fit);
     }
@@ -996,6 +1009,7 @@ int hr_render(hr_ctx *c, uint32_t s_begin, uint32_t s_end, uint32_t stride) {
     }
     int rc = ensure_draws(c, (size_t)tiles * batch);
     if (rc) return rc;
+    rp.rec_lo_off = rec_lo_off(c);
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * batch))) return rc;
     if (split && (rc = ensure_wf(c, (uint64_t)tiles * 64u * batch))) return rc;
     rp.ovf_cap = c->ovf_cap;
@@ -1549,6 +1563,7 @@ int hr_set_debug_option(hr_ctx *c, const char *key, double value) {
         c->trace_mode_opt = (int)value;
         return govern_reset(c);
     }
+    if (k == "draw_residuals") { if (value != 0 && value != 1) return fail(HR_ERR_INVALID, "draw_residuals must be 0 or 1"); c->draw_residuals = (int)value; return HR_OK; }
     if (k == "wf_adv_den") { if (value < 0 || value > 64) return fail(HR_ERR_INVALID, "wf_adv_den must be in [0,64]"); c->wf_adv_den = (uint32_t)value; return HR_OK; }
     if (k == "wf_trav_wgs") { if (value < 1 || value > 16) return fail(HR_ERR_INVALID, "wf_trav_wgs must be in [1,16]"); c->wf_trav_wgs = (uint32_t)value; return HR_OK; }
     if (k == "wf_shade_wgs") { if (value < 1 || value > 16) return fail(HR_ERR_INVALID, "wf_shade_wgs must be in [1,16]"); c->wf_shade_wgs = (uint32_t)value; return HR_OK; }
@@ -1575,12 +1590,13 @@ int hr_debug_draws(hr_ctx *c, uint32_t sampling, uint32_t first_path, uint32_t n
     return HR_OK;
 }
 
-int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
-    // the 20 fp32 draws per path exactly as the production seed kernel hands them to the trace kernel,
-    // re-ordered to pixel-major paths: out[((y*W + x)*4 + sub) * 20 + d]
-    if (!c || !host_out) return fail(HR_ERR_INVALID, "hr_debug_path_draws: bad argument");
-    if (!c->W) return fail(HR_ERR_NO_TARGET, "hr_debug_path_draws: hr_set_resolution not called");
-    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "hr_debug_path_draws: no scene (lens shape needed)");
+static int path_draws_out(hr_ctx *c, uint32_t sampling, float *host_out, bool residuals, const char *who) {
+    // the 20 fp32 draws per path exactly as the production seed kernel hands them to the trace kernel (residuals: the same slots of the
+    // records' twin), re-ordered to pixel-major paths: out[((y*W + x)*4 + sub) * 20 + d]
+    if (!c || !host_out) return fail(HR_ERR_INVALID, "%s: bad argument", who);
+    if (!c->W) return fail(HR_ERR_NO_TARGET, "%s: hr_set_resolution not called", who);
+    if (!c->have_scene) return fail(HR_ERR_NO_SCENE, "%s: no scene (lens shape needed)", who);
+    if (residuals && !draws_twin(c)) return fail(HR_ERR_UNSUPPORTED, "%s: no residuals are written (needs precise shading in force, seed_mode 2, draw_residuals 1)", who);
     HIP_TRY(hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
@@ -1589,12 +1605,17 @@ int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
     rp.sampling_begin = sampling; rp.stride = 1; rp.num_k = 1;
     uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, tiles))) return rc;
+    if (residuals) rp.rec_lo_off = rec_lo_off(c);
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u))) return rc;
     rp.ovf_cap = c->ovf_cap;
     if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
-    std::vector<float> h((size_t)tiles * REC_ITEM_FLOATS);
+    std::vector<float> h((size_t)tiles * REC_ITEM_FLOATS), lo;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(h.data(), c->recs[0], h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if (residuals) {
+        lo.resize(h.size());
+        HIP_TRY(hipMemcpy(lo.data(), c->recs[0] + rp.rec_lo_off, lo.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
     for (uint32_t t = 0; t < tiles; t++)
         for (uint32_t j = 0; j < 64; j++) {
             uint32_t tx = t % rp.tiles_x, ty = t / rp.tiles_x, pix = j >> 2, sub = j & 3;
@@ -1604,12 +1625,19 @@ int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) {
             const uint32_t lb = j * 4u;
             uint32_t a = float_as_uint(rec[rec_slot(lb, REC_HEAD)]);
             float *o = &host_out[(((size_t)py * c->W + px) * 4 + sub) * DRAWS_PER_PATH];
+            if (residuals) {
+                const float *rl = &lo[(size_t)t * REC_ITEM_FLOATS];
+                for (uint32_t d = 0; d < (uint32_t)DRAWS_PER_PATH; d++) o[d] = rl[rec_slot(lb, 2 * a + d)];
+                continue;
+            }
             o[0] = rec[rec_slot(lb, REC_HEAD + 1)];
             o[1] = rec[rec_slot(lb, REC_HEAD + 2)];
             for (uint32_t d = 2; d < (uint32_t)DRAWS_PER_PATH; d++) o[d] = rec[rec_slot(lb, 2 * a + d)];
         }
     return drain_events(c);
 }
+int hr_debug_path_draws(hr_ctx *c, uint32_t sampling, float *host_out) { return path_draws_out(c, sampling, host_out, false, "hr_debug_path_draws"); }
+int hr_debug_path_draw_residuals(hr_ctx *c, uint32_t sampling, float *host_out) { return path_draws_out(c, sampling, host_out, true, "hr_debug_path_draw_residuals"); }
 
 int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
     // one sampling through the production pipeline — the seed kernel, then the LOG instantiation of trace_kernel (same traversal, same
@@ -1628,6 +1656,7 @@ int hr_debug_path_log(hr_ctx *c, uint32_t sampling, uint32_t *host_out) {
     rp.nee_cull_off = ~c->nee_cull & 7u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, tiles))) return rc;
+    rp.rec_lo_off = rec_lo_off(c);
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u))) return rc;
     rp.ovf_cap = c->ovf_cap;
     if ((rc = launch_seed(c, rp, 0, c->stream))) return rc;
@@ -1690,6 +1719,7 @@ int hr_debug_wf_profile(hr_ctx *c, uint32_t sampling, uint32_t num_k, double *ms
     rp.nee_cull_off = ~c->nee_cull & 7u;
     const uint32_t tiles = rp.tiles_x * rp.tiles_y;
     if ((rc = ensure_draws(c, (size_t)tiles * num_k))) return rc;
+    rp.rec_lo_off = rec_lo_off(c);
     if ((rc = ensure_ovf(c, (uint64_t)tiles * 64u * num_k))) return rc;
     if ((rc = ensure_wf(c, (uint64_t)tiles * 64u * num_k))) return rc;
     rp.ovf_cap = c->ovf_cap;

@@ -26,12 +26,6 @@ HD V3f narrow(D3 a) { return v3((float)a.x, (float)a.y, (float)a.z); }
 HD V3f residual(D3 a, V3f hi) { return v3((float)(a.x - (double)hi.x), (float)(a.y - (double)hi.y), (float)(a.z - (double)hi.z)); }
 HD D3 dreflect(D3 v, D3 n) { return v - n * (2.0 * ddot(v, n)); }   // vector.rs:60-62
 
-// An iteration's draw as shading computes with it: the fp32 value of the hand-off record, widened.  (tests/emu defines PREC_DRAW to look up the
-// unrounded f64 draw instead: the ablation behind DESIGN §6.3's "what is left is the rounding of the draws".)
-#ifndef PREC_DRAW
-#define PREC_DRAW(r) ((double)(r))
-#endif
-
 // material.rs:154-199 in f64.  `in` = direction of the arriving ray.  Returns the new ray and the reflectance scalar; transmitted as in pt_core.h.
 HD void sample_refraction_f64(double r0, D3 pos, D3 in, D3 n, double ior, D3 &no, D3 &nd, float &refl, bool &transmitted) {
     transmitted = false;
@@ -91,70 +85,38 @@ HD D3 sample_ggx_half_f64(double r0, double r1, D3 n, double alpha2) {  // mater
 
 // What shading a hit in f64 produces: the material at the hit, the fp32 normal (for NEE and the log), the next ray in f64, the sampled bounce's scalar.
 struct PrecHit { PointMat m; Surf s; V3f nf; D3 no, nd; float cur_refl; bool sampled, transmitted; };
-// Texture and sky lookups at f64 coordinates (texture.rs:29-114, scene.rs:295-319): the texel quad and the bilinear WEIGHTS come from the f64
-// coordinate — a 1024^2 map over a floor turns an fp32 coordinate's 6e-8 into 1e-4 texel, which a roughness map hands to the GGX lobe as a turn
-// of the sampled direction and the HDR sky multiplies (NOTES G) —, the blend and the gamma curve stay fp32 (1e-7 of a smooth function).
-struct BilinearAt { uint32_t ix1, ix2, iy1, iy2; float w11, w21, w12, w22; };
-HD BilinearAt bilinear_at_f64(double x, double y) {
-    const double x1 = floor(x), y1 = floor(y), x2 = x1 + 1.0, y2 = y1 + 1.0;
-    BilinearAt b;
-    b.ix1 = f32_as_u32_sat((float)x1); b.ix2 = f32_as_u32_sat((float)x2); b.iy1 = f32_as_u32_sat((float)y1); b.iy2 = f32_as_u32_sat((float)y2);
-    b.w11 = (float)((x2 - x) * (y2 - y)); b.w21 = (float)((x - x1) * (y2 - y)); b.w12 = (float)((x2 - x) * (y - y1)); b.w22 = (float)((x - x1) * (y - y1));
-    return b;
-}
-HD V3f sample_bilinear_f64(const Scene &sc, int32_t image, double u, double v) {
+// A ROUGHNESS map is the one texture whose value becomes geometry (the GGX lobe): it is read at f64 texture coordinates — the texel quad and the
+// bilinear WEIGHTS from the f64 coordinate; a 1024^2 map over a floor turns an fp32 coordinate's 6e-8 into 1e-4 texel, the lobe turns with it and
+// the HDR sky multiplies that (NOTES G, P) —, the blend and the gamma curve stay fp32 (1e-7 of a smooth function).  Albedo and emission maps stay
+// fp32 lookups: a 1e-4-texel shift there is a 1e-5 change of a colour.  The value is computed inside the primitive's branch and ONE float leaves it:
+// with the coordinates kept in f64 across the material fetch the megakernel form rendered scenes without a single texture 25 % slower (register
+// pressure), as device functions that are not inlined 40 % (the calls' spills) — NOTES P.
+HD float roughness_map_f64(const Scene &sc, int32_t image, double u, double v) {   // texture.rs:29-114, channel x
     const ImageRef im = sc.images[image];
-    const BilinearAt b = bilinear_at_f64(u * (double)im.width, v * (double)im.height);
-    const V3f g = texel(sc, im, b.ix1, b.iy1) * b.w11 + texel(sc, im, b.ix2, b.iy1) * b.w21 + texel(sc, im, b.ix1, b.iy2) * b.w12 + texel(sc, im, b.ix2, b.iy2) * b.w22;
-    return v3(gamma_to_linear(g.x), gamma_to_linear(g.y), gamma_to_linear(g.z));
+    const double x = u * (double)im.width, y = v * (double)im.height;
+    const double x1 = floor(x), y1 = floor(y), x2 = x1 + 1.0, y2 = y1 + 1.0;
+    const uint32_t ix1 = f32_as_u32_sat((float)x1), ix2 = f32_as_u32_sat((float)x2), iy1 = f32_as_u32_sat((float)y1), iy2 = f32_as_u32_sat((float)y2);
+    const float w11 = (float)((x2 - x) * (y2 - y)), w21 = (float)((x - x1) * (y2 - y)), w12 = (float)((x2 - x) * (y - y1)), w22 = (float)((x - x1) * (y - y1));
+    const float g = texel(sc, im, ix1, iy1).x * w11 + texel(sc, im, ix2, iy1).x * w21 + texel(sc, im, ix1, iy2).x * w12 + texel(sc, im, ix2, iy2).x * w22;
+    return gamma_to_linear(g);
 }
-HD void material_at_f64(const Scene &sc, int32_t elem, double u, double v, PointMat &m) {  // material_at (scene.rs:389-396) at f64 coordinates
-    const Material mt = sc.materials[elem];
-    m.surface = mt.surface; m.param = mt.param;
-    m.albedo = mt.albedo_img >= 0 ? sample_bilinear_f64(sc, mt.albedo_img, u, v) * v3(mt.albedo) : v3(mt.albedo);
-    m.emission = mt.emission_img >= 0 ? sample_bilinear_f64(sc, mt.emission_img, u, v) * v3(mt.emission) : v3(mt.emission);
-    m.roughness = mt.roughness_img >= 0 ? sample_bilinear_f64(sc, mt.roughness_img, u, v).x * mt.roughness : mt.roughness;
-}
-HD V3f sky_sample_f64(const Scene &sc, D3 d) {  // sky_sample (scene.rs:295-319) for the f64 direction
-    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
-    int face; double u, v;
-    if (ax > ay && ax > az) {
-        const double i = 1.0 / d.x;
-        if (!signbit(d.x)) { face = 0; u = -d.z * i; v = d.y * i; } else { face = 1; u = -d.z * i; v = -d.y * i; }
-    } else if (ay > ax && ay > az) {
-        const double i = 1.0 / d.y;
-        if (!signbit(d.y)) { face = 2; u = d.x * i; v = -d.z * i; } else { face = 3; u = -d.x * i; v = -d.z * i; }
-    } else {
-        const double i = 1.0 / d.z;
-        if (!signbit(d.z)) { face = 4; u = d.x * i; v = d.y * i; } else { face = 5; u = d.x * i; v = -d.y * i; }
-    }
-    u = 0.5 * (u + 1.0); v = 0.5 * (v + 1.0);
-    if (sc.sky_quads) {     // (one 16-byte load per lookup, as sky_sample)
-        const BilinearAt b = bilinear_at_f64(fmax(u * (double)sc.sky_w, 0.0), fmax(v * (double)sc.sky_h, 0.0));
-        const uint32_t cx = b.ix1 > sc.sky_w ? sc.sky_w : b.ix1, cy = b.iy1 > sc.sky_h ? sc.sky_h : b.iy1;
-        const uint32_t *q = sc.sky_quads + (((size_t)face * (sc.sky_h + 1u) + cy) * (sc.sky_w + 2u) + cx) * 2u;
-        struct alignas(8) Quad { uint32_t p11, p12, p21, p22; };
-        const Quad t = *reinterpret_cast<const Quad *>(q);
-        const float k = 1.0f / 255.0f;
-        const V3f p11 = v3((float)(t.p11 & 255u) * k, (float)((t.p11 >> 8) & 255u) * k, (float)((t.p11 >> 16) & 255u) * k);
-        const V3f p12 = v3((float)(t.p12 & 255u) * k, (float)((t.p12 >> 8) & 255u) * k, (float)((t.p12 >> 16) & 255u) * k);
-        const V3f p21 = v3((float)(t.p21 & 255u) * k, (float)((t.p21 >> 8) & 255u) * k, (float)((t.p21 >> 16) & 255u) * k);
-        const V3f p22 = v3((float)(t.p22 & 255u) * k, (float)((t.p22 >> 8) & 255u) * k, (float)((t.p22 >> 16) & 255u) * k);
-        const V3f g = p11 * b.w11 + p21 * b.w21 + p12 * b.w12 + p22 * b.w22;
-        return v3(sc.sky_intensity) * v3(gamma_to_linear(g.x), gamma_to_linear(g.y), gamma_to_linear(g.z));
-    }
-    return v3(sc.sky_intensity) * sample_bilinear_f64(sc, sc.sky_image[face], u, v);
+// a sphere's texture coordinates (scene.rs:67-71) from the f64 normal, and the roughness map there
+HD float roughness_on_sphere_f64(const Scene &sc, int32_t image, double nx, double ny, double nz) {
+    const double PI_D = 3.14159265358979323846;
+    const double v = 1.0 - acos(fmin(fmax(ny, -1.0), 1.0)) * (1.0 / PI_D);
+    const double u = 0.5 - (signbit(nz) ? -1.0 : 1.0) * acos(fmin(fmax(nx / sqrt(nx * nx + nz * nz), -1.0), 1.0)) * (0.5 / PI_D);
+    return roughness_map_f64(sc, image, u, v);
 }
 
-// (ro, rd) + (fo, fd) = the ray the path follows (fp32 + residual); ts = what the fp32 walk found (a hit); r0, r1 = the iteration's draws.
+// (ro, rd) + (fo, fd) = the ray the path follows (fp32 + residual); ts = what the fp32 walk found (a hit); r0, r1 = the iteration's draws
+// (the record's fp32 values + their residuals when the launch carries them: the reference's f64 draws).
 // material.rs:91-151 with the geometry of scene.rs:58-78,152-183 / bvh.rs:266-290 recomputed from the f64 ray and the f64 primitive.
-HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const TraceState &ts, float r0, float r1, PrecHit &x) {
+HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const TraceState &ts, double r0, double r1, PrecHit &x) {
     const D3 o = widen(ro, fo), d = widen(rd, fd);
     D3 pos, n;
     Surf &s = x.s;
     s.u = ts.u; s.v = ts.v;
-    double ud = 0.0, vd = 0.0;
-    bool uv64 = false;
+    float rough64 = -1.0f;      // the roughness map's value at the f64 coordinates (where the material has one)
     const bool want_uv = material_needs_uv(sc, hit_element(sc, ts));
     if (ts.type == 0) {            // bvh.rs:266-290: the plane of the f64 triangle
         s.elem = sc.tri_shade[ts.prim].element;
@@ -178,11 +140,12 @@ HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const Tra
         n = nn * (1.0 / sqrt(ddot(nn, nn)));
         pos = c + nn;
         if (want_uv) {  // scene.rs:67-71
-            const double PI_D = 3.14159265358979323846;
-            vd = 1.0 - acos(fmin(fmax(n.y, -1.0), 1.0)) * (1.0 / PI_D);
-            ud = 0.5 - (signbit(n.z) ? -1.0 : 1.0) * acos(fmin(fmax(n.x / sqrt(n.x * n.x + n.z * n.z), -1.0), 1.0)) * (0.5 / PI_D);
-            s.u = (float)ud; s.v = (float)vd;
-            uv64 = true;
+            const V3f nf = narrow(n);
+            s.v = 1.0f - acosf(fminf(fmaxf(nf.y, -1.0f), 1.0f)) * (1.0f / PI_F);
+            float sg = signbit(nf.z) ? -1.0f : 1.0f;
+            s.u = 0.5f - sg * acosf(fminf(fmaxf(nf.x * HR_RSQ(nf.x * nf.x + nf.z * nf.z), -1.0f), 1.0f)) * (1.0f / PI2_F);
+            const int32_t rimg = sc.materials[s.elem].roughness_img;
+            if (rimg >= 0) rough64 = roughness_on_sphere_f64(sc, rimg, n.x, n.y, n.z);
         }
     } else {                       // bvh.rs:20-39 + scene.rs:152-182 on the f64 box
         const f4 mnf = sc.cuboids[2 * ts.prim], mxf = sc.cuboids[2 * ts.prim + 1];
@@ -196,7 +159,6 @@ HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const Tra
         // the fp32 walk decided that the box is hit; should the f64 slabs disagree at a grazing edge, the walk's distance stands
         const double dist = (tmin <= tmax && !signbit(tmax)) ? (signbit(tmin) ? tmax : tmin) : (double)ts.t;
         pos = o + d * dist;
-        const D3 uvw = dv((pos.x - mn.x) / (mx.x - mn.x), (pos.y - mn.y) / (mx.y - mn.y), (pos.z - mn.z) / (mx.z - mn.z));
         const double E = 1e-4;   // config.rs:7
         int face;
         if (fabs(pos.y - mx.y) < E) face = 0; else if (fabs(pos.y - mn.y) < E) face = 1; else if (fabs(pos.x - mn.x) < E) face = 2;
@@ -206,31 +168,40 @@ HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const Tra
             const double best = fmin(fmin(fmin(dy1, dy0), fmin(dx0, dx1)), fmin(dz0, dz1));
             face = best == dy1 ? 0 : best == dy0 ? 1 : best == dx0 ? 2 : best == dx1 ? 3 : best == dz0 ? 4 : 5;
         }
-        if (face == 0) { n = dv(0, 1, 0); ud = uvw.x; vd = 1.0 - uvw.z; }
-        else if (face == 1) { n = dv(0, -1, 0); ud = uvw.x; vd = 1.0 - uvw.z; }
-        else if (face == 2) { n = dv(-1, 0, 0); ud = uvw.z; vd = uvw.y; }
-        else if (face == 3) { n = dv(1, 0, 0); ud = uvw.z; vd = uvw.y; }
-        else if (face == 4) { n = dv(0, 0, -1); ud = uvw.x; vd = uvw.y; }
-        else { n = dv(0, 0, 1); ud = uvw.x; vd = uvw.y; }
-        s.u = (float)ud; s.v = (float)vd;
-        uv64 = true;
+        n = face == 0 ? dv(0, 1, 0) : face == 1 ? dv(0, -1, 0) : face == 2 ? dv(-1, 0, 0) : face == 3 ? dv(1, 0, 0) : face == 4 ? dv(0, 0, -1) : dv(0, 0, 1);
+        if (want_uv) {   // scene.rs:166-181: the two coordinates the face uses (two divisions, not three)
+            double un, uq, vn, vq;
+            if (face < 2) { un = pos.x - mn.x; uq = mx.x - mn.x; vn = pos.z - mn.z; vq = mx.z - mn.z; }
+            else if (face < 4) { un = pos.z - mn.z; uq = mx.z - mn.z; vn = pos.y - mn.y; vq = mx.y - mn.y; }
+            else { un = pos.x - mn.x; uq = mx.x - mn.x; vn = pos.y - mn.y; vq = mx.y - mn.y; }
+            double ud = un / uq, vd = vn / vq;
+            if (face < 2) vd = 1.0 - vd;
+            s.u = (float)ud; s.v = (float)vd;
+            const int32_t rimg = sc.materials[s.elem].roughness_img;
+            if (rimg >= 0) rough64 = roughness_map_f64(sc, rimg, ud, vd);
+        }
     }
     const V3f nf = narrow(n);
     x.nf = nf;
     PointMat &m = x.m;
-    if (uv64) material_at_f64(sc, s.elem, ud, vd, m);
-    else material_at(sc, s.elem, s.u, s.v, m);
+    {   // material_at (scene.rs:389-396), the roughness map's value from above
+        const Material mt = sc.materials[s.elem];
+        m.surface = mt.surface; m.param = mt.param;
+        m.albedo = tex_sample(sc, mt.albedo_img, v3(mt.albedo), s.u, s.v);
+        m.emission = tex_sample(sc, mt.emission_img, v3(mt.emission), s.u, s.v);
+        m.roughness = mt.roughness_img < 0 ? mt.roughness : (rough64 >= 0.0f ? rough64 : sample_bilinear(sc, mt.roughness_img, s.u, s.v).x) * mt.roughness;
+    }
         bool &transmitted = x.transmitted, &sampled = x.sampled;
     transmitted = false; sampled = true;
     D3 &no = x.no, &nd = x.nd;
     no = dv(0, 0, 0); nd = dv(0, 0, 0);
     switch (m.surface) {       // material.rs:91-151
-        case 0: no = pos + n * (double)OFFSET_F; nd = sample_diffuse_f64(PREC_DRAW(r0), PREC_DRAW(r1), n); x.cur_refl = 1.0f; break;
+        case 0: no = pos + n * (double)OFFSET_F; nd = sample_diffuse_f64(r0, r1, n); x.cur_refl = 1.0f; break;
         case 1: no = pos + n * (double)OFFSET_F; nd = dreflect(d, n); x.cur_refl = 1.0f; break;
-        case 2: sample_refraction_f64(PREC_DRAW(r0), pos, d, n, (double)m.param, no, nd, x.cur_refl, transmitted); break;
+        case 2: sample_refraction_f64(r0, pos, d, n, (double)m.param, no, nd, x.cur_refl, transmitted); break;
         case 3: {
             const float alpha2 = m.roughness * m.roughness;
-            const D3 hh = sample_ggx_half_f64(PREC_DRAW(r0), PREC_DRAW(r1), n, (double)m.roughness * (double)m.roughness);
+            const D3 hh = sample_ggx_half_f64(r0, r1, n, (double)m.roughness * (double)m.roughness);
             nd = dreflect(d, hh);
             const double lnd = ddot(nd, n);
             if (signbit(lnd)) { sampled = false; break; }
@@ -245,8 +216,8 @@ HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const Tra
             break;
         }
         default: {
-            const D3 hh = sample_ggx_half_f64(PREC_DRAW(r0), PREC_DRAW(r1), n, (double)m.roughness * (double)m.roughness);
-            sample_refraction_f64(PREC_DRAW(r0), pos, d, hh, (double)m.param, no, nd, x.cur_refl, transmitted);
+            const D3 hh = sample_ggx_half_f64(r0, r1, n, (double)m.roughness * (double)m.roughness);
+            sample_refraction_f64(r0, pos, d, hh, (double)m.param, no, nd, x.cur_refl, transmitted);
             break;
         }
     }

@@ -795,20 +795,20 @@ HD bool path_advance(const Scene &sc, const RenderParams &rp, Path &p, const flo
         p.r0 = r01[0]; p.r1 = r01[1];
         if (!hit) {  // scene.rs:398 + renderer.rs:196,199
             if (LOG) { plog_or(*lg, path_iter(p), 1u); plog_sky(sc, *lg, p.ray.d); }
-            if (PREC) {     // the sky at the f64 direction (prec_core.h): the residual is in the path's record
-                V3f fo, fd;
-                ray_fix_load(recs, path_draw_base(p), (p.q >> 12) & 15u, fo, fd);
-                p.accum = p.accum + p.refl * sky_sample_f64(sc, widen(p.ray.d, fd));
-            } else
-                p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
+            p.accum = p.accum + p.refl * sky_sample(sc, p.ray.d);
             return true;
         }
         if (PREC) {
             const uint32_t lb = path_draw_base(p), a2 = (p.q >> 12) & 15u;
             V3f fo, fd;
             ray_fix_load(recs, lb, a2, fo, fd);
+            double r0 = (double)p.r0, r1 = (double)p.r1;
+            if (rp.rec_lo_off) {    // the draws' residuals (device_scene.h: the records' twin)
+                const f2v l01 = *reinterpret_cast<const f2v *>(recs + rp.rec_lo_off + rec_slot(lb, a2 + 2u * path_iter(p)));
+                r0 += (double)l01[0]; r1 += (double)l01[1];
+            }
             PrecHit x;
-            shade_hit_f64(sc, p.ray.o, p.ray.d, fo, fd, p.ts, p.r0, p.r1, x);
+            shade_hit_f64(sc, p.ray.o, p.ray.d, fo, fd, p.ts, r0, r1, x);
             p.view = -p.ray.d;
             if (LOG) {
                 if (p.ts.type == 2) plog_hit(*lg, 0x1000 + cuboid_face_of(x.nf));

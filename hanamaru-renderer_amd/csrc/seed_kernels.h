@@ -44,10 +44,15 @@ struct LdsMem {
 // (the padding lanes of the last group write into spare items behind the last one: no predicate in the hot loop)
 struct RecStore {
     float *rec;   // &recs[item * REC_ITEM_FLOATS + lane * 4]
-    __device__ __forceinline__ RecStore(float *recs, uint64_t pid) : rec(recs + (size_t)(pid >> 6) * REC_ITEM_FLOATS + (size_t)(pid & 63u) * 4u) {}
+    uint64_t lo_off;   // RenderParams::rec_lo_off (uniform): the records' twin for the draws' residuals (RecordTail<.., LO>)
+    __device__ __forceinline__ RecStore(float *recs, uint64_t pid, uint64_t lo = 0) : rec(recs + (size_t)(pid >> 6) * REC_ITEM_FLOATS + (size_t)(pid & 63u) * 4u), lo_off(lo) {}
     __device__ __forceinline__ void st4(int slot, float a, float b, float c, float d) {
         f4 v; v.x = a; v.y = b; v.z = c; v.w = d;
         *reinterpret_cast<f4 *>(rec + (slot >> 2) * 256) = v;
+    }
+    __device__ __forceinline__ void st4lo(int slot, float a, float b, float c, float d) {
+        f4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+        *reinterpret_cast<f4 *>(rec + lo_off + (slot >> 2) * 256) = v;
     }
 };
 static const uint32_t SEED_SPARE_ITEMS = 3;
@@ -77,7 +82,7 @@ struct GlobalWindow {
     __device__ __forceinline__ void put(int step, u64 v) { col[(255 - step) * 40] = v; }
     __device__ __forceinline__ u64 ld(int k) const { return __hip_atomic_load(col + k * 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
-template <class Mem>
+template <class Mem, bool LO = false>
 __device__ __forceinline__ void seed_fixup_wave(const RenderParams &rp, int lens_shape, Mem m, uint32_t lane40, bool lane_on, const uint32_t *list, uint32_t count,
                                                 u64 *win, float *recs, Counters *cnt) {
     if (count > rp.ovf_cap) {
@@ -103,8 +108,8 @@ __device__ __forceinline__ void seed_fixup_wave(const RenderParams &rp, int lens
             isaac_seed_round<ISAAC_TAIL>(m, warm, 8700304ULL, (u64)(rp.sampling_begin + k * rp.stride), s, t, w);
             __builtin_amdgcn_s_waitcnt(0);   // the window stores have left the wave before it is read back (L1-bypassing loads)
             if (valid) {
-                RecStore rs(recs, pid);
-                if (!record_from_window(w, ISAAC_TAIL, lens_shape, rs)) atomicAdd(&cnt->rng_overflow, 1ULL);
+                RecStore rs(recs, pid, rp.rec_lo_off);
+                if (!record_from_window<LO>(w, ISAAC_TAIL, lens_shape, rs)) atomicAdd(&cnt->rng_overflow, 1ULL);
             }
         }
     }
@@ -472,7 +477,7 @@ struct SegRegs {
         if (l.on) isaac_init_run<SEG_NBLK>(m, st16);
     }
 };
-template <bool PROF>
+template <bool PROF, bool LO>
 __device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int lens_shape, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half,
                                                   float *__restrict__ recs, uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
     uint32_t *ovf_list = ovf + (size_t)(blockIdx.x * 2u + half) * rp.ovf_cap;
@@ -504,8 +509,8 @@ __device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int le
         __syncthreads();   // B: all three runs of every column are in
         HR_STAMP(3);
         if (it < n_groups) regs.load(r.ring_wg, r.G0 + it, half, sl);
-        RecStore rs(recs, pid);
-        RecordTail<RecStore> lt(rs, lens_shape);
+        RecStore rs(recs, pid, rp.rec_lo_off);
+        RecordTail<RecStore, LO> lt(rs, lens_shape);
         if (lane < (uint32_t)SEED_LANES) {
             isaac_round<REC_DRAWS>(m, lt);
             lt.finish();
@@ -521,7 +526,7 @@ __device__ __forceinline__ void seed_seg_consumer(const RenderParams &rp, int le
     if (PROF && lane == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&cnt->seed_phase[i], pc[i]);
     const bool lane_on = lane < (uint32_t)SEED_LANES;
-    seed_fixup_wave(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
+    seed_fixup_wave<LdsHalfMem, LO>(rp, lens_shape, m, colr, lane_on, ovf_list, ovf_count, win + (size_t)(blockIdx.x * 2u + half) * SEED_WIN_WORDS, recs, cnt);
 }
 __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const PcRange &r, unsigned char *smem, uint32_t lane, uint32_t half, const uint32_t pprio) {
     const IsaacWarm warm = isaac_warm();
@@ -571,7 +576,8 @@ __device__ __forceinline__ void seed_seg_producer(const RenderParams &rp, const 
         __syncthreads();   // A
     }
 }
-template <bool PROF = false>
+// LO: the records' twin with the draws' residuals is written too (precise shading, RenderParams::rec_lo_off)
+template <bool PROF = false, bool LO = false>
 __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens_shape, u64 *__restrict__ ring, float *__restrict__ recs,
                                                        uint32_t *__restrict__ ovf, u64 *__restrict__ win, Counters *cnt) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256) void seed_seg_kernel(RenderParams rp, int lens
     r.G0 = groups * blockIdx.x / gridDim.x; r.G1 = groups * (blockIdx.x + 1) / gridDim.x;
     r.first_path = r.G0 * SEED_COLS; r.end_path = r.G1 * SEED_COLS < r.paths ? r.G1 * SEED_COLS : r.paths;
     r.ring_wg = ring + (size_t)blockIdx.x * SEED_RING_WORDS_MAX;
-    if (consumer) seed_seg_consumer<PROF>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
+    if (consumer) seed_seg_consumer<PROF, LO>(rp, lens_shape, r, smem, lane, half, recs, ovf, win, cnt);
     else {
         seed_seg_producer(rp, r, smem, lane, half, pprio);
         seed_gov_end(rp, wave == 2u && lane == 0u);

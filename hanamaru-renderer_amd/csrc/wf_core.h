@@ -174,10 +174,11 @@ HD bool wf_bounces(const WfPath &p, const WfBounce &b) { return !(is_zero(p.refl
 // precise shading in the split pipeline: prec_core.h's shade_hit_f64 (shared with the megakernel's path_advance<.., PREC>) + the queue records
 struct WfBounceX { V3f next_o_lo, next_d_lo; };   // the residuals of WfBounce::next_o / next_d (precise shading only)
 
-// wf_surface with the geometry in f64.  (ro, rd) + (fo, fd) = the ray the path follows; h = what the fp32 walk found.
+// wf_surface with the geometry in f64.  (ro, rd) + (fo, fd) = the ray the path follows; h = what the fp32 walk found; rec_lo = the record's twin
+// with the draws' residuals (nullptr: none).
 // LOG: the per-path event log of pt_core.h (PathLog), as path_advance<.., LOG> keeps it.
 template <bool CNT, bool LOG>
-HD bool wf_surface_f64(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f rd, V3f fo, V3f fd, const WfHitRec &h, WfBounce &b, WfBounceX &bx, LaneCounters *cn, PathLog *lg) {
+HD bool wf_surface_f64(const Scene &sc, WfPath &p, const float *rec, const float *rec_lo, V3f ro, V3f rd, V3f fo, V3f fd, const WfHitRec &h, WfBounce &b, WfBounceX &bx, LaneCounters *cn, PathLog *lg) {
     if (CNT) cn->rays++;
     if (LOG) lg->rays++;
     TraceState ts;
@@ -187,11 +188,16 @@ HD bool wf_surface_f64(const Scene &sc, WfPath &p, const float *rec, V3f ro, V3f
     b.r0 = r01[0]; b.r1 = r01[1];
     if (ts.prim < 0) {
         if (LOG) { plog_or(*lg, it, 1u); plog_sky(sc, *lg, rd); }
-        p.accum = p.accum + p.refl * sky_sample_f64(sc, widen(rd, fd));
+        p.accum = p.accum + p.refl * sky_sample(sc, rd);
         return true;
     }
     PrecHit x;
-    shade_hit_f64(sc, ro, rd, fo, fd, ts, b.r0, b.r1, x);
+    double r0 = (double)b.r0, r1 = (double)b.r1;
+    if (rec_lo) {   // the draws' residuals (device_scene.h: the records' twin)
+        const f2v l01 = *reinterpret_cast<const f2v *>(rec_lo + rec_slot(0u, a2 + 2u * it));
+        r0 += (double)l01[0]; r1 += (double)l01[1];
+    }
+    shade_hit_f64(sc, ro, rd, fo, fd, ts, r0, r1, x);
     b.view = -rd;
     b.cur_refl = x.cur_refl;
     const PointMat &m = x.m;

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(Scene sc, RenderParams rp
             const f4 a = ldq(&ra[s]), b = ldq(&rb[s]);
             if (PREC) {
                 const f4 fo = ldq(&q.st_d[in][ii]), fd = ldq(&q.st_e[in][ii]);
-                fin = wf_surface_f64<CNT, LOG>(sc, p, rec, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(fo.x, fo.y, fo.z), v3(fd.x, fd.y, fd.z), ldh(&hits[s]), bc, bx, &lc, &lg);
+                fin = wf_surface_f64<CNT, LOG>(sc, p, rec, rp.rec_lo_off ? rec + rp.rec_lo_off : nullptr, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(fo.x, fo.y, fo.z), v3(fd.x, fd.y, fd.z), ldh(&hits[s]), bc, bx, &lc, &lg);
             } else
                 fin = wf_surface<CNT, LOG>(sc, p, rec, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), ldh(&hits[s]), bc, &lc, &lg);
             if (!fin) {

@@ -163,6 +163,8 @@ def hip_lib():
         L.hr_debug_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.hr_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hr_debug_path_log.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.hr_debug_path_draws.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.hr_debug_path_draw_residuals.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.hr_debug_wf_profile.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.hr_comm_get_unique_id.argtypes = [C.c_void_p]
         L.hr_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]

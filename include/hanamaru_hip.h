@@ -252,14 +252,16 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *   "max_tail_gib"  cap of each seed -> trace hand-off buffer, 1..128 GiB (default 20)
  *   "rng_window"    fixed: 64
  *   "precise_shading"  the GEOMETRY of every bounce in the reference's own f64: hit distance again from the f64 ray and the f64 primitive, hit
- *                   point, normal, mirror / Snell / Fresnel (material.rs:154-199) and the sampled lobe directions; the ray is carried as fp32 +
- *                   residual, the walk stays fp32.  Same estimator, same draws, closer to the reference: the paths that take the reference's
- *                   branches and still differ by more than 1e-3 — refraction chains through faceted glass, bounces off small spheres — fall
- *                   from 90 - 990 to 4 - 33 per million.  Two implementations that render the same bits: in the megakernel
- *                   at 128 VGPRs (0.4 - 1.6 % slower on scenes without meshes, 9 - 25 % on mesh scenes) and in the split pipeline's shading
- *                   kernel (5 - 20 % on mesh scenes); the library takes the faster one for the scene.
+ *                   point, normal, mirror / Snell / Fresnel (material.rs:154-199) and the sampled lobe directions, FROM THE REFERENCE'S f64 DRAWS
+ *                   (the seed kernel hands over what rounding a draw to fp32 took away as well: the hand-off record doubles); roughness maps are
+ *                   read at f64 texture coordinates; the ray is carried as fp32 + residual, the walk stays fp32.  Same estimator, closer to the
+ *                   reference: the paths that take the reference's branches and still differ by more than 1e-3 — refraction chains through
+ *                   faceted glass, bounces off small spheres, GGX lobes driven by a roughness map — fall from 90 - 990 per million to 0 - 6
+ *                   (BASELINE config 2: none in 10^6 paths, worst path 4e-5).  Two implementations that render the same bits:
+ *                   in the megakernel at 128 VGPRs (1.7 - 3.6 % slower on scenes without meshes) and in the split pipeline's shading kernel
+ *                   (8 - 26 % on mesh scenes); the library takes the faster one for the scene.
  *                   -1 (default) = automatic: ON for scenes without triangle meshes (BASELINE config 2: small spheres are what multiplies an
- *                   fp32 ray's error, and there it is all but free), OFF for the others; 0 = off; 1 = on.  hr_stats.shading_in_force says
+ *                   fp32 ray's error, and there it costs little), OFF for the others; 0 = off; 1 = on.  hr_stats.shading_in_force says
  *                   what runs.  (1 excludes "russian_roulette"; -1 stands back when the roulette is on.)
  *   next hr_upload_scene:
  *   "bvh_builder"   -1 = by scene size (default): the host's binned-SAH build below 200,000 primitives (the best tree; one host thread,

@@ -38,6 +38,10 @@ int hr_debug_draws(hr_ctx *ctx, uint32_t sampling, uint32_t first_path, uint32_t
  * sampling: out[((y*W + x)*4 + sub)*20 + d]; d=0,1 = accepted lens sample (2u-1, 2v-1) after the rejection
  * loop of camera.rs:66-81, d=2.. = the (f64,f64) pairs of renderer.rs:175 in order. */
 int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
+/* The same slots of the records' twin (precise shading in force; option "draw_residuals"): what rounding each of those draws to fp32 took away —
+ * f64 draw d of the path = (double)draw d + (double)residual d, to 2^-49; d = 0, 1 belong to the RAW lens draws u, v (not to 2u-1, 2v-1).
+ * HR_ERR_UNSUPPORTED when the launch would carry no residuals. */
+int hr_debug_path_draw_residuals(hr_ctx *ctx, uint32_t sampling, float *host_out);
 
 /* Per-path accounting of ONE sampling through the production pipeline (seed kernel + the render kernel's LOG instantiation: the same
  * traversal and the same path state machine as hr_render; the accumulator is not touched).  out: W*H*4 records of eight 32-bit words,
@@ -47,6 +51,9 @@ int hr_debug_path_draws(hr_ctx *ctx, uint32_t sampling, float *host_out);
  * The oracle keeps the same log (orc_path_log): tests/test_gpu_parity.py compares path by path. */
 int hr_debug_path_log(hr_ctx *ctx, uint32_t sampling, uint32_t *host_out);
 
+/* "draw_residuals" (default 1): with precise shading in force the default seed kernel (seed_mode 2) also writes what rounding each draw to fp32
+ * took away into the records' twin (device_scene.h RenderParams::rec_lo_off) and shading computes with fp32 draw + residual = the reference's
+ * f64 draw; 0 = the fp32 draws alone (the A/B: profiles/r06_exact_draws_ablation.txt).  Other seed kernels (seed_mode != 2) never write residuals. */
 /* The split pipeline (debug option "trace_mode" 1: the loop body of renderer.rs:174-200 cut at scene.intersect into a traversal kernel and a
  * shading kernel per path iteration) kernel by kernel: ONE launch of num_k samplings from `sampling`, alone on the chip, an event between
  * every two kernels.  ms_out[21]: [0] = camera rays, [2 s - 1] / [2 s] = traversal / shading kernel of step s = 1 .. 10;

@@ -18,16 +18,6 @@
 #include "lbvh_core.h"
 #include "post_core.h"
 #include <cstdlib>
-// Ablation hook (prec_core.h PREC_DRAW): with emu_set_exact_draws(1) precise shading computes with the path's UNROUNDED f64 draws (found by
-// their fp32 value among the path's outputs) instead of the hand-off record's fp32 values — what a record of f64 draws would buy.
-static thread_local const double *g_exact_draws = nullptr;
-static thread_local int g_exact_n = 0;
-static inline double emu_exact_draw(float r) {
-    for (int i = 0; i < g_exact_n; i++)
-        if ((float)g_exact_draws[i] == r) return g_exact_draws[i];
-    return (double)r;
-}
-#define PREC_DRAW(r) emu_exact_draw(r)
 #include "pt_core.h"
 #include "wf_core.h"
 
@@ -44,15 +34,18 @@ struct ArrMem {
     void st8(int i, u64 A, u64 B, u64 C, u64 D, u64 E, u64 F, u64 G, u64 H) { m[i] = A; m[i + 1] = B; m[i + 2] = C; m[i + 3] = D; m[i + 4] = E; m[i + 5] = F; m[i + 6] = G; m[i + 7] = H; }
 };
 // one hand-off record (device_scene.h) and a window of raw outputs for the fix-up path
-struct ArrRec {   // one lane (base = 4 * lane) of a one-item block in the device layout [quad][64 lanes][4]
-    float f[REC_ITEM_FLOATS];
+static int g_draw_residuals = 1;   // emu_set_draw_residuals: 0 = precise shading on the fp32 draws alone (the ablation)
+struct ArrRec {   // one lane (base = 4 * lane) of a one-item block in the device layout [quad][64 lanes][4], and its twin with the draws' residuals
+    float f[2 * REC_ITEM_FLOATS];
     uint32_t base = 0;
     void st4(int slot, float a, float b, float c, float d) { float *q = f + rec_slot(base, (uint32_t)slot); q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+    void st4lo(int slot, float a, float b, float c, float d) { float *q = f + REC_ITEM_FLOATS + rec_slot(base, (uint32_t)slot); q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
     float at(int slot) const { return f[rec_slot(base, (uint32_t)slot)]; }
 };
 // the path of pixel (x, y), sub-sample `sub` as the kernel addresses it: tile, lane of the tile (Path::q bits 0-5), record lane base
 static void emu_place_path(RenderParams &rp, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sub, Path &p, ArrRec &rec) {
     rp.width = W; rp.height = H; rp.tiles_x = (W + 3) / 4; rp.tiles_y = (H + 3) / 4;
+    rp.rec_lo_off = g_draw_residuals ? REC_ITEM_FLOATS : 0u;   // precise shading: as hr_api.hip sets it for a precise launch
     p.tile = (y / 4) * rp.tiles_x + x / 4;
     p.q = ((y % 4) * 4 + x % 4) * 4 + sub;
     rec.base = p.q * 4u;
@@ -66,7 +59,7 @@ static bool path_record(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     path_seed_words(W, H, px, py, sub, s, t);
     {
         ArrMem mem;
-        RecordTail<ArrRec> lt(rec, lens_shape);
+        RecordTail<ArrRec, true> lt(rec, lens_shape);
         isaac_seed_round<REC_DRAWS>(mem, warm, 8700304ULL, (u64)sampling, s, t, lt);
         lt.finish();
         if (fixed) *fixed = lt.overflow();
@@ -75,18 +68,7 @@ static bool path_record(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32
     ArrMem mem;
     ArrWindow win;
     isaac_seed_round<ISAAC_TAIL>(mem, warm, 8700304ULL, (u64)sampling, s, t, win);
-    return record_from_window(win, ISAAC_TAIL, lens_shape, rec);
-}
-static int g_exact_on = 0;
-// every output of the path's generator the record could hold, as the reference's f64 (isaac_to_f64)
-static void path_exact_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, double *out) {
-    static const IsaacWarm warm = isaac_warm();
-    u64 s, t;
-    path_seed_words(W, H, px, py, sub, s, t);
-    ArrMem mem;
-    ArrWindow win;
-    isaac_seed_round<ISAAC_TAIL>(mem, warm, 8700304ULL, (u64)sampling, s, t, win);
-    for (int k = 0; k < ISAAC_TAIL; k++) out[k] = isaac_to_f64(win.ld(k));
+    return record_from_window<true>(win, ISAAC_TAIL, lens_shape, rec);
 }
 static bool path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
     ArrRec rec;
@@ -302,6 +284,15 @@ void emu_scene_stats(const emu_scene *e, uint64_t *out) {
 int emu_path_draws(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
     return path_draws(W, H, px, py, sub, sampling, lens_shape, out20) ? 0 : 1;
 }
+// the same slots of the record's twin (RecordTail<.., LO> / record_from_window<LO>): what rounding each draw to fp32 took away; slots 0, 1 = the
+// residuals of the RAW lens draws u, v (path_draws reports the lens point 2 u - 1 there, from the head)
+int emu_path_draw_residuals(uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t sub, uint32_t sampling, int lens_shape, float *out20) {
+    ArrRec rec;
+    bool ok = path_record(W, H, px, py, sub, sampling, lens_shape, rec);
+    uint32_t a = float_as_uint(rec.at(REC_HEAD));
+    for (int d = 0; d < DRAWS_PER_PATH; d++) out20[d] = rec.f[REC_ITEM_FLOATS + rec_slot(rec.base, (uint32_t)(2 * (int)a + d))];
+    return ok ? 0 : 1;
+}
 
 // raw tail: out[k] = k-th next_u64, k < window <= ISAAC_TAIL
 struct RawTail { uint64_t *out; int window; void put(int step, u64 v) { int k = 255 - step; if (k < window) out[k] = v; } };
@@ -417,9 +408,6 @@ static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint
     path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
     path_start(sc, rpp, p0, x, y, sub, rec.f);
     const float *prec = rec.f + rec.base;      // the path's record, as wf_rec_base() addresses it on the device
-    double exact[ISAAC_TAIL];
-    if (PREC && g_exact_on) { path_exact_draws(W, H, x, y, sub, sampling, exact); g_exact_draws = exact; g_exact_n = ISAAC_TAIL; }
-    struct ExactOff { ~ExactOff() { g_exact_draws = nullptr; g_exact_n = 0; } } exact_off;
     WfPath p;
     p.pid = 0; p.st = wf_st(1u, true, (p0.q >> 12) & 15u, 0u); p.raybase = 0; p.cur_refl = 1.0f;
     p.accum = v3(0, 0, 0); p.refl = v3(1, 1, 1);
@@ -457,7 +445,7 @@ static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint
         b.nee = false;
         bx.next_o_lo = bx.next_d_lo = v3(0, 0, 0);
         bool fin;
-        if (PREC) fin = wf_surface_f64<false, LOG>(sc, p, prec, rays[ns].o, rays[ns].d, rays[ns].o_lo, rays[ns].d_lo, hits[ns], b, bx, &lc, lg);
+        if (PREC) fin = wf_surface_f64<false, LOG>(sc, p, prec, rpp.rec_lo_off ? prec + rpp.rec_lo_off : nullptr, rays[ns].o, rays[ns].d, rays[ns].o_lo, rays[ns].d_lo, hits[ns], b, bx, &lc, lg);
         else fin = wf_surface<false, LOG>(sc, p, prec, rays[ns].o, rays[ns].d, hits[ns], b, &lc, lg);
         if (fin) break;
         nxt.clear();
@@ -480,7 +468,7 @@ static V3f emu_wf_path(const Scene &sc, const RenderParams &rp, uint32_t W, uint
 extern "C" {
 static int g_wf_precise = 0;
 extern "C" void emu_set_wf_precise(int on) { g_wf_precise = on; }
-extern "C" void emu_set_exact_draws(int on) { g_exact_on = on; }
+extern "C" void emu_set_draw_residuals(int on) { g_draw_residuals = on; }
 extern "C" int emu_render_wf(const emu_scene *e, uint32_t W, uint32_t H, uint32_t s_begin, uint32_t s_end, uint32_t stride, int nthreads, float *acc) {
     Scene sc = e->view;
     sc.qnodes = nullptr;

@@ -111,10 +111,10 @@ def set_walk_mode(mode):
     lib().emu_set_walk_mode(mode)
 
 
-def set_exact_draws(on):
-    """ablation for path_log_wf / render_wf with precise shading: compute with the path's unrounded f64 draws (emu.cpp emu_exact_draw)"""
-    lib().emu_set_exact_draws.argtypes = [C.c_int]
-    lib().emu_set_exact_draws(1 if on else 0)
+def set_draw_residuals(on):
+    """precise shading with (default, as the library renders) or without the records' twin of draw residuals (isaac_core.h draw_lo_f32)"""
+    lib().emu_set_draw_residuals.argtypes = [C.c_int]
+    lib().emu_set_draw_residuals(1 if on else 0)
 
 
 def set_precise(on):
@@ -137,6 +137,14 @@ def last_node_tests():
 def path_draws(w, h, x, y, sub, sampling, lens_shape=1):
     out = np.empty(20, dtype=np.float32)
     rc = lib().emu_path_draws(w, h, x, y, sub, sampling, lens_shape, out.ctypes.data)
+    return out, rc == 0
+
+
+def path_draw_residuals(w, h, x, y, sub, sampling, lens_shape=1):
+    """the record's twin (precise shading): f64 draw k of the path = float(draw k) + residual k to 2^-49; [0], [1] belong to the raw lens draws"""
+    out = np.empty(20, dtype=np.float32)
+    lib().emu_path_draw_residuals.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
+    rc = lib().emu_path_draw_residuals(w, h, x, y, sub, sampling, lens_shape, out.ctypes.data)
     return out, rc == 0
 
 

@@ -18,7 +18,7 @@ def test_hip_library_exports_header(ha):
     names = _declared("hanamaru_hip.h", "hr")
     assert len(names) >= 29 and "hr_comm_info" in names and "hr_accumulator_sum" in names
     debug = _declared("hanamaru_hip_debug.h", "hr")
-    assert set(debug) == {"hr_set_debug_option", "hr_debug_draws", "hr_debug_path_draws", "hr_debug_path_log", "hr_debug_intersect", "hr_debug_trace", "hr_debug_wf_profile"}
+    assert set(debug) == {"hr_set_debug_option", "hr_debug_draws", "hr_debug_path_draws", "hr_debug_path_draw_residuals", "hr_debug_path_log", "hr_debug_intersect", "hr_debug_trace", "hr_debug_wf_profile"}
     assert not [n for n in names if n.startswith("hr_debug_") or n == "hr_set_debug_option"], "the product header declares a debug entry point"
     lib = C.CDLL(ha.HIP_LIB)
     for n in names + debug:

@@ -113,6 +113,11 @@ def test_kernel_lens_rejection_matches_oracle(emu, orc):
         deep = max(deep, j)
         exp = np.asarray([2 * f[2 * j] - 1, 2 * f[2 * j + 1] - 1] + f[2 * j + 2:2 * j + 20], dtype=np.float64).astype(np.float32)
         assert np.array_equal(got, exp)
+        # the record's twin (precise shading): fp32 draw + residual = the reference's f64 draw, to 2^-49
+        lo, ok = emu.path_draw_residuals(w, h, x, y, sub, s, 1)
+        exact = np.asarray(f[2 * j + 2:2 * j + 20], dtype=np.float64)
+        assert ok and np.abs(got[2:].astype(np.float64) + lo[2:].astype(np.float64) - exact).max() <= 2.0 ** -49
+        assert np.array_equal(lo[2:], (exact - got[2:].astype(np.float64)).astype(np.float32))
     assert deep >= 2                       # the sample exercised repeated rejections
     # paths that reject the first LENS_FAST = 5 attempts leave the 28-draw hand-off record and go through the fix-up
     # path (record_from_window, isaac_core.h): probability 4.6e-4 each, so search for some
@@ -130,6 +135,9 @@ def test_kernel_lens_rejection_matches_oracle(emu, orc):
         got, ok = emu.path_draws(w, h, x, y, sub, s, 1)
         exp = np.asarray([2 * f[2 * j] - 1, 2 * f[2 * j + 1] - 1] + f[2 * j + 2:2 * j + 20], dtype=np.float64).astype(np.float32)
         assert ok and np.array_equal(got, exp)
+        lo, ok = emu.path_draw_residuals(w, h, x, y, sub, s, 1)      # the fix-up path writes the twin too, rebased like the record
+        exact = np.asarray(f[2 * j + 2:2 * j + 20], dtype=np.float64)
+        assert ok and np.array_equal(lo[2:], (exact - got[2:].astype(np.float64)).astype(np.float32))
     assert fixed >= 3
     sq, ok = emu.path_draws(64, 64, 1, 2, 3, 4, 0)   # square lens: first pair always accepted
     f = [orc.u64_to_f64(v) for v in orc.path_draws(64, 64, 1, 2, 1, 1, 4, 4)]

@@ -1,6 +1,6 @@
-"""Ablation on the host emulation (CPU only, test infrastructure): what would precise shading gain if the hand-off record carried the
-reference's f64 draws instead of their fp32 roundings?  Per-path accounting against the oracle (tests/path_parity.py), precise shading
-as the kernels compute it vs. the same with the unrounded draws (tests/emu/emu.cpp emu_exact_draw).
+"""Ablation on the host emulation (CPU only, test infrastructure): what the records' twin of draw residuals (isaac_core.h draw_lo_f32,
+RenderParams::rec_lo_off) buys precise shading.  Per-path accounting against the oracle (tests/path_parity.py): fp32 shading, precise
+shading on the fp32 draws alone, precise shading as the library renders it (fp32 draw + residual = the reference's f64 draw).
 
     python tools/exact_draws_ablation.py [--size 192 108] [--samplings 1 2] [--threads 1] > profiles/r06_exact_draws_ablation.txt
 """
@@ -33,12 +33,12 @@ def main():
         for s in a.samplings:
             ref = o.path_log(w, h, s)
             rows = []
-            for label, exact in (("precise shading, fp32 draws (the kernels)", False), ("precise shading, unrounded f64 draws", True)):
-                emu.set_exact_draws(exact)
+            for label, lo in (("precise shading, fp32 draws alone", False), ("precise shading (draws with their residuals)", True)):
+                emu.set_draw_residuals(lo)
                 try:
                     acc = path_parity.account(e.path_log_wf(w, h, s, a.threads), ref)
                 finally:
-                    emu.set_exact_draws(False)
+                    emu.set_draw_residuals(True)
                 sb = acc["same_branch"]
                 rows.append("%-44s %6.0f | %6.0f | %7.0f | %.3g" % (label, acc["divergent_ppm"], sb["over_1e-3_floor1_ppm"], sb["over_1e-4_floor1_ppm"], sb["max_rel_floor1"]))
             fp = path_parity.account(e.path_log(w, h, s, a.threads), ref)

@@ -62,6 +62,13 @@ python tools/ab/split_ab.py --samplings 128 --scenes rtcamp6_v3_1,rtcamp6_v2,rtc
 python tools/ab/split_ab.py --samplings 128 --scenes simple,material_examples,cornell_mini --modes 0,3 2>&1 | grep -v libdrm >> $OUT/${TAG}_split_ab.txt
 python tools/ab/split_ab.py --scenes rtcamp6_v3_1,rtcamp6_v2,spheres --modes 2 --profile-only --counters 2>&1 | grep -v libdrm > $OUT/${TAG}_split_profile.txt
 python tools/ab/precise_check.py 2>&1 | grep -v libdrm > $OUT/${TAG}_precise_parity_480x270.txt
+# precise shading: fp32 / megakernel form / split form on every scene; the figures behind PATH_LIMITS_PRECISE; the draws' residuals on and off
+python tools/ab/split_ab.py --modes 0,3,2 --scenes spheres,simple,material_examples,cornell_mini,rtcamp6_v3_1,rtcamp6_v3,rtcamp5,tbf3,rtcamp6_dodeca,rtcamp6_v2,rtcamp6_v1 2>&1 | grep -v libdrm > $OUT/${TAG}_precise_pipelines.txt
+bash tools/ab/precise_limits.sh 2>/dev/null | grep precise > $OUT/${TAG}_precise_limits.txt
+( echo "# draw_residuals 1 (default), then 0: modes 0 = fp32 shading, 3 = precise in the megakernel, 2 = precise in the split pipeline"
+  python tools/ab/split_ab.py --modes 0,3,2 --scenes spheres,rtcamp6_v3_1 --opt draw_residuals=1 2>&1 | grep -v libdrm
+  python tools/ab/split_ab.py --modes 0,3,2 --scenes spheres,rtcamp6_v3_1 --opt draw_residuals=0 2>&1 | grep -v libdrm ) > $OUT/${TAG}_precise_draw_residuals_ab.txt
+python -m pytest tests -m gpu -q -s -k "precise or variants or path_draws" 2>&1 | grep -E "precise|passed|failed" > $OUT/${TAG}_precise_tests_gpu.txt
 bash tools/ab/cli_batch.sh > $OUT/${TAG}_cli_report_granularity.txt 2>&1
 python bench.py --precise --spp-per-step 16 --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_precise.json.log 2>> $OUT/bench_full.err
 python bench.py --no-precise --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres_fp32_shading.json.log 2>> $OUT/bench_full.err
