@@ -122,7 +122,7 @@ def test_path_draws_match_oracle_after_lens_rejection(gpu, scenes, orc):
         for x in range(w):
             for sub in range(4):
                 raw = orc.path_draws(w, h, x, y, sub & 1, sub >> 1, sampling, 64)
-                f = (np.asarray(raw, dtype=np.uint64) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+                f = (np.asarray(raw, dtype=np.uint64) & np.uint64((1 << 52) - 1)).astype(np.float64) * 2.0 ** -52      # rand 0.4.3 next_f64: the low 52 bits (orc.u64_to_f64)
                 j = 0
                 while not ((2 * f[2 * j] - 1) ** 2 + (2 * f[2 * j + 1] - 1) ** 2 < 1.0):
                     j += 1
