@@ -53,9 +53,10 @@ static void usage(const char *prog) {
            "        --launch L      reports per GPU launch (default 0: as many as fill the chip — 4 samplings per device at 1920x1080); the lines of a\n"
            "                        launch are printed when it is done, its time split evenly over them; 1 = a launch per report\n"
            "        --inflight K    launches enqueued ahead on the GPU (default 8; 1 = wait for every launch before the next starts)\n"
-           "        --precise       precise shading: the geometry of every bounce in f64 (hr_set_option \"precise_shading\"): closer to the reference's\n"
-           "                        f64 arithmetic on refraction chains and small spheres; default: on for scenes without meshes (where it is all but\n"
-           "                        free), off for mesh scenes (where it costs 5 - 20 %%); --no-precise: fp32 shading whatever the scene\n"
+           "        --precise       precise shading: the geometry of every bounce in f64 from the reference's f64 draws (hr_set_option\n"
+           "                        \"precise_shading\"): the reference's own arithmetic on refraction chains, small spheres and roughness maps;\n"
+           "                        default: on for scenes without meshes (where it costs 2 - 4 %%), off for mesh scenes (7 - 30 %%);\n"
+           "                        --no-precise: fp32 shading whatever the scene\n"
            "        --gpus N        render on devices 0..N-1 of this node from this one process: device r takes every N-th sampling,\n"
            "                        the accumulators are summed with one RCCL all-reduce when an image is written (default 1)\n"
            "        --gpu-ids LIST  the same with an explicit comma-separated device list\n"

@@ -3,7 +3,7 @@ path of one 320x180 sampling compared with the oracle's (tests/path_parity.py). 
 differ, or ppm figures far from their neighbours.  Round 5: on every scene the PRODUCTION kernel also renders two samplings with and without
 nee_setup's shortcuts (debug option nee_cull 7 / 0: shadow rays known to add nothing are not traced / every shadow ray traced) — the two
 accumulators must be the same bit for bit (`culls identical`), random emitters of random radii are where a marginal case would hide.
-python tools/fuzz_campaign.py [first_seed [count]] > profiles/rNN_fuzz_campaign.txt"""
+python tools/fuzz_campaign.py [first_seed [count [precise]]] > profiles/rNN_fuzz_campaign.txt      (precise 1: option precise_shading pinned on)"""
 import sys, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ import hanamaru_amd as ha, oracle_py as orc, path_parity, random_scenes
 r = ha.Renderer(0)
 FIRST = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 COUNT = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+PRECISE = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 0: fp32 shading pinned (as rounds 4, 5 ran it); 1: precise shading
 for seed in range(FIRST, FIRST + COUNT):
     kw = {}
     if seed % 4 == 1: kw = dict(spheres=40, cuboids=10, meshes=3)
@@ -26,6 +27,7 @@ for seed in range(FIRST, FIRST + COUNT):
     o = orc.OracleScene(sc.desc_ptr)
     r.set_option("bvh_builder", seed % 3)
     r.upload_scene(sc)
+    r.set_option("precise_shading", PRECISE)
     w, h = 320, 180
     r.set_resolution(w, h)
     a = path_parity.account(r.debug_path_log(1), o.path_log(w, h, 1))
