@@ -343,7 +343,7 @@ def test_oracle_whole_frame_pin(scenes, orc):
     """Pin 1b (round 6): the oracle against the reference binary's committed render over the WHOLE frame.  tools/oracle_whole_frame_pin.py
     rendered all 1920 x 1080 pixels x 1,000 samplings with the oracle once, offline (hours of CPU), ran its post chain and recorded, as data:
     every channel where oracle - reference != 0, per-row counts, and the f64 accumulators of six row triples.  Here: (i) the record is
-    consistent and says what DESIGN.md §6.1 quotes (the whole frame within 1 LSB, > 99.8 % identical); (ii) segments of the recorded
+    consistent and says what DESIGN.md §6.1 quotes (not one of the 6,220,800 channels differs); (ii) segments of the recorded
     accumulator rows are re-derived with the oracle as it is built now — exact equality: the record IS this oracle's output; (iii) the middle
     row of every triple, resolved here, reproduces reference + recorded difference on all 1,920 pixels — accumulator, post chain and the
     difference list hang together."""
@@ -362,7 +362,7 @@ def test_oracle_whole_frame_pin(scenes, orc):
     assert np.array_equal((diff == 0).reshape(H, -1).sum(axis=1), z["rows_exact"]) and np.array_equal((np.abs(diff) <= 1).reshape(H, -1).sum(axis=1), z["rows_within1"])
     identical, within1, worst = float((diff == 0).mean()), float((np.abs(diff) <= 1).mean()), int(np.abs(diff).max())
     print("oracle vs the reference binary's render, whole frame: %.4f %% identical, %.4f %% within 1 LSB, worst %d LSB, %d differing channels" % (100 * identical, 100 * within1, worst, len(z["diff_val"])))
-    assert identical >= 0.998 and within1 >= 0.9999 and worst <= 2
+    assert len(z["diff_val"]) == 0 and identical == 1.0 and worst == 0        # measured: byte-identical over the whole frame
     oracle_img = ref + diff
     # (ii) + (iii)
     _, o = scenes("rtcamp6_v3_1")
