@@ -1547,7 +1547,8 @@ def test_config2_spheres_full_size_crops(gpu, scenes):
     assert st["paths"] == 1920 * 1080 * 4 * 64 and st["rng_overflow"] == 0 and st["tri_tests"] == 0 and st["sphere_tests"] > 0
 
 
-def test_matches_the_reference_binarys_committed_render(gpu, scenes):
+@pytest.mark.parametrize("precise", [0, 1])
+def test_matches_the_reference_binarys_committed_render(gpu, scenes, precise):
     """tests/golden/reference_rtcamp6_1000x4spp.png is the image the REFERENCE binary produced (committed in its repository
     as rtcamp6_1000x4spp.png, README.md:19): default scene, 1920x1080, `-s 1000`.  It is the one output of the real Rust
     program available here, so it pins everything at once: per-path ISAAC-64 seeding incl. the u64->f64 conversion, the
@@ -1561,14 +1562,23 @@ def test_matches_the_reference_binarys_committed_render(gpu, scenes):
     gpu.upload_scene(sc)
     gpu.set_resolution(1920, 1080)
     gpu.set_option("batch", 0)
-    gpu.clear()
-    gpu.render(1, 1001)
-    img = gpu.resolve(1000).astype(np.float64)
+    gpu.set_option("precise_shading", precise)      # (automatic = fp32 shading on this scene; 1: the split pipeline with f64 bounces)
+    try:
+        gpu.clear()
+        gpu.render(1, 1001)
+        img = gpu.resolve(1000).astype(np.float64)
+    finally:
+        gpu.set_option("precise_shading", -1)
     d = np.abs(img - ref)
     psnr = 10 * np.log10(255.0 ** 2 / (d ** 2).mean())
-    print("PSNR %.2f dB, mean abs diff %.4f, exact channels %.4f, within 1 LSB %.4f, max %d" % (psnr, d.mean(), (d == 0).mean(), (d <= 1).mean(), d.max()))
-    # measured: PSNR 74.2 dB, 99.80 % of the channels identical, 99.99 % within 1 LSB, max 7
-    assert psnr > 70.0 and (d == 0).mean() > 0.997 and (d <= 1).mean() > 0.9998 and d.max() <= 12
+    print("vs the reference binary's image, precise %d: PSNR %.2f dB, mean abs diff %.4f, exact channels %.5f, within 1 LSB %.6f, max %d" % (precise, psnr, d.mean(), (d == 0).mean(), (d <= 1).mean(), d.max()))
+    # measured (profiles/r06_reference_image_compare.txt): fp32 shading PSNR 76.2 dB, 99.858 % of the channels identical, 99.9974 % within 1 LSB,
+    # max 6; precise shading 77.8 dB, 99.895 %, 99.9990 %, max 3.  (The ORACLE's image is byte-identical to it: tests/test_oracle.py.)  What is
+    # left with precise shading is the fp32 accumulator and post chain at quantisation borders, and the divergent paths.
+    if precise:
+        assert psnr > 74.0 and (d == 0).mean() > 0.998 and (d <= 1).mean() > 0.99995 and d.max() <= 6
+    else:
+        assert psnr > 70.0 and (d == 0).mean() > 0.997 and (d <= 1).mean() > 0.9998 and d.max() <= 12
 
 
 @pytest.mark.parametrize("name,max_leaf", [("rtcamp6_v3_1", 4), ("rtcamp6_dodeca", 4), ("spheres", 2), ("cornell_mini", 1)])
