@@ -181,12 +181,14 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> rgb((size_t)width * height * 3);
     double begin = now_sec(), last_progress = begin, last_image = begin;
     uint32_t counter = 0, sampled = 0;
+    std::string last_png;     // the image file save() wrote last: result.png is a copy of the final one (one PNG encode, not two)
     auto save = [&](uint32_t s) -> int {
         char path[32];
         snprintf(path, sizeof path, "%03u.png", counter);
         double t0 = now_sec();
         if (combine() || resolve(s, rgb.data()) != 0) { fprintf(stderr, "hr_resolve: %s\n", hr_last_error()); return 1; }
         printf("update_imgbuf: %.3f sec\n", now_sec() - t0);
+        last_png = path;
         return hh_write_png_rgb8(path, rgb.data(), width, height);
     };
     uint32_t first = 1;
@@ -345,7 +347,22 @@ int main(int argc, char **argv) {
         if (f) fclose(f);
         if (!ok) { fprintf(stderr, "cannot write checkpoint %s\n", ckpt_out.c_str()); return 1; }
     }
-    if (hh_write_png_rgb8("result.png", rgb.data(), width, height) != 0) { fprintf(stderr, "png: %s\n", hh_last_error()); return 1; }
+    {   // main.rs:1217: result.png = the final image — the bytes finish() has just written as NNN.png
+        bool copied = false;
+        if (!last_png.empty()) {
+            FILE *in = fopen(last_png.c_str(), "rb"), *out = in ? fopen("result.png", "wb") : nullptr;
+            if (in && out) {
+                std::vector<char> buf(1 << 20);
+                size_t n;
+                copied = true;
+                while ((n = fread(buf.data(), 1, buf.size(), in)) > 0) copied = copied && fwrite(buf.data(), 1, n, out) == n;
+                copied = copied && !ferror(in);
+            }
+            if (in) fclose(in);
+            if (out) copied = (fclose(out) == 0) && copied;
+        }
+        if (!copied && hh_write_png_rgb8("result.png", rgb.data(), width, height) != 0) { fprintf(stderr, "png: %s\n", hh_last_error()); return 1; }
+    }
     tee("sampled: %ux%u spp.", sampled, 4u);
     hr_stats st;
     if (hr_get_stats(ctx, &st) == 0) {
