@@ -412,7 +412,7 @@ def main():
                                    % (args.scene, W, H, samplings_run, total_paths, args.steps, ("%d or %d" % (SPS - 1, SPS)) if HEADLINE and HEADLINE % args.steps else str(SPS), world,
                                       (", last step clipped to --total-samplings %d" % S_TOTAL) if S_TOTAL else "",
                                       ("; the default plan: BASELINE's %d samplings per GPU whatever --steps is" % HEADLINE) if HEADLINE else ""),
-                       "shading": ["fp32 shading (megakernel)", "precise shading: bounce geometry in f64, in the megakernel", "precise shading: bounce geometry in f64, in the split pipeline",
+                       "shading": ["fp32 shading (megakernel)", "precise shading: bounce geometry in f64 from the f64 draws, in the megakernel", "precise shading: bounce geometry in f64 from the f64 draws, in the split pipeline",
                                    "fp32 shading in the split pipeline (debug)"][int(st.get("shading_in_force", 0))] + (" [option precise_shading %d]" % (1 if args.precise else 0) if args.precise or args.no_precise else " [automatic]"),
                        "samplings_total": samplings_run, "paths_total": total_paths,
                        "samplings_per_step_per_gpu": SPS, "samplings_per_launch_requested": args.batch, "paths_per_step": round(total_paths / args.steps) if HEADLINE else paths_per_step_gpu * world,

@@ -249,8 +249,8 @@ __global__ void governor_kernel(GovDev *g, uint32_t slot) {
 }
 // What options precise_shading / trace_mode mean for the scene in place.  Precise shading has two homes that render the same bits
 // (path_advance<.., PREC> in the megakernel at 128 VGPRs; the split pipeline's shading kernel), so which one runs is a question of speed only:
-// the megakernel form costs 1.7 - 3.6 % on scenes without meshes (the trace side stays hidden behind the seed kernel), on every mesh scene the
-// split form is the faster one (8 - 26 % below fp32 shading; profiles/r06_precise_pipelines.txt).  AUTOMATIC precise shading: on for scenes
+// the megakernel form costs 1.9 - 3.7 % on scenes without meshes (the trace side stays hidden behind the seed kernel), on every mesh scene the
+// split form is the faster one (7 - 30 % below fp32 shading; profiles/r06_precise_pipelines.txt).  AUTOMATIC precise shading: on for scenes
 // without triangle meshes — small spheres are what multiplies an fp32 ray's error, and there it costs little —, off where it costs.
 static void resolve_modes(hr_ctx *c) {
     const bool has_scene = c->have_scene;

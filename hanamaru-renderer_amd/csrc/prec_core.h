@@ -5,15 +5,16 @@
 
 namespace hr {
 
-// PRECISE shading (option precise_shading): the geometry of a bounce in the reference's own precision.  The walk stays fp32 — it only
-// has to find the right primitive —, but the ray the path really follows is carried as fp32 + residual (o + o_lo, d + d_lo: what rounding
-// the f64 ray to the fp32 ray the traversal walks took away), and everything between "this primitive was hit" and "the next ray" is f64:
-// the hit distance again from the f64 ray and the f64 primitive (triangle plane from the f64 vertices: Scene::tri_exact; sphere centre and
-// radius: sphere_lo; cuboid bounds: cuboid_lo), hit point, normal, mirror / Snell / Fresnel (material.rs:154-199, vector.rs:60-71).  A
-// faceted glass body is a billiard and a small sphere multiplies a position error by 2 t / r per bounce: fp32 ray state leaves 100 - 1,000 ppm
-// of the paths that took the reference's branches off by more than 1e-3 in such scenes; the megakernel has no registers
-// for this (profiles/NOTES.md G), the shading kernel of the split pipeline does.  What stays fp32: the draws themselves (the hand-off
-// record holds them rounded once), the directions SAMPLED from them (diffuse lobe, GGX half vector), textures, radiometry.
+// The walk stays fp32 — it only has to find the right primitive —, but the ray the path really follows is carried as fp32 + residual
+// (o + o_lo, d + d_lo: what rounding the f64 ray to the fp32 ray the traversal walks took away), and everything between "this primitive was
+// hit" and "the next ray" is f64: the hit distance again from the f64 ray and the f64 primitive (triangle plane from the f64 vertices:
+// Scene::tri_exact; sphere centre and radius: sphere_lo; cuboid bounds: cuboid_lo), hit point, normal, mirror / Snell / Fresnel
+// (material.rs:154-199, vector.rs:60-71), the directions sampled from the draws (diffuse lobe, GGX half vector; own f64 sincos) and the GGX
+// reflectance scalar — from the reference's f64 DRAWS (the record's fp32 value + its residual from the record's twin, device_scene.h) and, where
+// a roughness map drives the lobe, from the map read at f64 texture coordinates.  A faceted glass body is a billiard and a small sphere multiplies a
+// position error by 2 t / r per bounce: fp32 ray state leaves 100 - 1,000 ppm of the paths that took the reference's branches off by more than
+// 1e-3 in such scenes, this leaves 0 - 6.  What stays fp32: the walk, albedo / emission lookups, the sky lookup, NEE (sample
+// point, weight), radiometry.
 struct D3 { double x, y, z; };
 HD D3 dv(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
 HD D3 operator+(D3 a, D3 b) { return dv(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -191,7 +192,7 @@ HD void shade_hit_f64(const Scene &sc, V3f ro, V3f rd, V3f fo, V3f fd, const Tra
         m.emission = tex_sample(sc, mt.emission_img, v3(mt.emission), s.u, s.v);
         m.roughness = mt.roughness_img < 0 ? mt.roughness : (rough64 >= 0.0f ? rough64 : sample_bilinear(sc, mt.roughness_img, s.u, s.v).x) * mt.roughness;
     }
-        bool &transmitted = x.transmitted, &sampled = x.sampled;
+    bool &transmitted = x.transmitted, &sampled = x.sampled;
     transmitted = false; sampled = true;
     D3 &no = x.no, &nd = x.nd;
     no = dv(0, 0, 0); nd = dv(0, 0, 0);
