@@ -192,10 +192,15 @@ def main():
     # the default plan (neither --spp-per-step nor --total-samplings): the literal BASELINE configuration — samplings 1 .. 1024 per GPU
     # in exactly --steps steps (steps differ by at most one sampling); more steps than samplings: one sampling per step
     HEADLINE = 0
+    # the library's launch size (hr_api.hip: --batch, or automatic = launches of about 33 M paths, 4 samplings at 1920x1080): the plan's steps are
+    # whole launches wherever --steps allows it, so that no step ends in a short launch (20 steps: 16 x 52 + 4 x 48 samplings, not 4 x 52 + 16 x 51)
+    LAUNCH = args.batch if args.batch else min(64, max(4, -(-33177600 // (W * H * 4))))
     if not SPS and not S_TOTAL:
         if args.steps <= args.headline_samplings:
             HEADLINE = args.headline_samplings
-            SPS = -(-HEADLINE // args.steps)      # the largest step (for the record; steps hold SPS or SPS - 1 samplings)
+            if HEADLINE % LAUNCH or args.steps > HEADLINE // LAUNCH:
+                LAUNCH = 1
+            SPS = -(-(HEADLINE // LAUNCH) // args.steps) * LAUNCH      # the largest step (for the record; steps hold SPS or SPS - LAUNCH samplings)
         else:
             SPS = 1
     elif not SPS:
@@ -268,7 +273,7 @@ def main():
         # step i covers samplings [i*SPS*world + 1, (i+1)*SPS*world]; rank g takes (s-1) % world == g
         for r, (g, _) in zip(rs, mine):
             if HEADLINE:
-                b, e, stride = headline_step_range(i, args.steps, HEADLINE, world, g)
+                b, e, stride = headline_step_range(i, args.steps, HEADLINE, world, g, LAUNCH)
             else:
                 b, e, stride = strong_step_range(i, SPS, world, g, S_TOTAL) if S_TOTAL else step_range(i, SPS, world, g)   # --total-samplings: the last step ends at sampling S_TOTAL
             r.render(b, e, stride)
@@ -409,9 +414,9 @@ def main():
             "vs_baseline": None, "dtype": "f32",
             "data": "reference scene assets shipped in-repo (assets/), per-path ISAAC-64 seeds as in renderer.rs:165-168",
             "config": {"workload": "%s %dx%d x %d samplings (x4 sub-samples = %d paths) in this run: %d steps x %s samplings per step per GPU x %d GPU(s)%s%s"
-                                   % (args.scene, W, H, samplings_run, total_paths, args.steps, ("%d or %d" % (SPS - 1, SPS)) if HEADLINE and HEADLINE % args.steps else str(SPS), world,
+                                   % (args.scene, W, H, samplings_run, total_paths, args.steps, ("%d or %d" % (SPS - LAUNCH, SPS)) if HEADLINE and (HEADLINE // LAUNCH) % args.steps else str(SPS), world,
                                       (", last step clipped to --total-samplings %d" % S_TOTAL) if S_TOTAL else "",
-                                      ("; the default plan: BASELINE's %d samplings per GPU whatever --steps is" % HEADLINE) if HEADLINE else ""),
+                                      ("; the default plan: BASELINE's %d samplings per GPU whatever --steps is, steps of whole launches (%d samplings)" % (HEADLINE, LAUNCH)) if HEADLINE else ""),
                        "shading": ["fp32 shading (megakernel)", "precise shading: bounce geometry in f64 from the f64 draws, in the megakernel", "precise shading: bounce geometry in f64 from the f64 draws, in the split pipeline",
                                    "fp32 shading in the split pipeline (debug)"][int(st.get("shading_in_force", 0))] + (" [option precise_shading %d]" % (1 if args.precise else 0) if args.precise or args.no_precise else " [automatic]"),
                        "samplings_total": samplings_run, "paths_total": total_paths,

@@ -31,11 +31,16 @@ def strong_step_range(step, samplings_per_rank, world, rank, total_samplings):
     return b, min(e, total_samplings + 1), s
 
 
-def headline_step_range(step, steps, per_gpu_total, world, rank):
+def headline_step_range(step, steps, per_gpu_total, world, rank, unit=1):
     """bench.py's default plan: exactly `per_gpu_total` samplings per GPU (BASELINE's 1,024) whatever --steps is.  Step i of K covers
-    the per-GPU sampling counts [floor(i*T/K), floor((i+1)*T/K)) — steps differ by at most one sampling — i.e. the 1-origin sampling
-    indices floor(i*T/K)*world + 1 .. floor((i+1)*T/K)*world over all GPUs, of which rank r takes those with (s-1) % world == r.
-    hr_render(begin, end, stride) arguments; requires steps <= per_gpu_total (every step renders at least one sampling per GPU)."""
-    lo = (step * per_gpu_total) // steps
-    hi = ((step + 1) * per_gpu_total) // steps
+    the per-GPU sampling counts [lo_i, lo_(i+1)) with lo_i = floor(i*U/K) * unit, U = per_gpu_total / unit — whole kernel launches (`unit`
+    samplings per GPU, the library's launch size: 4 at 1920x1080), so that no step ends in a short launch; steps differ by at most one launch.
+    With unit = 1, with a total that is no multiple of `unit`, or with more steps than launches: lo_i = floor(i*T/K), steps differ by at most
+    one sampling.  The 1-origin sampling indices of step i are lo_i*world + 1 .. lo_(i+1)*world over all GPUs, of which rank r takes those
+    with (s-1) % world == r.  hr_render(begin, end, stride) arguments; requires steps <= per_gpu_total."""
+    if unit > 1 and per_gpu_total % unit == 0 and steps <= per_gpu_total // unit:
+        units = per_gpu_total // unit
+        lo, hi = (step * units) // steps * unit, ((step + 1) * units) // steps * unit
+    else:
+        lo, hi = (step * per_gpu_total) // steps, ((step + 1) * per_gpu_total) // steps
     return lo * world + 1 + rank, hi * world + 1, world

@@ -80,17 +80,18 @@ def test_strong_scaling_plan_covers_exactly_the_total():
 @pytest.mark.timeout(300)
 def test_headline_plan_is_exactly_1024_samplings_per_gpu_for_any_step_count():
     """bench.py's default plan (no --spp-per-step, no --total-samplings): BASELINE's 1,024 samplings per GPU in exactly --steps steps,
-    whatever --steps is — the driver's `--steps 20` renders samplings 1..1024, not 320 (main.rs:1249-1251: `-s` is the sampling count)."""
+    whatever --steps is — the driver's `--steps 20` renders samplings 1..1024, not 320 (main.rs:1249-1251: `-s` is the sampling count) —, in
+    steps of whole kernel launches where the step count allows it (20 steps at 1080p: 16 x 52 + 4 x 48 samplings)."""
     sys.path.insert(0, os.path.join(ROOT, "hanamaru-renderer_amd", "python"))
     from hanamaru_amd.sharding import headline_step_range
-    for world in (1, 2, 3, 8):
-        for steps in (1, 7, 20, 64, 333, 1000, 1024):
+    for world, steps, unit in [(w, k, u) for w in (1, 2, 3, 8) for k in (1, 7, 20, 64, 256, 333, 1000, 1024) for u in (1, 4)]:
+        if True:
             seen, per_rank = [], [0] * world
             sizes = set()
             for i in range(steps):
                 n_step = 0
                 for r in range(world):
-                    b, e, st = headline_step_range(i, steps, 1024, world, r)
+                    b, e, st = headline_step_range(i, steps, 1024, world, r, unit)
                     mine = list(range(b, e, st))
                     assert all((s - 1) % world == r for s in mine)
                     seen += mine
@@ -99,7 +100,11 @@ def test_headline_plan_is_exactly_1024_samplings_per_gpu_for_any_step_count():
                 assert n_step % world == 0 and n_step >= world     # every rank the same count, at least one sampling per step
                 sizes.add(n_step // world)
             assert sorted(seen) == list(range(1, 1024 * world + 1))
-            assert per_rank == [1024] * world and max(sizes) - min(sizes) <= 1
+            assert per_rank == [1024] * world
+            if unit > 1 and steps <= 1024 // unit:      # whole launches of `unit` samplings per GPU: no step ends in a short launch
+                assert all(n % unit == 0 for n in sizes) and max(sizes) - min(sizes) <= unit, (world, steps, sizes)
+            else:
+                assert max(sizes) - min(sizes) <= 1
 
 
 def test_two_ranks_equal_one(tmp_path, emu, ha):
