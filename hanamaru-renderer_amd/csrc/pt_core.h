@@ -526,7 +526,10 @@ HD float bsdf_eval(int32_t surface, float param, float roughness, V3f view, V3f 
     float alpha2 = roughness * roughness;
     V3f h = normalize(light + view);
     float ln = dot(light, n);
-    if (signbit(ln)) return 0.0f;
+    // material.rs:64-67 returns 0 for a NEGATIVE l.n; l.n = +0 EXACTLY goes on to 0 / 0 there as well — in f64 it never happens, in fp32 it does
+    // (a shadow ray toward an emitter sample at the very height of a horizontal face: one path in ~10^10, a NaN pixel in a 1,024-sampling
+    // frame of cornell_mini).  The limit of bsdf x (l.n) for l.n -> 0+ is 0 (the Smith term vanishes): 0 is what a grazing sample adds.
+    if (!(ln > 0.0f)) return 0.0f;
     float vn = dot(view, n), vh = dot(view, h), hn = dot(h, n);
     float tmp = 1.0f - (1.0f - alpha2) * hn * hn;
     float d = alpha2 * HR_RCP(PI_F * tmp * tmp);

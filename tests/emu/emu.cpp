@@ -530,6 +530,28 @@ extern "C" int emu_path_log_wf(const emu_scene *e, uint32_t W, uint32_t H, uint3
     return 0;
 }
 
+// ONE path (debugging aid: build with -DHR_PATH_VERBOSE and set HR_V=1 for path_advance's line per finished ray): its radiance, fp32 or
+// precise shading as emu_set_precise says
+int emu_one_path(const emu_scene *e, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sub, uint32_t sampling, float *out3) {
+    Scene sc = e->view;
+    sc.qnodes = nullptr;
+    RenderParams rp{};
+    rp.width = W; rp.height = H;
+    rp.nee_cull_off = ~(uint32_t)g_nee_cull & 7u;
+    ArrRec rec;
+    Path p;
+    emu_place_path(rp, W, H, x, y, sub, p, rec);
+    path_record(W, H, x, y, sub, sampling, sc.cam.lens_shape, rec);
+    path_start(sc, rp, p, x, y, sub, rec.f);
+    LaneCounters lc = {0, 0, 0, 0, 0, 0};
+    for (;;) {
+        while (p.ts.cur != NODE_END) { trace_step<true>(sc, p.ray, p.ts, &lc); shadow_early_out(p); }
+        if (g_precise ? path_advance<true, false, false, true>(sc, rp, p, rec.f, &lc) : path_advance<true>(sc, rp, p, rec.f, &lc)) break;
+    }
+    out3[0] = p.accum.x; out3[1] = p.accum.y; out3[2] = p.accum.z;
+    return 0;
+}
+
 // hr_debug_path_log's layout from the emulated render: eight words per path {r, g, b (float bits), rays, ev 0-3, ev 4-7, ev 8, hash}
 // (path_advance<.., LOG> of pt_core.h — the code the kernel's LOG instantiation runs)
 int emu_path_log(const emu_scene *e, uint32_t W, uint32_t H, uint32_t sampling, int nthreads, uint32_t *out) {

@@ -86,6 +86,13 @@ class EmuScene:
         ev = np.ascontiguousarray(raw[..., 4:7]).view(np.uint8).reshape(h, w, 4, 12)[..., :12]
         return rad, raw[..., 3].copy(), ev.copy(), raw[..., 7].copy()
 
+    def one_path(self, w, h, x, y, sub, sampling):
+        """radiance of ONE path (fp32 or precise shading as set_precise says)"""
+        out = np.zeros(3, dtype=np.float32)
+        lib().emu_one_path.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p]
+        lib().emu_one_path(self._h, w, h, x, y, sub, sampling, out.ctypes.data)
+        return out
+
     def render_debug(self, w, h, mode):
         acc = np.zeros((h, w, 3), dtype=np.float32)
         lib().emu_render_debug(self._h, w, h, mode, acc.ctypes.data)

@@ -531,6 +531,25 @@ def test_precise_shading_closes_the_same_branch_tail(emu, emu_scenes, name, fp32
     assert abs(a64["mean_radiance"]["gpu"] - a64["mean_radiance"]["oracle"]) <= 1e-3 * a64["mean_radiance"]["oracle"]
 
 
+def test_ggx_nee_sample_exactly_at_the_horizon_adds_nothing(emu, emu_scenes):
+    """Round 6's second non-finite pixel, found by rendering every scene at 1920x1080 x 1,024 samplings: cornell_mini, sampling 732, pixel
+    (1394, 371), sub-sample 2 — a GGX hit on a horizontal cuboid face whose NEE sample on the second emitter lies, after fp32 rounding, at
+    EXACTLY the face's height: l.n = +0, material.rs:64-67 lets +0 through (it tests the sign), the Smith term is 0 and the denominator
+    4 (l.n)(v.n) too: 0 / 0.  In the reference's f64 the case does not occur (l.n ~ 1e-9 there: the term is ~0).  bsdf_eval returns the limit, 0;
+    the pixel then equals the oracle's."""
+    _, o, e = emu_scenes("cornell_mini")
+    w, h, x, y, s = 1920, 1080, 1394, 371, 732
+    ref = o.render_region(w, h, x, y, 1, 1, s, s + 1, threads=1)[0, 0]
+    for precise in (False, True):
+        try:
+            emu.set_precise(precise)
+            subs = np.asarray([e.one_path(w, h, x, y, sub, s) for sub in range(4)], dtype=np.float64)
+        finally:
+            emu.set_precise(False)
+        assert np.isfinite(subs).all() and subs[2].min() > 0.0, subs
+        assert np.abs(subs.sum(axis=0) - ref).max() <= (1e-6 if precise else 1e-5), (precise, subs.sum(axis=0), ref)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_scenes_path_by_path(ha, orc, emu, seed):
     """Fuzz tier (tests/random_scenes.py): every element kind x surface type x textured / constant parameters, overlapping and nested —

@@ -1458,6 +1458,26 @@ def test_precise_shading_defaults_and_finite_radiance(gpu, scenes):
         gpu.set_option("precise_shading", -1)
 
 
+@pytest.mark.parametrize("precise", [0, 1])
+def test_ggx_nee_sample_exactly_at_the_horizon_adds_nothing(gpu, scenes, precise):
+    """The non-finite pixel tools/finite_soak.py found (every scene at 1920x1080 x 1,024 samplings, both shading modes): cornell_mini, sampling
+    732, pixel (1394, 371) — a GGX hit whose NEE sample lies EXACTLY on the horizon of the shaded face after fp32 rounding (l.n = +0: 0 / 0 in
+    material.rs:64-89's expression; tests/test_emu_parity.py has the path on the host).  The sampling is finite and the pixel is the oracle's."""
+    sc, o = scenes("cornell_mini")
+    gpu.upload_scene(sc)
+    gpu.set_resolution(1920, 1080)
+    gpu.set_option("precise_shading", precise)
+    try:
+        gpu.clear()
+        gpu.render(732, 733)
+        acc = gpu.read_accumulator().copy()
+    finally:
+        gpu.set_option("precise_shading", -1)
+    assert np.isfinite(acc).all()
+    ref = o.render_region(1920, 1080, 1394, 371, 1, 1, 732, 733, threads=1)[0, 0]
+    assert np.abs(acc[371, 1394].astype(np.float64) - ref).max() <= 1e-4, (acc[371, 1394], ref)
+
+
 def test_config5_full_length_through_the_cli(tmp_path, scenes, orc):
     """BASELINE config 5 end to end at its FULL length on one GPU: `hanamaru-hip --scene rtcamp6_dodeca -w 3840 -h 2160 -s 1024` —
     3.4e10 paths (half a minute), the reference's log lines, and the 4K PNG that comes out of accumulate -> Reinhard -> gamma ->

@@ -70,6 +70,7 @@ bash tools/ab/precise_limits.sh 2>/dev/null | grep precise > $OUT/${TAG}_precise
   python tools/ab/split_ab.py --modes 0,3,2 --scenes spheres,rtcamp6_v3_1 --opt draw_residuals=0 2>&1 | grep -v libdrm ) > $OUT/${TAG}_precise_draw_residuals_ab.txt
 python -m pytest tests -m gpu -q -s -k "precise or variants or path_draws" 2>&1 | grep -E "precise|passed|failed" > $OUT/${TAG}_precise_tests_gpu.txt
 bash tools/ab/cli_batch.sh > $OUT/${TAG}_cli_report_granularity.txt 2>&1
+python tools/finite_soak.py 1024 2>/dev/null > $OUT/${TAG}_finite_soak_all_scenes_1024.txt
 ( echo "# python tools/reference_image_compare.py: hr_render of samplings 1 .. 1000 at 1920x1080 + hr_resolve against tests/golden/reference_rtcamp6_1000x4spp.png"; python tools/reference_image_compare.py 2>/dev/null ) > $OUT/${TAG}_reference_image_compare.txt
 python bench.py --precise --spp-per-step 16 --steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_precise.json.log 2>> $OUT/bench_full.err
 python bench.py --no-precise --scene spheres --steps 4 --spp-per-step 16 --no-cpu-baseline > $OUT/${TAG}_bench_c2_spheres_fp32_shading.json.log 2>> $OUT/bench_full.err
