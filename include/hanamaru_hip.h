@@ -258,7 +258,7 @@ int hr_get_stats(hr_ctx *ctx, hr_stats *out);
  *                   reference: the paths that take the reference's branches and still differ by more than 1e-3 — refraction chains through
  *                   faceted glass, bounces off small spheres, GGX lobes driven by a roughness map — fall from 90 - 990 per million to 0 - 6
  *                   (BASELINE config 2: none in 10^6 paths, worst path 4e-5).  Two implementations that render the same bits:
- *                   in the megakernel at 128 VGPRs (1.9 - 3.7 % slower on scenes without meshes) and in the split pipeline's shading kernel
+ *                   in the megakernel at 128 VGPRs (2 - 4 % slower on scenes without meshes) and in the split pipeline's shading kernel
  *                   (7 - 30 % on mesh scenes); the library takes the faster one for the scene.
  *                   -1 (default) = automatic: ON for scenes without triangle meshes (BASELINE config 2: small spheres are what multiplies an
  *                   fp32 ray's error, and there it costs little), OFF for the others; 0 = off; 1 = on.  hr_stats.shading_in_force says
