@@ -257,6 +257,11 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, MINW) void trace_kernel(Scene sc,
 // of the launch): one wave per tile, lane j = (pixel of the tile, sub-sample) as everywhere; the lane adds up its slot of the num_k
 // records the trace kernel left (quad 0 of the hand-off record), the four sub-samples of a pixel are neighbouring lanes, and the lane
 // of sub-sample 0 adds the sum to the pixel — plain loads and stores, nothing else touches the accumulator while this runs.
+// A path's radiance enters the image through path_radiance_in(): a NaN adds nothing and an overflow adds 1e30 ("white" after Reinhard, and 4,096
+// of them still sum to a finite fp32).  Neither occurs in the reference's scenes (4,096-sampling soak of all of them: DESIGN.md §6.5); in random
+// scenes a near-mirror GGX from a roughness map's ~0 texel can overflow fp32's D term where the reference's f64 carries 1e29, and one NaN of an
+// approximate reciprocal was seen in 1.2e11 paths — one such path must not cost a pixel (and, through the bilateral filter, its neighbours).
+__device__ __forceinline__ float path_radiance_in(float x) { return x == x ? fminf(fmaxf(x, -1e30f), 1e30f) : 0.0f; }
 __global__ __launch_bounds__(256) void accumulate_kernel(RenderParams rp, const float *__restrict__ recs, float *__restrict__ accum) {
     const uint32_t lane = threadIdx.x & 63u, tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= rp.tiles_x * rp.tiles_y) return;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(RenderParams rp, const 
     float r = 0.0f, g = 0.0f, b = 0.0f;
     for (uint32_t k = 0; k < rp.num_k; k++) {
         const f4 v = valid ? src[(size_t)k * (REC_ITEM_FLOATS / 4u)] : f4{0.0f, 0.0f, 0.0f, 0.0f};
-        r += v.x; g += v.y; b += v.z;
+        r += path_radiance_in(v.x); g += path_radiance_in(v.y); b += path_radiance_in(v.z);
     }
     r += __shfl_xor(r, 1); g += __shfl_xor(g, 1); b += __shfl_xor(b, 1);
     r += __shfl_xor(r, 2); g += __shfl_xor(g, 2); b += __shfl_xor(b, 2);

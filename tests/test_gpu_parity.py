@@ -1478,6 +1478,33 @@ def test_ggx_nee_sample_exactly_at_the_horizon_adds_nothing(gpu, scenes, precise
     assert np.abs(acc[371, 1394].astype(np.float64) - ref).max() <= 1e-4, (acc[371, 1394], ref)
 
 
+@pytest.mark.parametrize("seed,precise", [(6438, 0), (6438, 1), (6219, 0)])
+def test_random_scenes_rendered_long_stay_finite(gpu, ha, seed, precise):
+    """tools/finite_fuzz.py (1,000 random scenes x 640x360 x 256 samplings x both shading modes) found two scenes with non-finite pixels: a
+    near-mirror GGX from a roughness map's ~0 texel whose NEE term overflows fp32 (seed 6438: +inf where the reference's f64 carries 1e29), and
+    one NaN of an approximate reciprocal (seed 6219, fp32 shading).  accumulate_kernel takes a path's radiance in through path_radiance_in: the
+    image stays finite, the overflowing path's pixel is white."""
+    import random_scenes
+    kw = dict(spheres=2, cuboids=1, meshes=1) if seed % 4 == 2 else dict(spheres=0, cuboids=6, meshes=2)
+    sc = random_scenes.build(ha, seed, **kw)
+    gpu.set_option("bvh_builder", seed % 3)
+    try:
+        gpu.upload_scene(sc)
+    finally:
+        gpu.set_option("bvh_builder", -1)
+    gpu.set_resolution(640, 360)
+    gpu.set_option("precise_shading", precise)
+    try:
+        gpu.clear()
+        gpu.render(1, 257)
+        acc = gpu.read_accumulator().copy()
+        img = gpu.resolve(256)
+    finally:
+        gpu.set_option("precise_shading", -1)
+    assert np.isfinite(acc).all() and acc.max() < 1e34
+    assert img.shape == (360, 640, 3)
+
+
 def test_config5_full_length_through_the_cli(tmp_path, scenes, orc):
     """BASELINE config 5 end to end at its FULL length on one GPU: `hanamaru-hip --scene rtcamp6_dodeca -w 3840 -h 2160 -s 1024` —
     3.4e10 paths (half a minute), the reference's log lines, and the 4K PNG that comes out of accumulate -> Reinhard -> gamma ->
